@@ -1,0 +1,171 @@
+/*
+ * tksmseq.h -- C-ABI of the MI355X-native TKSM `Seq` hot path (libtksmseq.so).
+ *
+ * This is the drop-in boundary for the path BASELINE.json names: TKSM's Seq exit module,
+ *   src/sequence.cpp:21-57  (Sequencer_module::impl::run -> embedded Python)
+ *   py/sequence.py:323-376  (main block: load reference + models, per-molecule loop, write)
+ *   py/tksm_badread.py      (Badread identity / error / q-score model)
+ * Every entry point below names the reference code it replaces (file:line into vpc-ccg/tksm).
+ * Plain pointers and sizes only; no C++ or torch types; no exceptions cross this boundary.
+ * All functions return TKSMSEQ_OK (0) or a TKSMSEQ_E* code; tksmseq_last_error() gives the text.
+ * A context is used from one host thread at a time and owns one HIP device + stream.
+ *
+ * There is no CPU fallback: every compute entry point runs HIP kernels on gfx950 and fails with
+ * TKSMSEQ_EDEVICE when no device is usable.
+ */
+#ifndef TKSMSEQ_H
+#define TKSMSEQ_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TKSMSEQ_OK 0
+#define TKSMSEQ_EINVAL 1    /* bad argument / malformed input (reference: Python exception -> exit 1) */
+#define TKSMSEQ_EIO 2       /* file could not be read / written */
+#define TKSMSEQ_EDEVICE 3   /* HIP error or no device */
+#define TKSMSEQ_ENOMEM 4
+#define TKSMSEQ_ESTATE 5    /* call order violated (e.g. run before models are set) */
+#define TKSMSEQ_ELIMIT 6    /* input exceeds a documented limit of this build (molecule too long) */
+
+typedef struct tksmseq_ctx tksmseq_ctx;
+typedef struct tksmseq_batch tksmseq_batch;
+
+/* ---- lifetime ------------------------------------------------------------------------------
+ * Replaces Py_Initialize + module globals (src/python_runner.h:44-73, py/sequence.py:323-345). */
+int tksmseq_create(int device, tksmseq_ctx** out);
+void tksmseq_destroy(tksmseq_ctx* ctx);
+const char* tksmseq_last_error(const tksmseq_ctx* ctx);   /* ctx may be NULL: last create() error */
+const char* tksmseq_version(void);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = library stream. */
+int tksmseq_set_stream(tksmseq_ctx* ctx, void* hip_stream);
+int tksmseq_synchronize(tksmseq_ctx* ctx);
+
+/* ---- reference genome (S0) -------------------------------------------------------------------
+ * get_reference_seqs / generate_fasta, py/sequence.py:168-194: name = header up to the first
+ * space; later contigs with the same name replace earlier ones.  The library packs to 2 bit/base
+ * on the device (upper-cased; 4096-base blocks holding any non-ACGT byte are kept as bytes). */
+int tksmseq_reference_add_fasta(tksmseq_ctx* ctx, const char* path /* .fa / .fa.gz */);
+/* ascii: host pointer (on_device = 0) or device pointer (on_device = 1); caller keeps ownership. */
+int tksmseq_reference_add_contig(tksmseq_ctx* ctx, const char* name, const uint8_t* ascii, uint64_t len,
+                                 int on_device);
+int tksmseq_reference_contig_id(const tksmseq_ctx* ctx, const char* name);   /* -1 if absent */
+int tksmseq_reference_info(const tksmseq_ctx* ctx, uint64_t* n_contigs, uint64_t* total_bases,
+                           uint64_t* device_bytes);
+
+/* ---- models ----------------------------------------------------------------------------------
+ * ErrorModel.__init__/load_from_file + align_kmers, py/tksm_badread.py:76-117, :146-197.
+ * QScoreModel.__init__/load_from_file/random/ideal, py/tksm_badread.py:464-582.
+ * name_or_path: "random" (both), "ideal" (q-score), a model name resolved through $TKSM_MODELS
+ * (colon list, <dir>/badread/<name>.{error,qscore}.gz, py/sequence.py:17-31) or a file path. */
+int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path);
+int tksmseq_load_qscore_model(tksmseq_ctx* ctx, const char* name_or_path);
+/* Identities.__init__ + beta_parameters, py/tksm_badread.py:703-757 (percent units, as the CLI). */
+int tksmseq_set_identity(tksmseq_ctx* ctx, double mean, double max, double stdev);
+
+/* Table read-back (host copies) so tests can compare the packed layouts with the oracle's.
+ * Pass NULL for an array to query sizes only. */
+int tksmseq_get_error_model(const tksmseq_ctx* ctx, int32_t* type, int32_t* k, int32_t* max_alts,
+                            uint32_t* cdf, uint64_t* alts, uint8_t* nalts);
+int tksmseq_get_qscore_model(const tksmseq_ctx* ctx, int32_t* n_slots, int32_t* kmer_size, uint64_t* pool_len,
+                             uint64_t* keys, uint32_t* row_off, uint32_t* row_cnt, uint32_t* cdf_pool,
+                             uint8_t* q_pool);
+int tksmseq_get_identity(const tksmseq_ctx* ctx, int32_t* constant, double* value, double* beta_a,
+                         double* beta_b, double* qtab /* [65537] or NULL */);
+
+/* ---- molecule batches (MDF) ------------------------------------------------------------------
+ * mdf_generator, py/sequence.py:197-221: header '+id\tdepth\tcomment', interval lines with exactly
+ * 5 tab fields 'contig\tstart\tend\tstrand\tmods'; a molecule is emitted `depth` times.  A contig
+ * name absent from the reference is a literal sequence (py/sequence.py:307).
+ * Binary layout (what the kernels read; "algorithmic bytes" 8 + 16 S + 8 M per read):
+ *   reads      [n_reads]      {u32 ivl_begin, u32 ivl_count}
+ *   intervals  [n_intervals]  {u32 contig (bit31: literal index), u32 start, u32 end,
+ *                              u32 mod_begin | strand_minus << 31}
+ *   mods       [n_mods]       {u32 pos, u32 chr}
+ *   literals   [n_literals]   {u64 off, u64 len} into literal_pool
+ *   ids        [n_reads]      {u32 off, u32 len} into id_pool                                   */
+typedef struct {
+    uint64_t n_reads, n_intervals, n_mods, n_literals, literal_bytes, id_bytes;
+    const uint32_t* reads;        /* [n_reads][2] */
+    const uint32_t* intervals;    /* [n_intervals][4]; mods of interval i are [mod_begin_i, mod_begin_{i+1}) */
+    const uint32_t* mods;         /* [n_mods][2] */
+    const uint64_t* literals;     /* [n_literals][2] */
+    const uint8_t* literal_pool;
+    const uint32_t* ids;          /* [n_reads][2] */
+    const uint8_t* id_pool;
+} tksmseq_batch_desc;
+
+/* Copies host arrays to the device (validated first). */
+int tksmseq_batch_create(tksmseq_ctx* ctx, const tksmseq_batch_desc* host_desc, tksmseq_batch** out);
+/* Parses MDF text (whole file or a chunk ending at a molecule boundary) and uploads it. */
+int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out);
+int tksmseq_batch_info(const tksmseq_batch* b, uint64_t* n_reads, uint64_t* n_intervals, uint64_t* n_mods);
+void tksmseq_batch_free(tksmseq_ctx* ctx, tksmseq_batch* b);
+
+/* ---- the hot path ----------------------------------------------------------------------------
+ * One call = the body of the reference's per-molecule loop for every read of the batch:
+ * mdf_to_seq (py/sequence.py:303-320) -> perfect (:261-270) or badread (:242-258) ->
+ * sequence_fragment / get_qscores (py/tksm_badread.py:324-451, :607-655) -> fastq/fasta
+ * formatter (py/sequence.py:273-288).  Output records are concatenated in read order.
+ * Randomness is counter-based: it depends only on (seed, global read index), where
+ * global index = first_read_index + i * read_index_stride for read i of the batch. */
+#define TKSMSEQ_MODE_PERFECT 0
+#define TKSMSEQ_MODE_BADREAD 1
+typedef struct {
+    uint64_t seed;
+    uint64_t first_read_index;
+    uint64_t read_index_stride;   /* 0 is treated as 1 */
+    int32_t mode;                 /* TKSMSEQ_MODE_* */
+    int32_t fastq;                /* 1: '@id info\nSEQ\n+\nQUAL\n'   0: '>id info\nSEQ\n' */
+    int32_t compute_qual;         /* badread only: 0 = all 'K' (--skip-qual-compute) */
+    int32_t collect_stats;        /* 1: fill the per-read debug statistics (tests) */
+    int32_t perfect_of_badread;   /* badread only: format the badread sequence the way perfect() does (quals 'K',
+                                     error_free_length = length, identity 100.00%).  This is what the reference
+                                     writes to --perfect when -o is given too (py/sequence.py:317-319 rebinds
+                                     `seq`); the CLI uses it to reproduce that behaviour. */
+    int32_t reserved;
+} tksmseq_run_params;
+
+typedef struct {
+    const void* records;          /* device pointer, records_bytes bytes */
+    const void* record_offsets;   /* device u64[n_reads + 1] */
+    uint64_t records_bytes;
+    uint64_t n_reads;
+    uint64_t bases_in;            /* error-free bases (sum of spliced lengths) */
+    uint64_t bases_out;           /* emitted bases */
+    float kernel_ms[8];           /* per-stage device time of this call, 0 if timing off */
+} tksmseq_result;
+
+int tksmseq_run(tksmseq_ctx* ctx, const tksmseq_batch* batch, const tksmseq_run_params* params,
+                tksmseq_result* result);
+/* Caller-provided device buffer for the record stream (e.g. a torch tensor); NULL restores the
+ * library-owned buffer.  tksmseq_run fails with TKSMSEQ_ENOMEM if it is too small. */
+int tksmseq_set_output_buffer(tksmseq_ctx* ctx, void* device_ptr, uint64_t capacity);
+int tksmseq_set_timing(tksmseq_ctx* ctx, int enable);   /* hipEvent per stage, read via result.kernel_ms */
+/* Copies the last result to host memory (records: records_bytes, offsets: n_reads + 1). */
+int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets);
+/* Per-read debug statistics of the last badread run with collect_stats = 1: int32[n_reads][16]
+ * {n_draws, change_count, n_aligns, frag_len, new_len, start_trim, end_trim, status, ...} +
+ * double[n_reads][2] {errors, target_identity}. */
+int tksmseq_stats_download(tksmseq_ctx* ctx, int32_t* istats, double* dstats);
+
+/* ---- multi-GPU record ordering (S7) ----------------------------------------------------------
+ * Interleaves P per-rank record streams (rank p holds global reads p, p+P, p+2P, ...) into global
+ * read order on the device: dst gets sum(len) bytes.  Used after an RCCL gather on rank 0.
+ * streams[p] / offsets[p] are device pointers (u64 offsets[n_p + 1]). */
+int tksmseq_interleave_records(tksmseq_ctx* ctx, int n_ranks, const void* const* streams,
+                               const void* const* offsets, const uint64_t* n_reads_per_rank,
+                               void* dst, uint64_t dst_capacity, uint64_t* dst_bytes);
+
+/* ---- the module entry point ------------------------------------------------------------------
+ * int Sequencer_module::run() (src/sequence.cpp:30-54, src/pimpl.h:5-9) with the CLI of
+ * py/sequence.py:34-165; argv[0] is "sequence" as in src/tksm.cpp:164-166.  Returns the process
+ * exit code (0 ok, 1 argument / input error). */
+int tksmseq_sequence_main(int argc, char** argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

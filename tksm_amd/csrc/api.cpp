@@ -1,0 +1,609 @@
+// api.cpp -- implementation of the C-ABI in include/tksmseq.h (host orchestration of the HIP path).
+// No CPU fallback exists here: every compute call launches the kernels of kernels.hip.
+#include "../../include/tksmseq.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "host.h"
+#include "kernels.h"
+
+using namespace tkh;
+
+static thread_local std::string g_create_error;
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return TKSMSEQ_EDEVICE;                                                               \
+        }                                                                                         \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
+        if (bytes <= cap) return hipSuccess;
+        size_t ncap = std::max(bytes, cap + cap / 2);
+        ncap = (ncap + 255) & ~(size_t)255;
+        void* np = nullptr;
+        hipError_t e = hipMalloc(&np, ncap);
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { (void)hipFree(np); return e; }
+        }
+        if (p) (void)hipFree(p);
+        p = np; cap = ncap;
+        return hipSuccess;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+}  // namespace
+
+struct tksmseq_batch {
+    uint64_t n_reads = 0, n_intervals = 0, n_mods = 0, n_literals = 0;
+    DevBuf reads, intervals, mods, literals, litpool, ids, idpool;
+    std::vector<uint32_t> raw_len;       // host copy, for sizing
+    uint32_t max_raw = 0;
+    uint64_t total_raw = 0;
+    // cached scratch sizing, keyed by (k, cap_num, cap_den, cap_add)
+    int cache_k = -1, cache_num = 0, cache_den = 0, cache_add = 0;
+    uint64_t cache_scratch = 0;
+};
+
+struct tksmseq_ctx : ContigLookup {
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // reference
+    std::vector<std::string> contig_names;
+    std::unordered_map<std::string, int> contig_index;
+    std::vector<uint64_t> contigs;        // {gstart, len}
+    uint64_t total_alloc = 0;             // bases allocated in the global coordinate (block aligned)
+    uint64_t total_bases = 0;
+    uint32_t pool_blocks = 0;
+    DevBuf d_packed, d_blocktab, d_pool, d_contigs, d_stage;
+
+    // models
+    ErrorModelHost em; QScoreModelHost qm; IdentityHost idm;
+    DevBuf d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab;
+
+    // per-run work buffers
+    DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
+        w_scratch, w_records, w_istats, w_dstats, w_sums;
+    void* user_out = nullptr; uint64_t user_out_cap = 0;
+    bool timing = false;
+    hipEvent_t ev[6] = {};
+    tksmseq_result last{};
+    bool have_last = false, have_stats = false;
+
+    int find(const std::string& name) const override {
+        auto it = contig_index.find(name);
+        return it == contig_index.end() ? -1 : it->second;
+    }
+};
+
+template <class T>
+static int upload(tksmseq_ctx* ctx, DevBuf& b, const std::vector<T>& v) {
+    HIPCHK(ctx, b.ensure(v.size() * sizeof(T) + 16));
+    if (!v.empty()) HIPCHK(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TKSMSEQ_OK;
+}
+
+extern "C" {
+
+const char* tksmseq_version(void) { return "tksm-amd seq 0.1 (gfx950)"; }
+
+int tksmseq_create(int device, tksmseq_ctx** out) {
+    if (!out) return TKSMSEQ_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = "no HIP device available (this library has no CPU fallback)"; return TKSMSEQ_EDEVICE; }
+    if (device < 0 || device >= n) { g_create_error = "device index out of range"; return TKSMSEQ_EINVAL; }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return TKSMSEQ_EDEVICE; }
+    std::unique_ptr<tksmseq_ctx> c(new tksmseq_ctx());
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return TKSMSEQ_EDEVICE; }
+    c->own_stream = true;
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    *out = c.release();
+    return TKSMSEQ_OK;
+}
+
+void tksmseq_destroy(tksmseq_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* tksmseq_last_error(const tksmseq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int tksmseq_set_stream(tksmseq_ctx* ctx, void* s) {
+    if (!ctx) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (s) { ctx->stream = (hipStream_t)s; ctx->own_stream = false; }
+    else { HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_synchronize(tksmseq_ctx* ctx) {
+    if (!ctx) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_set_timing(tksmseq_ctx* ctx, int enable) { if (!ctx) return TKSMSEQ_EINVAL; ctx->timing = enable != 0; return TKSMSEQ_OK; }
+
+// ------------------------------------------------------------------------------------------- reference
+int tksmseq_reference_add_contig(tksmseq_ctx* ctx, const char* name, const uint8_t* ascii, uint64_t len, int on_device) {
+    if (!ctx || !name || (!ascii && len)) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t BLK = 1ull << tk::BLOCK_SHIFT;
+    const uint64_t gstart = ctx->total_alloc;
+    const uint64_t nblk = (len + BLK - 1) / BLK;
+    if (gstart + nblk * BLK > (1ull << 44)) { ctx->err = "reference larger than 2^44 bases"; return TKSMSEQ_ELIMIT; }
+    HIPCHK(ctx, ctx->d_packed.ensure(((gstart + nblk * BLK) >> 4) * 4 + 64, true, ctx->stream));
+    HIPCHK(ctx, ctx->d_blocktab.ensure(((gstart >> tk::BLOCK_SHIFT) + nblk) * 4 + 64, true, ctx->stream));
+    uint32_t* blocktab = ctx->d_blocktab.as<uint32_t>() + (gstart >> tk::BLOCK_SHIFT);
+    const uint64_t CH = 64ull << 20;   // staging chunk (multiple of the block size)
+    std::vector<uint32_t> flags;
+    for (uint64_t off = 0; off < len; off += CH) {
+        const uint64_t n = std::min(CH, len - off);
+        const uint64_t cb = (n + BLK - 1) / BLK;
+        const uint8_t* dsrc;
+        if (on_device) dsrc = ascii + off;
+        else {
+            HIPCHK(ctx, ctx->d_stage.ensure(CH));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage.p, ascii + off, n, hipMemcpyHostToDevice, ctx->stream));
+            dsrc = ctx->d_stage.as<uint8_t>();
+        }
+        uint32_t* bt = blocktab + (off >> tk::BLOCK_SHIFT);
+        HIPCHK(ctx, hipMemsetAsync(bt, 0, cb * 4, ctx->stream));
+        HIPCHK(ctx, tk::launch_pack(dsrc, n, gstart + off, ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->stream));
+        flags.resize(cb);
+        HIPCHK(ctx, hipMemcpyAsync(flags.data(), bt, cb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t newblocks = 0;
+        for (auto& f : flags) { if (f) { f = ctx->pool_blocks + newblocks; newblocks++; } else f = tk::NO_BLOCK; }
+        HIPCHK(ctx, hipMemcpyAsync(bt, flags.data(), cb * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (newblocks) {
+            HIPCHK(ctx, ctx->d_pool.ensure((uint64_t)(ctx->pool_blocks + newblocks) * BLK, true, ctx->stream));
+            HIPCHK(ctx, tk::launch_fill_pool(dsrc, n, gstart + off, ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(), ctx->stream));
+            ctx->pool_blocks += newblocks;
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // later contigs with the same name replace earlier ones (dict.update, py/sequence.py:193)
+    std::string nm(name);
+    auto it = ctx->contig_index.find(nm);
+    if (it == ctx->contig_index.end()) {
+        ctx->contig_index[nm] = (int)ctx->contig_names.size();
+        ctx->contig_names.push_back(nm);
+        ctx->contigs.push_back(gstart); ctx->contigs.push_back(len);
+    } else {
+        ctx->total_bases -= ctx->contigs[2 * it->second + 1];
+        ctx->contigs[2 * it->second] = gstart; ctx->contigs[2 * it->second + 1] = len;
+    }
+    ctx->total_alloc = gstart + nblk * BLK;
+    ctx->total_bases += len;
+    HIPCHK(ctx, ctx->d_contigs.ensure(ctx->contigs.size() * 8 + 16));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_contigs.p, ctx->contigs.data(), ctx->contigs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_reference_add_fasta(tksmseq_ctx* ctx, const char* path) {
+    if (!ctx || !path) return TKSMSEQ_EINVAL;
+    std::vector<FastaRecord> recs;
+    if (!read_fasta(path, recs, ctx->err)) return TKSMSEQ_EIO;
+    for (auto& r : recs) {
+        int rc = tksmseq_reference_add_contig(ctx, r.name.c_str(), (const uint8_t*)r.seq.data(), r.seq.size(), 0);
+        if (rc) return rc;
+    }
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_reference_contig_id(const tksmseq_ctx* ctx, const char* name) { return (!ctx || !name) ? -1 : ctx->find(name); }
+
+int tksmseq_reference_info(const tksmseq_ctx* ctx, uint64_t* n_contigs, uint64_t* total_bases, uint64_t* device_bytes) {
+    if (!ctx) return TKSMSEQ_EINVAL;
+    if (n_contigs) *n_contigs = ctx->contig_names.size();
+    if (total_bases) *total_bases = ctx->total_bases;
+    if (device_bytes) *device_bytes = (ctx->total_alloc >> 2) + (ctx->total_alloc >> tk::BLOCK_SHIFT) * 4 + ((uint64_t)ctx->pool_blocks << tk::BLOCK_SHIFT);
+    return TKSMSEQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------- models
+int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
+    if (!ctx || !name_or_path) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ErrorModelHost m;
+    if (!load_error_model(name_or_path, m, ctx->err)) return TKSMSEQ_EIO;
+    ctx->em = std::move(m);
+    int rc;
+    if ((rc = upload(ctx, ctx->d_cdf, ctx->em.cdf))) return rc;
+    if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
+    return upload(ctx, ctx->d_nalts, ctx->em.nalts);
+}
+
+int tksmseq_load_qscore_model(tksmseq_ctx* ctx, const char* name_or_path) {
+    if (!ctx || !name_or_path) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    QScoreModelHost m;
+    if (!load_qscore_model(name_or_path, m, ctx->err)) return TKSMSEQ_EIO;
+    ctx->qm = std::move(m);
+    int rc;
+    if ((rc = upload(ctx, ctx->d_qkeys, ctx->qm.keys))) return rc;
+    if ((rc = upload(ctx, ctx->d_qoff, ctx->qm.row_off))) return rc;
+    if ((rc = upload(ctx, ctx->d_qcnt, ctx->qm.row_cnt))) return rc;
+    if ((rc = upload(ctx, ctx->d_qcdf, ctx->qm.cdf_pool))) return rc;
+    return upload(ctx, ctx->d_qq, ctx->qm.q_pool);
+}
+
+int tksmseq_set_identity(tksmseq_ctx* ctx, double mean, double max, double stdev) {
+    if (!ctx) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    IdentityHost id;
+    if (!make_identity(mean, max, stdev, id, ctx->err)) return TKSMSEQ_EINVAL;
+    id.set = true;
+    ctx->idm = std::move(id);
+    if (!ctx->idm.constant) return upload(ctx, ctx->d_qtab, ctx->idm.qtab);
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_get_error_model(const tksmseq_ctx* ctx, int32_t* type, int32_t* k, int32_t* max_alts, uint32_t* cdf, uint64_t* alts, uint8_t* nalts) {
+    if (!ctx || ctx->em.type < 0) return TKSMSEQ_ESTATE;
+    if (type) *type = ctx->em.type;
+    if (k) *k = ctx->em.k;
+    if (max_alts) *max_alts = ctx->em.max_alts;
+    if (cdf) memcpy(cdf, ctx->em.cdf.data(), ctx->em.cdf.size() * 4);
+    if (alts) memcpy(alts, ctx->em.alts.data(), ctx->em.alts.size() * 8);
+    if (nalts) memcpy(nalts, ctx->em.nalts.data(), ctx->em.nalts.size());
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_get_qscore_model(const tksmseq_ctx* ctx, int32_t* n_slots, int32_t* kmer_size, uint64_t* pool_len, uint64_t* keys,
+                             uint32_t* row_off, uint32_t* row_cnt, uint32_t* cdf_pool, uint8_t* q_pool) {
+    if (!ctx || ctx->qm.n_slots == 0) return TKSMSEQ_ESTATE;
+    if (n_slots) *n_slots = ctx->qm.n_slots;
+    if (kmer_size) *kmer_size = ctx->qm.kmer_size;
+    if (pool_len) *pool_len = ctx->qm.q_pool.size();
+    if (keys) memcpy(keys, ctx->qm.keys.data(), ctx->qm.keys.size() * 8);
+    if (row_off) memcpy(row_off, ctx->qm.row_off.data(), ctx->qm.row_off.size() * 4);
+    if (row_cnt) memcpy(row_cnt, ctx->qm.row_cnt.data(), ctx->qm.row_cnt.size() * 4);
+    if (cdf_pool) memcpy(cdf_pool, ctx->qm.cdf_pool.data(), ctx->qm.cdf_pool.size() * 4);
+    if (q_pool) memcpy(q_pool, ctx->qm.q_pool.data(), ctx->qm.q_pool.size());
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_get_identity(const tksmseq_ctx* ctx, int32_t* constant, double* value, double* beta_a, double* beta_b, double* qtab) {
+    if (!ctx || !ctx->idm.set) return TKSMSEQ_ESTATE;
+    if (constant) *constant = ctx->idm.constant ? 1 : 0;
+    if (value) *value = ctx->idm.value;
+    if (beta_a) *beta_a = ctx->idm.beta_a;
+    if (beta_b) *beta_b = ctx->idm.beta_b;
+    if (qtab && !ctx->idm.constant) memcpy(qtab, ctx->idm.qtab.data(), 65537 * sizeof(double));
+    return TKSMSEQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------- batches
+static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmseq_batch** out) {
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (d->n_intervals >= 0x7fffffffull || d->n_mods >= 0x7fffffffull || d->n_reads >= 0xffffffffull) {
+        ctx->err = "batch too large (split it: < 2^31 intervals/mods per batch)"; return TKSMSEQ_ELIMIT;
+    }
+    std::unique_ptr<tksmseq_batch> b(new tksmseq_batch());
+    b->n_reads = d->n_reads; b->n_intervals = d->n_intervals; b->n_mods = d->n_mods; b->n_literals = d->n_literals;
+    // validate + host-side raw lengths (python slice clamp, py/sequence.py:307)
+    std::vector<uint32_t> ilen(d->n_intervals);
+    const uint64_t nc = ctx->contig_names.size();
+    uint32_t prev_mod = 0;
+    for (uint64_t i = 0; i < d->n_intervals; i++) {
+        const uint32_t* iv = d->intervals + 4 * i;
+        uint64_t clen;
+        if (iv[0] >> 31) {
+            uint32_t li = iv[0] & 0x7fffffffu;
+            if (li >= d->n_literals) { ctx->err = "interval refers to a literal that does not exist"; return TKSMSEQ_EINVAL; }
+            clen = d->literals[2 * li + 1];
+            if (d->literals[2 * li] + clen > d->literal_bytes) { ctx->err = "literal outside the literal pool"; return TKSMSEQ_EINVAL; }
+        } else {
+            if (iv[0] >= nc) { ctx->err = "interval refers to a contig that does not exist"; return TKSMSEQ_EINVAL; }
+            clen = ctx->contigs[2 * (uint64_t)iv[0] + 1];
+        }
+        const uint64_t s = std::min<uint64_t>(iv[1], clen), e = std::min<uint64_t>(iv[2], clen);
+        ilen[i] = e > s ? (uint32_t)(e - s) : 0;
+        const uint32_t mb = iv[3] & 0x7fffffffu;
+        if (mb < prev_mod || mb > d->n_mods) { ctx->err = "interval modification offsets are not monotone"; return TKSMSEQ_EINVAL; }
+        prev_mod = mb;
+    }
+    // the reference raises IndexError for a modification outside its slice (py/sequence.py:238)
+    for (uint64_t i = 0; i < d->n_intervals; i++) {
+        const uint32_t mb = d->intervals[4 * i + 3] & 0x7fffffffu;
+        const uint32_t me = i + 1 < d->n_intervals ? (d->intervals[4 * (i + 1) + 3] & 0x7fffffffu) : (uint32_t)d->n_mods;
+        for (uint32_t m = mb; m < me; m++)
+            if (d->mods[2 * (uint64_t)m] >= ilen[i]) { ctx->err = "modification position outside its interval (the reference raises IndexError)"; return TKSMSEQ_EINVAL; }
+    }
+    b->raw_len.resize(d->n_reads);
+    for (uint64_t r = 0; r < d->n_reads; r++) {
+        const uint32_t ib = d->reads[2 * r], ic = d->reads[2 * r + 1];
+        if ((uint64_t)ib + ic > d->n_intervals) { ctx->err = "read refers to intervals that do not exist"; return TKSMSEQ_EINVAL; }
+        uint64_t t = 0;
+        for (uint32_t i = 0; i < ic; i++) t += ilen[ib + i];
+        if (t > 0x7fffff00ull) { ctx->err = "molecule longer than 2^31 bases"; return TKSMSEQ_ELIMIT; }
+        b->raw_len[r] = (uint32_t)t;
+        b->max_raw = std::max(b->max_raw, (uint32_t)t);
+        b->total_raw += t;
+        if ((uint64_t)d->ids[2 * r] + d->ids[2 * r + 1] > d->id_bytes) { ctx->err = "molecule id outside the id pool"; return TKSMSEQ_EINVAL; }
+    }
+    auto up = [&](DevBuf& buf, const void* src, size_t bytes) -> int {
+        HIPCHK(ctx, buf.ensure(bytes + 64));
+        if (bytes) HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return TKSMSEQ_OK;
+    };
+    int rc;
+    if ((rc = up(b->reads, d->reads, d->n_reads * 8))) return rc;
+    // intervals + sentinel carrying n_mods
+    std::vector<uint32_t> iv(d->intervals, d->intervals + 4 * d->n_intervals);
+    iv.push_back(0); iv.push_back(0); iv.push_back(0); iv.push_back((uint32_t)d->n_mods);
+    if ((rc = up(b->intervals, iv.data(), iv.size() * 4))) return rc;
+    if ((rc = up(b->mods, d->mods, d->n_mods * 8))) return rc;
+    if ((rc = up(b->literals, d->literals, d->n_literals * 16))) return rc;
+    if ((rc = up(b->litpool, d->literal_pool, d->literal_bytes))) return rc;
+    if ((rc = up(b->ids, d->ids, d->n_reads * 8))) return rc;
+    if ((rc = up(b->idpool, d->id_pool, d->id_bytes))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = b.release();
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_batch_create(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmseq_batch** out) {
+    if (!ctx || !d || !out) return TKSMSEQ_EINVAL;
+    return batch_from_host(ctx, d, out);
+}
+
+int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out) {
+    if (!ctx || (!text && len) || !out) return TKSMSEQ_EINVAL;
+    BatchHost h;
+    if (!parse_mdf(text, len, *ctx, h, ctx->err)) return TKSMSEQ_EINVAL;
+    tksmseq_batch_desc d{};
+    d.n_reads = h.reads.size() / 2; d.n_intervals = h.intervals.size() / 4; d.n_mods = h.mods.size() / 2;
+    d.n_literals = h.literals.size() / 2; d.literal_bytes = h.literal_pool.size(); d.id_bytes = h.id_pool.size();
+    d.reads = h.reads.data(); d.intervals = h.intervals.data(); d.mods = h.mods.data(); d.literals = h.literals.data();
+    d.literal_pool = h.literal_pool.data(); d.ids = h.ids.data(); d.id_pool = h.id_pool.data();
+    return batch_from_host(ctx, &d, out);
+}
+
+int tksmseq_batch_info(const tksmseq_batch* b, uint64_t* n_reads, uint64_t* n_intervals, uint64_t* n_mods) {
+    if (!b) return TKSMSEQ_EINVAL;
+    if (n_reads) *n_reads = b->n_reads;
+    if (n_intervals) *n_intervals = b->n_intervals;
+    if (n_mods) *n_mods = b->n_mods;
+    return TKSMSEQ_OK;
+}
+
+void tksmseq_batch_free(tksmseq_ctx* ctx, tksmseq_batch* b) {
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    delete b;
+}
+
+// ------------------------------------------------------------------------------------------- run
+int tksmseq_set_output_buffer(tksmseq_ctx* ctx, void* p, uint64_t cap) {
+    if (!ctx) return TKSMSEQ_EINVAL;
+    ctx->user_out = p; ctx->user_out_cap = p ? cap : 0;
+    return TKSMSEQ_OK;
+}
+
+static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params* p, int cap_num, int cap_den, int cap_add,
+                    tksmseq_result* res, bool* overflow) {
+    *overflow = false;
+    const uint64_t n = b->n_reads;
+    hipStream_t s = ctx->stream;
+    const bool badread = p->mode == TKSMSEQ_MODE_BADREAD;
+    const int k = badread ? ctx->em.k : 0;
+    auto align16 = [](uint64_t v) { return (v + 15) & ~15ull; };
+    auto capf = [&](uint64_t raw) { return align16((raw + 2 * (uint64_t)k) * cap_num / cap_den + cap_add); };
+    if (b->cache_k != k || b->cache_num != cap_num || b->cache_den != cap_den || b->cache_add != cap_add) {
+        uint64_t t = 0;
+        for (uint32_t rl : b->raw_len) t += 2 * capf(rl);
+        b->cache_scratch = t; b->cache_k = k; b->cache_num = cap_num; b->cache_den = cap_den; b->cache_add = cap_add;
+    }
+    // LDS geometry from the longest molecule of the batch
+    const int lcap = (int)((b->max_raw + 2 * k + 3) & ~3u);
+    const int ncap = badread ? (int)capf(b->max_raw) : 4;
+    int wpw = tk::WAVES_PER_WG;
+    while (wpw > 1 && tk::simulate_lds_bytes(lcap, ncap, wpw) > 160 * 1024) wpw >>= 1;
+    const int lds = tk::simulate_lds_bytes(lcap, ncap, wpw);
+    if (lds > 160 * 1024 || ncap >= 65000 || lcap >= 65000) {
+        ctx->err = "molecule of " + std::to_string(b->max_raw) + " bases exceeds the LDS-resident limit of this build";
+        return TKSMSEQ_ELIMIT;
+    }
+    int wgs_per_cu = std::min(std::min(32 / wpw, 16), std::max(1, (160 * 1024) / std::max(lds, 1)));
+    const uint64_t want = (n + wpw - 1) / wpw;
+    const int n_wgs = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->n_cus * wgs_per_cu));
+    const int trace_words = ((lcap >> 4) + 2) * 64;
+
+    HIPCHK(ctx, ctx->w_rawlen.ensure(n * 4 + 16));
+    HIPCHK(ctx, ctx->w_slotcap.ensure(n * 8 + 16));
+    HIPCHK(ctx, ctx->w_slotoff.ensure((n + 1) * 8 + 16));
+    HIPCHK(ctx, ctx->w_outlen.ensure(n * 4 + 16));
+    HIPCHK(ctx, ctx->w_ident.ensure(n * 8 + 16));
+    HIPCHK(ctx, ctx->w_reclen.ensure(n * 8 + 16));
+    HIPCHK(ctx, ctx->w_recoff.ensure((n + 1) * 8 + 16));
+    HIPCHK(ctx, ctx->w_status.ensure(n * 4 + 16));
+    HIPCHK(ctx, ctx->w_scan.ensure(tk::scan_temp_bytes(n) + 64));
+    HIPCHK(ctx, ctx->w_trace.ensure((size_t)n_wgs * wpw * trace_words * 4 + 64));
+    HIPCHK(ctx, ctx->w_counter.ensure(64));
+    HIPCHK(ctx, ctx->w_sums.ensure(64));
+    HIPCHK(ctx, ctx->w_scratch.ensure(b->cache_scratch + 64));
+    if (p->collect_stats) {
+        HIPCHK(ctx, ctx->w_istats.ensure(n * 64 + 16));
+        HIPCHK(ctx, ctx->w_dstats.ensure(n * 16 + 16));
+        HIPCHK(ctx, hipMemsetAsync(ctx->w_istats.p, 0, n * 64, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->w_dstats.p, 0, n * 16, s));
+    }
+
+    tk::BatchView B{b->reads.as<uint32_t>(), b->intervals.as<uint32_t>(), b->mods.as<uint32_t>(), b->literals.as<uint64_t>(),
+                    b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), n, (uint32_t)b->n_literals};
+    tk::RefView R{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
+                  ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>()};
+    tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
+                       ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>()};
+    tk::IdentView IM{ctx->idm.constant ? 1 : 0, ctx->idm.value, ctx->d_qtab.as<double>()};
+    tk::SimParams P{};
+    P.seed = p->seed; P.first_read = p->first_read_index; P.stride = p->read_index_stride ? p->read_index_stride : 1;
+    P.mode = badread ? 1 : 0; P.fastq = p->fastq ? 1 : 0;
+    P.quirk_perfect = (badread && p->perfect_of_badread) ? 1 : 0;
+    P.compute_q = (badread && p->compute_qual && p->fastq && !P.quirk_perfect) ? 1 : 0;
+    P.lcap = lcap; P.ncap = ncap; P.trace_words = trace_words; P.cap_num = cap_num; P.cap_den = cap_den; P.cap_add = cap_add;
+    tk::SimBuffers O{};
+    O.raw_len = ctx->w_rawlen.as<uint32_t>(); O.slot_off = ctx->w_slotoff.as<uint64_t>(); O.scratch = ctx->w_scratch.as<uint8_t>();
+    O.out_len = ctx->w_outlen.as<uint32_t>(); O.identity = ctx->w_ident.as<double>(); O.rec_len = ctx->w_reclen.as<uint64_t>();
+    O.status = ctx->w_status.as<uint32_t>(); O.trace = ctx->w_trace.as<uint32_t>();
+    O.work_counter = ctx->w_counter.as<unsigned long long>();
+    O.istats = p->collect_stats ? ctx->w_istats.as<int32_t>() : nullptr;
+    O.dstats = p->collect_stats ? ctx->w_dstats.as<double>() : nullptr;
+
+    const bool T = ctx->timing;
+    if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->w_counter.p, 0, 8, s));
+    HIPCHK(ctx, tk::launch_read_lengths(B, R, k, cap_num, cap_den, cap_add, ctx->w_rawlen.as<uint32_t>(), ctx->w_slotcap.as<uint64_t>(),
+                                        ctx->w_status.as<uint32_t>(), s));
+    HIPCHK(ctx, tk::launch_scan(ctx->w_slotcap.as<uint64_t>(), ctx->w_slotoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
+    if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+    HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O, n_wgs, wpw, s));
+    if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+    HIPCHK(ctx, tk::launch_scan(ctx->w_reclen.as<uint64_t>(), ctx->w_recoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
+    unsigned long long* sums = ctx->w_sums.as<unsigned long long>();
+    HIPCHK(ctx, tk::launch_sum_u32(ctx->w_status.as<uint32_t>(), n, sums, s));
+    HIPCHK(ctx, tk::launch_sum_u32(ctx->w_outlen.as<uint32_t>(), n, sums + 1, s));
+    if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+    unsigned long long hs[2] = {0, 0}; uint64_t total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->w_recoff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (hs[0]) {
+        std::vector<uint32_t> st(n);
+        HIPCHK(ctx, hipMemcpy(st.data(), ctx->w_status.p, n * 4, hipMemcpyDeviceToHost));
+        uint32_t any = 0; uint64_t first = 0;
+        for (uint64_t i = 0; i < n; i++) if (st[i]) { if (!any) first = i; any |= st[i]; }
+        if (any & 2) { ctx->err = "modification position outside its interval at read " + std::to_string(first); return TKSMSEQ_EINVAL; }
+        if (any & 4) { ctx->err = "internal: alignment band failure at read " + std::to_string(first); return TKSMSEQ_EDEVICE; }
+        if (any & 1) { *overflow = true; return TKSMSEQ_OK; }
+    }
+    uint8_t* records;
+    if (ctx->user_out) {
+        if (total > ctx->user_out_cap) { ctx->err = "caller-provided output buffer too small: need " + std::to_string(total) + " bytes"; return TKSMSEQ_ENOMEM; }
+        records = (uint8_t*)ctx->user_out;
+    } else {
+        HIPCHK(ctx, ctx->w_records.ensure(total + 64));
+        records = ctx->w_records.as<uint8_t>();
+    }
+    HIPCHK(ctx, tk::launch_emit(B, P, O, ctx->w_recoff.as<uint64_t>(), records, s));
+    if (T) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev[4]));
+        for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&res->kernel_ms[i], ctx->ev[i], ctx->ev[i + 1]);
+        (void)hipEventElapsedTime(&res->kernel_ms[4], ctx->ev[0], ctx->ev[4]);
+    }
+    res->records = records; res->record_offsets = ctx->w_recoff.p; res->records_bytes = total; res->n_reads = n;
+    res->bases_in = b->total_raw; res->bases_out = hs[1];
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_run(tksmseq_ctx* ctx, const tksmseq_batch* batch, const tksmseq_run_params* p, tksmseq_result* result) {
+    if (!ctx || !batch || !p || !result) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(result, 0, sizeof(*result));
+    if (p->mode != TKSMSEQ_MODE_PERFECT && p->mode != TKSMSEQ_MODE_BADREAD) { ctx->err = "unknown mode"; return TKSMSEQ_EINVAL; }
+    if (p->mode == TKSMSEQ_MODE_BADREAD) {
+        if (ctx->em.type < 0) { ctx->err = "no error model loaded"; return TKSMSEQ_ESTATE; }
+        if (!ctx->idm.set) { ctx->err = "identity distribution not set"; return TKSMSEQ_ESTATE; }
+        if (p->compute_qual && p->fastq && ctx->qm.n_slots == 0) { ctx->err = "no q-score model loaded"; return TKSMSEQ_ESTATE; }
+    }
+    tksmseq_batch* b = const_cast<tksmseq_batch*>(batch);
+    bool overflow = false;
+    int rc = run_once(ctx, b, p, 3, 2, 64, result, &overflow);
+    if (rc == TKSMSEQ_OK && overflow) {
+        // insertion-heavy reads outgrew the default 1.5x slot: rerun with the worst-case factor
+        rc = run_once(ctx, b, p, 6, 1, 64, result, &overflow);
+        if (rc == TKSMSEQ_OK && overflow) { ctx->err = "internal: output slot overflow at the worst-case factor"; rc = TKSMSEQ_EDEVICE; }
+    }
+    if (rc == TKSMSEQ_OK) { ctx->last = *result; ctx->have_last = true; ctx->have_stats = p->collect_stats != 0; }
+    return rc;
+}
+
+int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets) {
+    if (!ctx || !ctx->have_last) return TKSMSEQ_ESTATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (records && ctx->last.records_bytes) HIPCHK(ctx, hipMemcpyAsync(records, ctx->last.records, ctx->last.records_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (offsets) HIPCHK(ctx, hipMemcpyAsync(offsets, ctx->last.record_offsets, (ctx->last.n_reads + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_stats_download(tksmseq_ctx* ctx, int32_t* istats, double* dstats) {
+    if (!ctx || !ctx->have_last || !ctx->have_stats) return TKSMSEQ_ESTATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (istats) HIPCHK(ctx, hipMemcpyAsync(istats, ctx->w_istats.p, ctx->last.n_reads * 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (dstats) HIPCHK(ctx, hipMemcpyAsync(dstats, ctx->w_dstats.p, ctx->last.n_reads * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TKSMSEQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------- interleave
+int tksmseq_interleave_records(tksmseq_ctx* ctx, int n_ranks, const void* const* streams, const void* const* offsets,
+                               const uint64_t* n_per_rank, void* dst, uint64_t dst_capacity, uint64_t* dst_bytes) {
+    if (!ctx || n_ranks < 1 || n_ranks > 16 || !streams || !offsets || !n_per_rank || !dst) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    uint64_t n_total = 0;
+    for (int i = 0; i < n_ranks; i++) {
+        // round-robin sharding: rank p holds ceil((N - p) / P) reads
+        n_total += n_per_rank[i];
+        if (i && n_per_rank[i] > n_per_rank[i - 1]) { ctx->err = "per-rank read counts are not a round-robin split"; return TKSMSEQ_EINVAL; }
+    }
+    if (n_per_rank[0] - n_per_rank[n_ranks - 1] > 1) { ctx->err = "per-rank read counts are not a round-robin split"; return TKSMSEQ_EINVAL; }
+    HIPCHK(ctx, ctx->w_reclen.ensure(n_total * 8 + 16));
+    HIPCHK(ctx, ctx->w_slotoff.ensure((n_total + 1) * 8 + 16));
+    HIPCHK(ctx, ctx->w_scan.ensure(tk::scan_temp_bytes(n_total) + 64));
+    HIPCHK(ctx, tk::launch_interleave_lens(n_ranks, (const uint64_t* const*)offsets, n_per_rank, n_total, ctx->w_reclen.as<uint64_t>(), ctx->stream));
+    HIPCHK(ctx, tk::launch_scan(ctx->w_reclen.as<uint64_t>(), ctx->w_slotoff.as<uint64_t>(), n_total, ctx->w_scan.p, ctx->w_scan.cap, ctx->stream));
+    uint64_t total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->w_slotoff.as<uint64_t>() + n_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (total > dst_capacity) { ctx->err = "interleave destination too small"; return TKSMSEQ_ENOMEM; }
+    HIPCHK(ctx, tk::launch_interleave_copy(n_ranks, (const uint8_t* const*)streams, (const uint64_t* const*)offsets, n_total,
+                                           ctx->w_slotoff.as<uint64_t>(), (uint8_t*)dst, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dst_bytes) *dst_bytes = total;
+    return TKSMSEQ_OK;
+}
+
+}  // extern "C"

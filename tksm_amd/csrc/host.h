@@ -1,0 +1,57 @@
+// host.h -- host-side data structures shared by the C-ABI implementation, the loaders and the CLI.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace tkh {
+
+struct ErrorModelHost {
+    int type = -1, k = 0, max_alts = 0;
+    std::vector<uint32_t> cdf;
+    std::vector<uint64_t> alts;
+    std::vector<uint8_t> nalts;
+};
+
+struct QScoreModelHost {
+    int n_slots = 0, kmer_size = 1;
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> row_off, row_cnt, cdf_pool;
+    std::vector<uint8_t> q_pool;
+};
+
+struct IdentityHost {
+    bool set = false, constant = true;
+    double mean = 0, stdev = 0, max_identity = 0, value = 0, beta_a = 0, beta_b = 0;
+    std::vector<double> qtab;
+};
+
+// host image of a molecule batch in the binary layout of include/tksmseq.h
+struct BatchHost {
+    std::vector<uint32_t> reads;       // [n][2]
+    std::vector<uint32_t> intervals;   // [n][4] (no sentinel)
+    std::vector<uint32_t> mods;        // [n][2]
+    std::vector<uint64_t> literals;    // [n][2]
+    std::vector<uint8_t> literal_pool;
+    std::vector<uint32_t> ids;         // [n][2]
+    std::vector<uint8_t> id_pool;
+};
+
+bool read_text_file(const std::string& path, std::string& out, std::string& err);
+std::string resolve_model(const std::string& name, const char* kind);
+void cdf_thresholds(const std::vector<double>& probs, bool residual_to_one, std::vector<uint32_t>& out);
+bool load_error_model(const std::string& name_or_path, ErrorModelHost& m, std::string& err);
+bool load_qscore_model(const std::string& name_or_path, QScoreModelHost& m, std::string& err);
+bool make_identity(double mean, double max, double stdev, IdentityHost& id, std::string& err);
+
+// FASTA (py/sequence.py:168-186): calls sink(name, sequence) per record, in file order
+struct FastaRecord { std::string name, seq; };
+bool read_fasta(const std::string& path, std::vector<FastaRecord>& out, std::string& err);
+
+// MDF text (py/sequence.py:197-221) -> binary batch; contig_id(name) returns -1 for literals
+struct ContigLookup { virtual int find(const std::string& name) const = 0; virtual ~ContigLookup() {} };
+bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, BatchHost& out, std::string& err);
+
+}  // namespace tkh

@@ -1,0 +1,139 @@
+// hostio.cpp -- FASTA and MDF text readers (the wire formats either side of the kernels).
+//
+//   read_fasta   restates generate_fasta, py/sequence.py:168-186 (name = header up to the first
+//                space, lines concatenated verbatim); C++ statement of the same job: src/fasta.h:28-60
+//   parse_mdf    restates mdf_generator, py/sequence.py:197-221 and apply_modifications' token
+//                grammar, py/sequence.py:229-239 ("<pos><char>" comma separated); the writer side is
+//                src/interval.h:898-905 (always 5 tab fields)
+#include "host.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace tkh {
+
+bool read_fasta(const std::string& path, std::vector<FastaRecord>& out, std::string& err) {
+    std::string text;
+    if (!read_text_file(path, text, err)) return false;
+    size_t a = 0;
+    FastaRecord cur;
+    bool have = false;
+    while (a < text.size()) {
+        size_t b = text.find('\n', a);
+        if (b == std::string::npos) b = text.size();
+        if (b == a) { err = "empty line in FASTA " + path; return false; }   // reference: l[0] IndexError
+        if (text[a] == '>') {
+            // the reference only flushes when it has collected sequence lines (py/sequence.py:178-183):
+            // a header directly following a header replaces the name
+            if (have && !cur.seq.empty()) { out.push_back(cur); cur = FastaRecord(); }
+            size_t sp = text.find(' ', a + 1);
+            if (sp == std::string::npos || sp > b) sp = b;
+            cur.name = text.substr(a + 1, sp - a - 1);
+            cur.seq.clear();
+            have = true;
+        } else {
+            cur.seq.append(text, a, b - a);
+        }
+        a = b + 1;
+    }
+    out.push_back(cur);     // the reference yields the last record unconditionally (py/sequence.py:186)
+    return true;
+}
+
+static bool parse_i64(const char* s, const char* e, long long& v) {
+    if (s == e) return false;
+    bool neg = false;
+    if (*s == '-' || *s == '+') { neg = *s == '-'; s++; if (s == e) return false; }
+    v = 0;
+    for (; s < e; s++) {
+        if (*s < '0' || *s > '9') return false;
+        v = v * 10 + (*s - '0');
+        if (v > (1ll << 40)) return false;
+    }
+    if (neg) v = -v;
+    return true;
+}
+
+bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, BatchHost& out, std::string& err) {
+    out = BatchHost();
+    std::unordered_map<std::string, uint32_t> literal_ids;
+    const char* p = text; const char* end = text + len;
+    bool have = false;
+    long long depth = 0;
+    uint32_t ivl_begin = 0, id_off = 0, id_len = 0;
+    uint64_t line_no = 0;
+    auto flush = [&]() {
+        if (!have) return;
+        const uint32_t cnt = (uint32_t)(out.intervals.size() / 4) - ivl_begin;
+        for (long long d = 0; d < depth; d++) {
+            out.reads.push_back(ivl_begin); out.reads.push_back(cnt);
+            out.ids.push_back(id_off); out.ids.push_back(id_len);
+        }
+    };
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        line_no++;
+        if (le == p) { err = "MDF line " + std::to_string(line_no) + ": empty line"; return false; }
+        // split on tabs
+        const char* f[8]; const char* fe[8]; int nf = 0;
+        const char* s = p;
+        for (;;) {
+            const char* t = (const char*)memchr(s, '\t', (size_t)(le - s));
+            if (nf < 8) { f[nf] = s; fe[nf] = t ? t : le; }
+            nf++;
+            if (!t) break;
+            s = t + 1;
+        }
+        if (*p == '+') {
+            flush();
+            if (nf < 2 || !parse_i64(f[1], fe[1], depth)) { err = "MDF line " + std::to_string(line_no) + ": bad molecule header"; return false; }
+            have = true;
+            ivl_begin = (uint32_t)(out.intervals.size() / 4);
+            id_off = (uint32_t)out.id_pool.size(); id_len = (uint32_t)(fe[0] - f[0] - 1);
+            out.id_pool.insert(out.id_pool.end(), f[0] + 1, fe[0]);
+        } else {
+            if (nf != 5) { err = "MDF line " + std::to_string(line_no) + ": interval lines need exactly 5 tab-separated fields"; return false; }
+            if (!have) { err = "MDF line " + std::to_string(line_no) + ": interval before the first molecule header"; return false; }
+            long long st, en;
+            if (!parse_i64(f[1], fe[1], st) || !parse_i64(f[2], fe[2], en)) { err = "MDF line " + std::to_string(line_no) + ": bad interval coordinates"; return false; }
+            if (st < 0 || en < 0 || st > 0xFFFFFFFFll || en > 0xFFFFFFFFll) { err = "MDF line " + std::to_string(line_no) + ": interval coordinate out of the supported range"; return false; }
+            std::string name(f[0], fe[0]);
+            uint32_t contig;
+            int cid = contigs.find(name);
+            if (cid >= 0) contig = (uint32_t)cid;
+            else {
+                auto it = literal_ids.find(name);
+                if (it == literal_ids.end()) {
+                    uint32_t li = (uint32_t)(out.literals.size() / 2);
+                    out.literals.push_back(out.literal_pool.size()); out.literals.push_back(name.size());
+                    out.literal_pool.insert(out.literal_pool.end(), name.begin(), name.end());
+                    it = literal_ids.emplace(name, li).first;
+                }
+                contig = 0x80000000u | it->second;
+            }
+            const bool minus = !(fe[3] - f[3] == 1 && *f[3] == '+');   // strand == "+" else reverse complement
+            const uint32_t mod_begin = (uint32_t)(out.mods.size() / 2);
+            // modifications: "<pos><char>" joined by ','
+            const char* m = f[4];
+            if (m < fe[4]) {
+                for (;;) {
+                    const char* c = (const char*)memchr(m, ',', (size_t)(fe[4] - m));
+                    const char* te = c ? c : fe[4];
+                    long long pos;
+                    if (te - m < 2 || !parse_i64(m, te - 1, pos) || pos < 0) { err = "MDF line " + std::to_string(line_no) + ": bad modification token"; return false; }
+                    out.mods.push_back((uint32_t)pos); out.mods.push_back((uint8_t)te[-1]);
+                    if (!c) break;
+                    m = c + 1;
+                }
+            }
+            out.intervals.push_back(contig); out.intervals.push_back((uint32_t)st); out.intervals.push_back((uint32_t)en);
+            out.intervals.push_back(mod_begin | (minus ? 0x80000000u : 0u));
+        }
+        p = nl ? nl + 1 : end;
+    }
+    flush();
+    return true;
+}
+
+}  // namespace tkh

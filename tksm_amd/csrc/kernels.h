@@ -1,0 +1,100 @@
+// kernels.h -- device-side views and launchers of the Seq hot path (see DESIGN.md for layouts).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tk {
+
+constexpr uint32_t NO_BLOCK = 0xFFFFFFFFu;   // blocktab entry: block is pure 2-bit
+constexpr int BLOCK_SHIFT = 12;              // 4096-base exception blocks
+constexpr int WAVES_PER_WG = 4;
+
+struct RefView {
+    const uint32_t* packed;     // 16 bases per word, base g at bits 2*(g&15)
+    const uint32_t* blocktab;   // [total_blocks] NO_BLOCK or index into pool
+    const uint8_t* pool;        // [n_pool_blocks][4096] upper-cased bytes
+    const uint64_t* contigs;    // [n][2] {gstart (block aligned), len}
+    uint32_t n_contigs;
+};
+
+struct BatchView {
+    const uint32_t* reads;      // [n_reads][2] {ivl_begin, ivl_count}
+    const uint32_t* intervals;  // [n_intervals+1][4]
+    const uint32_t* mods;       // [n_mods][2]
+    const uint64_t* literals;   // [n_literals][2]
+    const uint8_t* litpool;
+    const uint32_t* ids;        // [n_reads][2]
+    const uint8_t* idpool;
+    uint64_t n_reads;
+    uint32_t n_literals;
+};
+
+struct ErrModelView {
+    int type, k, max_alts;
+    const uint32_t* cdf;
+    const uint64_t* alts;
+    const uint8_t* nalts;
+};
+
+struct QsModelView {
+    int n_slots, kmer_size;
+    const uint64_t* keys;
+    const uint32_t* row_off;
+    const uint32_t* row_cnt;
+    const uint32_t* cdf_pool;
+    const uint8_t* q_pool;
+};
+
+struct IdentView {
+    int constant;
+    double value;
+    const double* qtab;
+};
+
+struct SimParams {
+    uint64_t seed, first_read, stride;
+    int mode, compute_q, fastq, quirk_perfect;
+    int lcap;          // LDS capacity for the padded fragment (bytes, multiple of 4)
+    int ncap;          // LDS capacity for the joined new sequence (bytes, multiple of 4)
+    int trace_words;   // u32 words per wave in the traceback scratch
+    int cap_num, cap_den, cap_add;   // per-read scratch capacity = (raw+2k)*num/den + add, 16-aligned
+};
+
+struct SimBuffers {
+    const uint32_t* raw_len;     // [n_reads]
+    const uint64_t* slot_off;    // [n_reads] byte offset of the read's scratch slot (seq | qual)
+    uint8_t* scratch;
+    uint32_t* out_len;           // [n_reads]
+    double* identity;            // [n_reads]
+    uint64_t* rec_len;           // [n_reads] formatted record length
+    uint32_t* status;            // [n_reads] 0 ok, bit0 overflow, bit1 bad mod position, bit2 band failure
+    uint32_t* trace;             // [n_waves][trace_words]
+    unsigned long long* work_counter;
+    int32_t* istats;             // optional [n_reads][16]
+    double* dstats;              // optional [n_reads][2]
+};
+
+hipError_t launch_pack(const uint8_t* ascii, uint64_t n, uint64_t gstart, uint32_t* packed, uint32_t* blockflag,
+                       hipStream_t s);
+hipError_t launch_fill_pool(const uint8_t* ascii, uint64_t n, uint64_t gstart, const uint32_t* blocktab,
+                            uint8_t* pool, hipStream_t s);
+hipError_t launch_read_lengths(const BatchView& b, const RefView& r, int k, int cap_num, int cap_den, int cap_add,
+                               uint32_t* raw_len, uint64_t* slot_cap, uint32_t* status, hipStream_t s);
+hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
+                           const IdentView& im, const SimParams& p, const SimBuffers& o, int n_wgs,
+                           int waves_per_wg, hipStream_t s);
+hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off,
+                       uint8_t* records, hipStream_t s);
+hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank,
+                                  uint64_t n_total, uint64_t* lens, hipStream_t s);
+hipError_t launch_interleave_copy(int n_ranks, const uint8_t* const* streams, const uint64_t* const* offsets,
+                                  uint64_t n_total, const uint64_t* dst_off, uint8_t* dst, hipStream_t s);
+// exclusive scan of n u64 values (+ total in out[n]); temp storage managed by the caller through
+// scan_temp_bytes().
+size_t scan_temp_bytes(uint64_t n);
+hipError_t launch_scan(const uint64_t* in, uint64_t* out, uint64_t n, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_sum_u32(const uint32_t* in, uint64_t n, unsigned long long* out, hipStream_t s);
+int simulate_lds_bytes(int lcap, int ncap, int waves_per_wg);
+int simulate_max_wgs(int lds_bytes);
+
+}  // namespace tk

@@ -1,0 +1,813 @@
+// kernels.hip -- hand-written gfx950 kernels of the TKSM Seq hot path.
+//
+// One wavefront (64 lanes) owns one read from splice to finished sequence/qualities; its working
+// set (padded fragment, per-position edit slots, joined new sequence, per-position alignment ops)
+// lives in LDS.  Reference behaviour restated per stage (file:line into vpc-ccg/tksm):
+//   S0 pack        py/sequence.py:168-194  (FASTA text -> contig strings; here 2 bit/base + byte blocks)
+//   S1 splice      py/sequence.py:303-313, :224-239
+//   S2 identity    py/tksm_badread.py:741-745
+//   S3 errors      py/tksm_badread.py:333-432, :119-144, :199-213
+//   S4 identity re-estimation   py/tksm_badread.py:405-432 (edlib -> banded NW on the wave)
+//   S5 q-scores    py/tksm_badread.py:607-655, :584-598
+//   S6 trim/format py/tksm_badread.py:434-451, py/sequence.py:252-288
+// Integer/byte work throughout: no MFMA.  fp64 is used only for the scalar identity bookkeeping
+// and is compiled with -ffp-contract=off so it matches the CPU oracle bit for bit.
+#include "kernels.h"
+
+namespace tk {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+#define DEV __device__ __forceinline__
+
+constexpr int BIG = 1 << 28;
+DEV bool is_inf(int v) { return v >= (1 << 27); }
+
+struct Ph4 { uint32_t x, y, z, w; };
+enum { ST_ID = 0, ST_PAD = 1, ST_IDENT = 2, ST_DRAW = 3, ST_ALNPOS = 4, ST_QUAL = 5, ST_TAIL = 6 };
+
+DEV Ph4 philox(uint64_t seed, uint64_t read, uint32_t stream, uint32_t n) {
+    uint32_t c0 = (uint32_t)read, c1 = (uint32_t)(read >> 32), c2 = stream, c3 = n;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Ph4{c0, c1, c2, c3};
+}
+
+DEV uint8_t base_char(int code) { return (uint8_t)((0x54474341u >> (8 * (code & 3))) & 0xff); }
+DEV int code_of(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+DEV uint8_t upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+DEV uint8_t comp(uint8_t c) {
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+}
+
+DEV int scan_min_incl(int x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x = min(x, y); }
+    return x;
+}
+DEV int scan_max_incl(int x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x = max(x, y); }
+    return x;
+}
+DEV int scan_add_incl(int x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    return x;
+}
+DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+DEV uint8_t ref_base(const RefView& R, uint64_t g) {
+    uint32_t ex = R.blocktab[g >> BLOCK_SHIFT];
+    if (ex != NO_BLOCK) return R.pool[((uint64_t)ex << BLOCK_SHIFT) + (g & ((1u << BLOCK_SHIFT) - 1))];
+    uint32_t w = R.packed[g >> 4];
+    return base_char((int)(w >> ((g & 15) * 2)));
+}
+
+// slot code (u16) of new_fragment_bases[p]: 0 = pristine (the original byte).  Otherwise
+// bit15 = 1, bits 14..12 = length (0..5), bits 11..10 = 1 + index of the symbol that is the
+// ORIGINAL byte (0 = none), bits 9..0 = 2-bit base codes, symbol x at bits 2x.
+DEV int slot_len(uint32_t code) { return code ? (int)((code >> 12) & 7) : 1; }
+DEV uint8_t slot_sym(uint32_t code, int x, uint8_t orig) {
+    if (!code) return orig;
+    if ((int)((code >> 10) & 3) == x + 1) return orig;
+    return base_char((int)(code >> (2 * x)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// S0: ASCII -> 2 bit/base (+ per-4096-base-block exception flags), then byte copies of flagged blocks
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t* __restrict__ ascii, uint64_t n, uint64_t gstart, uint32_t* __restrict__ packed,
+                       uint32_t* __restrict__ blockflag) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // word index within the contig
+    uint64_t nw = (n + 15) >> 4;
+    for (; w < nw; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t b0 = w << 4;
+        uint32_t word = 0; bool exc = false;
+        if (b0 + 16 <= n && ((uintptr_t)(ascii + b0) & 15) == 0) {
+            uint4 v = *reinterpret_cast<const uint4*>(ascii + b0);
+            uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                int c = code_of(upper((uint8_t)(q[i >> 2] >> (8 * (i & 3)))));
+                exc |= c < 0; word |= (uint32_t)(c & 3) << (2 * i);
+            }
+        } else {
+            for (int i = 0; i < 16 && b0 + i < n; i++) {
+                int c = code_of(upper(ascii[b0 + i]));
+                exc |= c < 0; word |= (uint32_t)(c & 3) << (2 * i);
+            }
+        }
+        packed[(gstart >> 4) + w] = word;
+        if (exc) blockflag[(gstart + b0) >> BLOCK_SHIFT] = 1;
+    }
+}
+
+__global__ void k_fill_pool(const uint8_t* __restrict__ ascii, uint64_t n, uint64_t gstart,
+                            const uint32_t* __restrict__ blocktab, uint8_t* __restrict__ pool) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t g = gstart + i;
+        uint32_t ex = blocktab[g >> BLOCK_SHIFT];
+        if (ex != NO_BLOCK) pool[((uint64_t)ex << BLOCK_SHIFT) + (g & ((1u << BLOCK_SHIFT) - 1))] = upper(ascii[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// interval geometry shared by the length pre-pass and the splice
+// ------------------------------------------------------------------------------------------------
+struct Ivl { uint64_t gbase; uint32_t s, len; bool literal, minus; uint32_t mod_begin, mod_end; };
+
+DEV Ivl load_interval(const BatchView& B, const RefView& R, uint32_t idx) {
+    const uint4 v = *reinterpret_cast<const uint4*>(B.intervals + 4ull * idx);
+    uint32_t next_mod = B.intervals[4ull * (idx + 1) + 3] & 0x7fffffffu;
+    Ivl iv;
+    iv.literal = v.x >> 31; iv.minus = v.w >> 31;
+    iv.mod_begin = v.w & 0x7fffffffu; iv.mod_end = next_mod;
+    uint64_t clen, base;
+    if (iv.literal) { uint32_t li = v.x & 0x7fffffffu; base = B.literals[2ull * li]; clen = B.literals[2ull * li + 1]; }
+    else { base = R.contigs[2ull * v.x]; clen = R.contigs[2ull * v.x + 1]; }
+    uint64_t s = min((uint64_t)v.y, clen), e = min((uint64_t)v.z, clen);   // python slice clamp
+    iv.s = (uint32_t)s; iv.len = e > s ? (uint32_t)(e - s) : 0; iv.gbase = base;
+    return iv;
+}
+
+__global__ void k_read_lengths(BatchView B, RefView R, int k, int cap_num, int cap_den, int cap_add,
+                               uint32_t* __restrict__ raw_len, uint64_t* __restrict__ slot_cap,
+                               uint32_t* __restrict__ status) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.n_reads) return;
+    uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < ic; i++) total += load_interval(B, R, ib + i).len;
+    raw_len[r] = (uint32_t)total;
+    uint64_t cap = (total + 2 * (uint64_t)k) * cap_num / cap_den + cap_add;
+    cap = (cap + 15) & ~15ull;
+    slot_cap[r] = 2 * cap;       // seq | qual
+    status[r] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// S4/S5: guided banded global alignment on one wave.
+// rows = fragment window (n), cols = joined new bases (m); lane l of row r is column
+// c_r - 31 + l, c_r = joined length of the first r slots (the generative path).
+// MODE 0: predecessor preference up, left, diagonal (query = fragment).
+// MODE 1: left, up, diagonal (query = new sequence; q-score cigar).
+// stat = matches << 16 | columns of the preferred optimal path.
+// ------------------------------------------------------------------------------------------------
+struct AlnOut { int dist; uint32_t stat; };
+
+template <int MODE, bool TRACE>
+DEV AlnOut band_align(const uint8_t* F, const uint16_t* nbw, int n, const uint8_t* N, int m, int lane,
+                      uint32_t* trace) {
+    int c = 0, j = lane - 31;
+    bool inb = j >= 0 && j <= m;
+    int H = inb ? j : BIG;
+    uint32_t st = inb ? (uint32_t)j : 0u;
+    uint32_t tw = (TRACE && j >= 1 && j <= m) ? 2u : 0u;
+    for (int r = 1; r <= n; r++) {
+        const uint32_t code = nbw[r - 1];
+        const int d = slot_len(code);
+        const int fc = F[r - 1];
+        c += d; j = c - 31 + lane;
+        const int lu = lane + d, ld = lu - 1;
+        int hu = __shfl(H, lu & 63, 64); uint32_t su = __shfl(st, lu & 63, 64);
+        int hd = __shfl(H, ld & 63, 64); uint32_t sd = __shfl(st, ld & 63, 64);
+        if (lu > 63) hu = BIG;
+        if (ld > 63 || ld < 0) hd = BIG;
+        inb = j >= 0 && j <= m;
+        const int tch = (j >= 1 && j <= m) ? (int)N[j - 1] : 256;
+        const int match = tch == fc;
+        const int vd = (j >= 1 && !is_inf(hd)) ? hd + 1 - match : BIG;
+        const int vu = !is_inf(hu) ? hu + 1 : BIG;
+        const int t = inb ? min(vd, vu) : BIG;
+        const int x = scan_min_incl(t - lane, lane) + lane;
+        const int h = (inb && !is_inf(x)) ? x : BIG;
+        int hl = __shfl_up(h, 1, 64);
+        if (lane == 0) hl = BIG;
+        const bool ok = !is_inf(h);
+        const bool upok = ok && vu == h;
+        const bool leftok = ok && !is_inf(hl) && hl + 1 == h;
+        const int take = MODE == 0 ? (upok ? 0 : (leftok ? 1 : 2)) : (leftok ? 1 : (upok ? 0 : 2));
+        const uint32_t sb = take == 0 ? su + 1u : sd + ((uint32_t)match << 16) + 1u;
+        const int srcl = scan_max_incl(take != 1 ? lane : -1, lane);
+        const uint32_t ss = __shfl(sb, srcl & 63, 64);
+        st = take == 1 ? ss + (uint32_t)(lane - srcl) : sb;
+        H = h;
+        if (TRACE) {
+            tw |= ((upok ? 1u : 0u) | (leftok ? 2u : 0u)) << (2 * (r & 15));
+            if ((r & 15) == 15 || r == n) { trace[(r >> 4) * 64 + lane] = tw; tw = 0; }
+        }
+    }
+    const int lf = m - c + 31;
+    AlnOut o;
+    if (lf < 0 || lf > 63) { o.dist = BIG; o.stat = 0; return o; }
+    o.dist = __shfl(H, lf, 64); o.stat = __shfl(st, lf, 64);
+    return o;
+}
+
+// joins slots [p0, p0+n) into N; returns the joined length (may exceed ncap: nothing is written
+// past ncap and the caller flags the overflow).
+DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint8_t* N, int ncap, int lane) {
+    int base = 0;
+    for (int q = 0; q < n; q += 64) {
+        const int p = q + lane;
+        uint32_t code = 0; int len = 0; uint8_t orig = 0;
+        if (p < n) { code = nb[p0 + p]; len = slot_len(code); orig = frag[p0 + p]; }
+        const int incl = scan_add_incl(len, lane);
+        const int off = base + incl - len;
+        if (off + len <= ncap)
+            for (int x2 = 0; x2 < len; x2++) N[off + x2] = slot_sym(code, x2, orig);
+        base += __shfl(incl, 63, 64);
+    }
+    return base;
+}
+
+DEV uint64_t qs_hash(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+// '{:.2f}'.format(identity * 100) as an integer number of hundredths, correctly rounded
+DEV long long pct_hundredths(double identity) {
+    double e = identity * 100.0;
+    double r = rint(e * 100.0);
+    double err = fma(e, 100.0, -r);
+    if (err > 0.5) r += 1.0; else if (err < -0.5) r -= 1.0;
+    else if (err == 0.5) { if (fmod(r, 2.0) != 0.0) r += 1.0; }
+    else if (err == -0.5) { if (fmod(r, 2.0) != 0.0) r -= 1.0; }
+    return (long long)r;
+}
+DEV int ndigits(unsigned long long v) { int d = 1; while (v >= 10) { v /= 10; d++; } return d; }
+
+// ------------------------------------------------------------------------------------------------
+// S1..S6 main kernel: persistent waves pull reads from a global counter.
+// LDS per wave: frag[lcap] | nb[lcap] (u16) | N[ncap] | popd[ncap]
+// ------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, RefView R, ErrModelView EM,
+                                                                 QsModelView QM, IdentView IM, SimParams P,
+                                                                 SimBuffers O) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_wave = P.lcap * 3 + P.ncap * 2;
+    const int wpw = blockDim.x >> 6;
+    uint8_t* frag = lds_raw + (size_t)wave * per_wave;
+    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + P.lcap);
+    uint8_t* N = frag + 3 * (size_t)P.lcap;
+    uint8_t* popd = N + P.ncap;
+    uint32_t* trace = O.trace + ((size_t)blockIdx.x * wpw + wave) * (size_t)P.trace_words;
+    const int k = EM.k;
+
+    for (;;) {
+        unsigned long long rr = 0;
+        if (lane == 0) rr = atomicAdd(O.work_counter, 1ull);
+        rr = __shfl((long long)rr, 0, 64);
+        if (rr >= B.n_reads) break;               // every wave reaches this exit
+        const uint64_t r = rr;
+        const uint64_t g = P.first_read + r * P.stride;
+        const int raw_len = (int)O.raw_len[r];
+        const int L = raw_len + 2 * k;
+        const uint64_t slot = O.slot_off[r];
+        const int cap = (int)((O.slot_off[r + 1] - slot) >> 1);
+        uint8_t* out_seq = O.scratch + slot;
+        uint8_t* out_qual = out_seq + cap;
+        uint32_t status = 0;
+
+        // ---- S1 splice (py/sequence.py:303-313) into frag[k .. k+raw_len)
+        {
+            const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+            int o = k;
+            for (uint32_t ii = 0; ii < ic; ii++) {
+                const Ivl iv = load_interval(B, R, ib + ii);
+                const int len = (int)iv.len;
+                for (int t = lane; t < len; t += 64) {
+                    const uint32_t src = iv.minus ? iv.s + (uint32_t)(len - 1 - t) : iv.s + (uint32_t)t;
+                    uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + src]) : ref_base(R, iv.gbase + src);
+                    frag[o + t] = iv.minus ? comp(b) : b;
+                }
+                wave_sync();
+                // modifications: position relative to the slice, applied before the strand flip,
+                // later entries overwrite earlier ones (py/sequence.py:229-239) -> serial order
+                for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++) {
+                    const uint32_t mp = B.mods[2ull * mi], mc = B.mods[2ull * mi + 1];
+                    if (mp >= (uint32_t)len) { status |= 2; continue; }
+                    if (lane == 0) frag[o + (iv.minus ? len - 1 - (int)mp : (int)mp)] = iv.minus ? comp((uint8_t)mc) : (uint8_t)mc;
+                }
+                o += len;
+            }
+        }
+        double identity = 1.0;
+        int out_len = 0;
+        int st_draws = 0, st_changes = 0, st_aligns = 0, st_newlen = 0, st_strim = 0, st_etrim = 0;
+        double errors = 0.0, target = 1.0;
+
+        if (P.mode == 0) {
+            // perfect (py/sequence.py:261-270): the error-free sequence itself
+            wave_sync();
+            for (int t = lane; t < raw_len; t += 64) out_seq[t] = frag[k + t];
+            out_len = raw_len;
+        } else {
+            // ---- :334-341 pad with k random bases each side
+            {
+                const Ph4 pad = philox(P.seed, g, ST_PAD, 0);
+                if (lane < k) {
+                    frag[lane] = base_char((int)(pad.x >> (2 * lane)));
+                    frag[k + raw_len + lane] = base_char((int)(pad.y >> (2 * lane)));
+                }
+            }
+            for (int p = lane; p < L; p += 64) nb[p] = 0;
+            // ---- S2 target identity (py/tksm_badread.py:741-745)
+            if (IM.constant) target = IM.value;
+            else {
+                const uint32_t u = philox(P.seed, g, ST_IDENT, 0).x;
+                const uint32_t idx = u >> 16;
+                const double fr = (double)(u & 0xffffu) * (1.0 / 65536.0);
+                const double qa = IM.qtab[idx], qb = IM.qtab[idx + 1];
+                target = IM.value * (qa + (qb - qa) * fr);
+            }
+            wave_sync();
+
+            // ---- S3 error insertion loop (py/tksm_badread.py:348-432)
+            const double frag_len = (double)L;
+            const int max_kmer_index = L - 1 - k;
+            int change_count = 0;
+            uint32_t n_base = 0, aln_no = 0;
+            const long long loop_limit = 100ll * L;   // iterations with loop_count <= loop_limit run
+            bool done = false;
+            // the stop rules are evaluated at the top of every iteration; state only changes when a
+            // draw is applied, so they are re-evaluated after each applied draw.
+            if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
+            while (!done) {
+                // 64 candidate draws, lane l = draw n_base + l  (loop_count = n + 1)
+                const uint32_t n = n_base + (uint32_t)lane;
+                const bool live = (long long)n + 1 <= loop_limit;
+                const Ph4 d = philox(P.seed, g, ST_DRAW, n);
+                const int i = (int)__umulhi(d.x, (uint32_t)(max_kmer_index + 1));
+                int kind = 0;            // 0 no-op, 1 model alternative, 2 random change
+                uint64_t alt = 0;
+                if (live) {
+                    int kidx = 0; bool valid = true;
+                    for (int jj = 0; jj < k; jj++) { const int cc = code_of(frag[i + jj]); valid &= cc >= 0; kidx = (kidx << 2) | (cc & 3); }
+                    if (EM.type == 0 || !valid) kind = 2;
+                    else {
+                        const uint32_t* cdf = EM.cdf + (size_t)kidx * EM.max_alts;
+                        const int na = EM.nalts[kidx];
+                        int a = 0;
+                        while (a < na && !(d.y < cdf[a])) a++;
+                        if (a == na) kind = 2;
+                        else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
+                    }
+                    if (kind == 2) {
+                        const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
+                        const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
+                        const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
+                        alt = type | (pos << 2) | (base4 << 8) | (side << 10) | (r3 << 12);
+                    }
+                }
+                unsigned long long mask = __ballot(live && kind != 0);
+                const unsigned long long dead = __ballot(!live);
+                while (mask) {
+                    const int src = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int ai = __shfl(i, src, 64);
+                    const int akind = __shfl(kind, src, 64);
+                    const uint64_t aalt = ((uint64_t)(uint32_t)__shfl((int)(alt >> 32), src, 64) << 32) |
+                                          (uint32_t)__shfl((int)(uint32_t)alt, src, 64);
+                    const double est = 1.0 - errors / frag_len;
+                    int boff = 0;
+                    for (int jj = 0; jj < k; jj++) {
+                        const int p = ai + jj;
+                        const uint8_t orig = frag[p];
+                        uint32_t enc; int len; bool differs;
+                        if (akind == 1) {
+                            len = (int)((aalt >> (3 * jj)) & 7);
+                            const uint32_t codes = (uint32_t)((aalt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u));
+                            boff += len;
+                            differs = !(len == 1 && base_char((int)codes) == orig);
+                            enc = 0x8000u | ((uint32_t)len << 12) | codes;
+                        } else {
+                            const int type = (int)(aalt & 3), pos = (int)((aalt >> 2) & 15);
+                            const uint32_t base4 = (uint32_t)((aalt >> 8) & 3), side = (uint32_t)((aalt >> 10) & 1);
+                            const int r3 = (int)((aalt >> 12) & 3);
+                            if (jj != pos) continue;
+                            differs = true;
+                            if (type == 0) {
+                                const int cc = code_of(orig);
+                                len = 1; enc = 0x8000u | (1u << 12) | (uint32_t)(cc < 0 ? (int)base4 : ((cc + r3) & 3));
+                            } else if (type == 1) {
+                                len = 2;
+                                enc = side ? (0x8000u | (2u << 12) | (1u << 10) | (base4 << 2))    // orig + random
+                                           : (0x8000u | (2u << 12) | (2u << 10) | base4);          // random + orig
+                            } else { len = 0; enc = 0x8000u; }
+                        }
+                        if (!differs || nb[p] != 0) continue;
+                        if (lane == 0) nb[p] = (uint16_t)enc;
+                        change_count++;
+                        const int new_errors = len < 2 ? 1 : len - 1;
+                        errors += (double)new_errors * (est * sqrt(est));
+                        if (change_count % 25 == 0) {           // ALIGNMENT_INTERVAL
+                            wave_sync();
+                            st_aligns++;
+                            int p0 = 0, nrows = L;
+                            if (L > 1000) {                     // ALIGNMENT_SIZE: random 1000-base window
+                                const uint32_t w = philox(P.seed, g, ST_ALNPOS, aln_no).x;
+                                p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
+                                nrows = 1000;
+                            }
+                            const int m = join_window(frag, nb, p0, nrows, N, P.ncap, lane);
+                            wave_sync();
+                            if (m > P.ncap) status |= 1;
+                            else {
+                                const AlnOut a = band_align<0, false>(frag + p0, nb + p0, nrows, N, m, lane, nullptr);
+                                if (is_inf(a.dist)) status |= 4;
+                                const int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
+                                const double ident = cols ? (double)mt / (double)cols : 0.0;
+                                if (L <= 1000) errors = (1.0 - ident) * frag_len;
+                                else {
+                                    const double estimated = (1.0 - ident) * frag_len;
+                                    const double weight = 1000.0 / frag_len;
+                                    errors = estimated * weight + errors * (1.0 - weight);
+                                }
+                            }
+                            aln_no++;
+                        }
+                    }
+                    wave_sync();
+                    if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) {
+                        done = true; st_draws = (int)n_base + src + 1; break;
+                    }
+                }
+                if (!done) {
+                    if (dead) { done = true; st_draws = (int)loop_limit; }
+                    else n_base += 64;
+                }
+            }
+            st_changes = change_count;
+
+            // ---- :434-437 trims and the joined sequence
+            wave_sync();
+            int start_trim = 0, end_trim = 0;
+            {
+                int v1 = lane < k ? slot_len(nb[lane]) : 0, v2 = lane < k ? slot_len(nb[L - k + lane]) : 0;
+                start_trim = __shfl(scan_add_incl(v1, lane), 63, 64);
+                end_trim = __shfl(scan_add_incl(v2, lane), 63, 64);
+            }
+            const int m = join_window(frag, nb, 0, L, N, min(P.ncap, cap), lane);
+            wave_sync();
+            st_newlen = m; st_strim = start_trim; st_etrim = end_trim;
+            int lo = start_trim, hi = end_trim == 0 ? 0 : m - end_trim;   // seq[start_trim:-end_trim]
+            lo = min(lo, m); hi = max(hi, lo);
+            if (m > min(P.ncap, cap)) { status |= 1; lo = hi = 0; }
+            out_len = hi - lo;
+            if (P.compute_q && m > 0 && !(status & 1)) {
+                // ---- S5 q-scores (py/tksm_badread.py:607-655): align read vs fragment with path
+                const AlnOut a = band_align<1, true>(frag, nb, L, N, m, lane, trace);
+                if (is_inf(a.dist)) status |= 4;
+                wave_sync();
+                int mt = 0, cols = 0;
+                if (!(status & 4)) {
+                    int rr2 = L, j = m, c = m, grp = -1, dpend = 0;
+                    uint32_t tw = 0;
+                    while (rr2 > 0 || j > 0) {
+                        if ((rr2 >> 4) != grp) { grp = rr2 >> 4; tw = trace[grp * 64 + lane]; }
+                        const int l = j - c + 31;
+                        const uint32_t tb = ((uint32_t)__shfl((int)tw, l & 63, 64) >> (2 * (rr2 & 15))) & 3u;
+                        // a consistent trace never asks for a move that leaves the matrix; bound the
+                        // walk anyway so that a corrupted trace cannot hang the wave
+                        if (cols > L + m || ((tb & 2u) && j == 0) || (!(tb & 2u) && (tb & 1u) && rr2 == 0) ||
+                            (!(tb & 3u) && (rr2 == 0 || j == 0))) { status |= 4; break; }
+                        cols++;
+                        if (tb & 2u) {                          // read-only base: 'I'
+                            if (lane == 0) popd[j - 1] = (uint8_t)(2 | (min(dpend, 63) << 2));
+                            dpend = 0; j--;
+                        } else if (tb & 1u) {                   // fragment-only base: 'D'
+                            dpend++; rr2--; c -= slot_len(nb[rr2]);
+                        } else {
+                            const bool eq = frag[rr2 - 1] == N[j - 1];
+                            mt += eq;
+                            if (lane == 0) popd[j - 1] = (uint8_t)((eq ? 0 : 1) | (min(dpend, 63) << 2));
+                            dpend = 0; rr2--; j--; c -= slot_len(nb[rr2]);
+                        }
+                    }
+                }
+                identity = cols ? (double)mt / (double)cols : 0.0;
+                wave_sync();
+                const int margins = (QM.kmer_size - 1) / 2;
+                const uint32_t hmask = (uint32_t)QM.n_slots - 1u;
+                for (int i2 = lo + lane; i2 < hi; i2 += 64) {
+                    int s0 = i2 - margins, e0 = i2 + margins;
+                    while (s0 < 0 || e0 >= m) { s0++; e0--; }
+                    int row = -1;
+                    for (;;) {                                   // get_qscore :584-598
+                        uint64_t key = 0; int len = 0; bool ok = true;
+                        for (int x2 = s0; x2 <= e0; x2++) {
+                            if (x2 > s0) {
+                                const int dd = popd[x2 - 1] >> 2;
+                                if (len + dd > 29) { ok = false; break; }
+                                key |= ((1ull << (2 * dd)) - 1ull) << (2 * len); len += dd;
+                            }
+                            if (len >= 29) { ok = false; break; }
+                            key |= (uint64_t)(popd[x2] & 3) << (2 * len); len++;
+                        }
+                        if (ok) {
+                            key |= (uint64_t)len << 58;
+                            uint32_t s = (uint32_t)qs_hash(key) & hmask;
+                            for (;;) {
+                                const uint64_t kk = QM.keys[s];
+                                if (kk == key) { row = (int)s; break; }
+                                if (kk == 0) break;
+                                s = (s + 1) & hmask;
+                            }
+                        }
+                        if (row >= 0 || s0 == e0) break;
+                        s0++; e0--;
+                    }
+                    uint8_t q = 0;
+                    if (row >= 0) {
+                        const uint32_t w = philox(P.seed, g, ST_QUAL, (uint32_t)i2).x;
+                        const uint32_t off = QM.row_off[row], cnt = QM.row_cnt[row];
+                        uint32_t a = 0;
+                        while (a + 1 < cnt && !(w < QM.cdf_pool[off + a])) a++;
+                        q = QM.q_pool[off + a];
+                    }
+                    out_qual[i2 - lo] = (uint8_t)(q + 33);
+                }
+            } else {
+                identity = 1.0 - errors / frag_len;             // :442-445
+            }
+            for (int t = lo + lane; t < hi; t += 64) out_seq[t - lo] = N[t];
+        }
+
+        // ---- per-read results; record length of py/sequence.py:252-288
+        if (P.quirk_perfect) identity = 1.0;
+        if (lane == 0) {
+            const int efl = P.quirk_perfect ? out_len : raw_len;
+            const long long h = pct_hundredths(identity);
+            const uint32_t idl = B.ids[2 * r + 1];
+            // '@' uuid(36) ' length=' n ' error_free_length=' n ' read_identity=' x.xx '% molecule_id=' id '\n'
+            uint64_t rec = 1 + 36 + 8 + ndigits((unsigned)out_len) + 19 + ndigits((unsigned)efl) + 15 +
+                           ndigits((unsigned long long)(h / 100)) + 3 + 14 + idl + 1;
+            rec += (uint64_t)out_len + 1;
+            if (P.fastq) rec += 2 + (uint64_t)out_len + 1;
+            O.out_len[r] = (uint32_t)out_len;
+            O.identity[r] = identity;
+            O.rec_len[r] = rec;
+            O.status[r] |= status;
+            if (O.istats) {
+                int32_t* s = O.istats + 16 * r;
+                s[0] = st_draws; s[1] = st_changes; s[2] = st_aligns; s[3] = L; s[4] = st_newlen;
+                s[5] = st_strim; s[6] = st_etrim; s[7] = (int32_t)status;
+                O.dstats[2 * r] = errors; O.dstats[2 * r + 1] = target;
+            }
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S6 emit: one wave formats one record at its scanned offset
+// ------------------------------------------------------------------------------------------------
+DEV int put_str(uint8_t* o, const char* s) { int n = 0; while (s[n]) { o[n] = (uint8_t)s[n]; n++; } return n; }
+DEV int put_u(uint8_t* o, unsigned long long v) {
+    int d = ndigits(v);
+    for (int i = d - 1; i >= 0; i--) { o[i] = (uint8_t)('0' + v % 10); v /= 10; }
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
+                                               uint8_t* __restrict__ records) {
+    __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t r = (uint64_t)blockIdx.x * WAVES_PER_WG + wave;
+    if (r >= B.n_reads) return;
+    uint8_t* hdr = hdr_all[wave];
+    const uint64_t g = P.first_read + r * P.stride;
+    const uint32_t out_len = O.out_len[r], raw_len = P.quirk_perfect ? O.out_len[r] : O.raw_len[r];
+    int hl = 0;
+    if (lane == 0) {
+        int kx = 0;
+        hdr[kx++] = P.fastq ? '@' : '>';
+        const Ph4 id = philox(P.seed, g, ST_ID, 0);
+        const uint32_t w[4] = {id.x, id.y, id.z, id.w};
+        int nib = 0;
+        for (int a = 0; a < 4; a++)
+            for (int b = 7; b >= 0; b--) {
+                if (nib == 8 || nib == 12 || nib == 16 || nib == 20) hdr[kx++] = '-';
+                const uint32_t v = (w[a] >> (4 * b)) & 15u;
+                hdr[kx++] = (uint8_t)(v < 10 ? '0' + v : 'a' + v - 10); nib++;
+            }
+        kx += put_str(hdr + kx, " length="); kx += put_u(hdr + kx, out_len);
+        kx += put_str(hdr + kx, " error_free_length="); kx += put_u(hdr + kx, raw_len);
+        kx += put_str(hdr + kx, " read_identity=");
+        const long long h = pct_hundredths(O.identity[r]);
+        kx += put_u(hdr + kx, (unsigned long long)(h / 100));
+        hdr[kx++] = '.'; hdr[kx++] = (uint8_t)('0' + (h % 100) / 10); hdr[kx++] = (uint8_t)('0' + h % 10);
+        kx += put_str(hdr + kx, "% molecule_id=");
+        hl = kx;
+    }
+    hl = __shfl(hl, 0, 64);
+    wave_sync();
+    uint8_t* dst = records + rec_off[r];
+    for (int t = lane; t < hl; t += 64) dst[t] = hdr[t];
+    dst += hl;
+    const uint32_t ido = B.ids[2 * r], idl = B.ids[2 * r + 1];
+    for (uint32_t t = lane; t < idl; t += 64) dst[t] = B.idpool[ido + t];
+    dst += idl;
+    const uint8_t* seq = O.scratch + O.slot_off[r];
+    const uint64_t cap = (O.slot_off[r + 1] - O.slot_off[r]) >> 1;
+    if (lane == 0) dst[0] = '\n';
+    dst += 1;
+    for (uint32_t t = lane; t < out_len; t += 64) dst[t] = seq[t];
+    dst += out_len;
+    if (lane == 0) dst[0] = '\n';
+    dst += 1;
+    if (P.fastq) {
+        if (lane == 0) { dst[0] = '+'; dst[1] = '\n'; }
+        dst += 2;
+        const bool real_q = P.mode == 1 && P.compute_q && !P.quirk_perfect;
+        const uint8_t* qual = seq + cap;
+        for (uint32_t t = lane; t < out_len; t += 64) dst[t] = real_q ? qual[t] : (uint8_t)'K';
+        dst += out_len;
+        if (lane == 0) dst[0] = '\n';
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S7: interleave P per-rank record streams into global read order
+// ------------------------------------------------------------------------------------------------
+struct PtrPack { const void* p[16]; uint64_t n[16]; };
+
+__global__ void k_interleave_lens(int P_, PtrPack offs, uint64_t n_total, uint64_t* __restrict__ lens) {
+    uint64_t gi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n_total) return;
+    const int p = (int)(gi % P_); const uint64_t i = gi / P_;
+    const uint64_t* o = (const uint64_t*)offs.p[p];
+    lens[gi] = o[i + 1] - o[i];
+}
+
+__global__ __launch_bounds__(256) void k_interleave_copy(int P_, PtrPack streams, PtrPack offs, uint64_t n_total,
+                                                          const uint64_t* __restrict__ dst_off, uint8_t* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t gi = (uint64_t)blockIdx.x * WAVES_PER_WG + wave;
+    if (gi >= n_total) return;
+    const int p = (int)(gi % P_); const uint64_t i = gi / P_;
+    const uint64_t* o = (const uint64_t*)offs.p[p];
+    const uint8_t* s = (const uint8_t*)streams.p[p] + o[i];
+    const uint64_t len = o[i + 1] - o[i];
+    uint8_t* d = dst + dst_off[gi];
+    for (uint64_t t = lane; t < len; t += 64) d[t] = s[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan (u64), three-phase: block sums -> recursive scan -> apply.  2048 values per block.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_T = 256, SCAN_V = 8, SCAN_B = SCAN_T * SCAN_V;
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(const uint64_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ sums) {
+    __shared__ uint64_t sh[SCAN_T];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_B + (uint64_t)threadIdx.x * SCAN_V;
+    uint64_t a = 0;
+    for (int i = 0; i < SCAN_V; i++) if (base + i < n) a += in[base + i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = SCAN_T / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) sums[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_apply(const uint64_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ block_off,
+                                                        uint64_t* __restrict__ out) {
+    __shared__ uint64_t sh[SCAN_T];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_B + (uint64_t)threadIdx.x * SCAN_V;
+    uint64_t v[SCAN_V], a = 0;
+    for (int i = 0; i < SCAN_V; i++) { v[i] = base + i < n ? in[base + i] : 0; a += v[i]; }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 1; o < SCAN_T; o <<= 1) {
+        uint64_t y = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += y;
+        __syncthreads();
+    }
+    uint64_t run = (block_off ? block_off[blockIdx.x] : 0) + sh[threadIdx.x] - a;
+    for (int i = 0; i < SCAN_V; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (base <= n - 1 && n - 1 < base + SCAN_V) out[n] = run;   // total after the last element
+}
+
+__global__ void k_set_u64(uint64_t* p, uint64_t v) { *p = v; }
+
+__global__ void k_sum_u32(const uint32_t* __restrict__ in, uint64_t n, unsigned long long* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long a = 0;
+    for (; i < n; i += (uint64_t)gridDim.x * blockDim.x) a += in[i];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down((long long)a, o, 64);
+    if ((threadIdx.x & 63) == 0 && a) atomicAdd(out, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline unsigned grid_for(uint64_t n, unsigned threads, unsigned cap = 256 * 16) {
+    uint64_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+hipError_t launch_pack(const uint8_t* ascii, uint64_t n, uint64_t gstart, uint32_t* packed, uint32_t* blockflag, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_pack, dim3(grid_for((n + 15) >> 4, 256)), dim3(256), 0, s, ascii, n, gstart, packed, blockflag);
+    return hipGetLastError();
+}
+hipError_t launch_fill_pool(const uint8_t* ascii, uint64_t n, uint64_t gstart, const uint32_t* blocktab, uint8_t* pool, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_pool, dim3(grid_for(n, 256)), dim3(256), 0, s, ascii, n, gstart, blocktab, pool);
+    return hipGetLastError();
+}
+hipError_t launch_read_lengths(const BatchView& b, const RefView& r, int k, int cap_num, int cap_den, int cap_add,
+                               uint32_t* raw_len, uint64_t* slot_cap, uint32_t* status, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    hipLaunchKernelGGL(k_read_lengths, dim3((unsigned)((b.n_reads + 255) / 256)), dim3(256), 0, s, b, r, k, cap_num, cap_den,
+                       cap_add, raw_len, slot_cap, status);
+    return hipGetLastError();
+}
+int simulate_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap * 2); }
+int simulate_max_wgs(int lds_bytes) {
+    int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 8;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    return per_cu;
+}
+hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
+                           const IdentView& im, const SimParams& p, const SimBuffers& o, int n_wgs, int wpw, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    const int lds = simulate_lds_bytes(p.lcap, p.ncap, wpw);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_simulate), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_simulate, dim3(n_wgs), dim3(64 * wpw), lds, s, b, r, em, qm, im, p, o);
+    return hipGetLastError();
+}
+hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)((b.n_reads + WAVES_PER_WG - 1) / WAVES_PER_WG)), dim3(256), 0, s, b, p, o, rec_off, records);
+    return hipGetLastError();
+}
+hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank, uint64_t n_total,
+                                  uint64_t* lens, hipStream_t s) {
+    if (!n_total) return hipSuccess;
+    PtrPack o{};
+    for (int i = 0; i < n_ranks; i++) { o.p[i] = offsets[i]; o.n[i] = n_per_rank[i]; }
+    hipLaunchKernelGGL(k_interleave_lens, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, s, n_ranks, o, n_total, lens);
+    return hipGetLastError();
+}
+hipError_t launch_interleave_copy(int n_ranks, const uint8_t* const* streams, const uint64_t* const* offsets, uint64_t n_total,
+                                  const uint64_t* dst_off, uint8_t* dst, hipStream_t s) {
+    if (!n_total) return hipSuccess;
+    PtrPack st{}, o{};
+    for (int i = 0; i < n_ranks; i++) { st.p[i] = streams[i]; o.p[i] = offsets[i]; }
+    hipLaunchKernelGGL(k_interleave_copy, dim3((unsigned)((n_total + WAVES_PER_WG - 1) / WAVES_PER_WG)), dim3(256), 0, s, n_ranks,
+                       st, o, n_total, dst_off, dst);
+    return hipGetLastError();
+}
+
+size_t scan_temp_bytes(uint64_t n) {
+    size_t total = 0;
+    while (n > 1) { uint64_t nb = (n + SCAN_B - 1) / SCAN_B; total += (nb + 1) * sizeof(uint64_t) * 2; n = nb; if (nb == 1) break; }
+    return total + 64;
+}
+hipError_t launch_scan(const uint64_t* in, uint64_t* out, uint64_t n, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (n == 0) { hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, out, 0ull); return hipGetLastError(); }
+    const uint64_t nb = (n + SCAN_B - 1) / SCAN_B;
+    if (nb == 1) {
+        hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(SCAN_T), 0, s, in, n, (const uint64_t*)nullptr, out);
+        return hipGetLastError();
+    }
+    uint64_t* sums = (uint64_t*)temp;
+    uint64_t* sums_scan = sums + (nb + 1);
+    const size_t used = (nb + 1) * sizeof(uint64_t) * 2;
+    if (used > temp_bytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, n, sums);
+    hipError_t e = launch_scan(sums, sums_scan, nb, (uint8_t*)temp + used, temp_bytes - used, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, n, (const uint64_t*)sums_scan, out);
+    return hipGetLastError();
+}
+hipError_t launch_sum_u32(const uint32_t* in, uint64_t n, unsigned long long* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || !n) return e;
+    hipLaunchKernelGGL(k_sum_u32, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, in, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace tk

@@ -1,0 +1,377 @@
+// models.cpp -- host-side loaders for the Badread model files and the identity distribution.
+//
+// Restates (file:line into vpc-ccg/tksm):
+//   ErrorModel.load_from_file            py/tksm_badread.py:91-117
+//   align_kmers                          py/tksm_badread.py:146-197  (edlib -> unit-cost NW with
+//                                        path; traceback prefers query-only, target-only, diagonal)
+//   QScoreModel.load_from_file/random/ideal   py/tksm_badread.py:487-582
+//   Identities / beta_parameters         py/tksm_badread.py:703-757
+//   model-name lookup through $TKSM_MODELS    py/sequence.py:17-31, src/sequence.cpp:38-52
+// and produces the packed device layouts described in DESIGN.md (identical, bit for bit, to the
+// tables oracle/pyoracle.py builds independently).
+#include "host.h"
+
+#include <zlib.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace tkh {
+
+static bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+
+// reads a whole (optionally gzip-compressed) text file; gzread handles plain files transparently
+bool read_text_file(const std::string& path, std::string& out, std::string& err) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    gzbuffer(f, 1 << 20);
+    out.clear();
+    std::vector<char> buf(1 << 22);
+    for (;;) {
+        int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n < 0) { err = "read error in " + path; gzclose(f); return false; }
+        if (n == 0) break;
+        out.append(buf.data(), (size_t)n);
+    }
+    gzclose(f);
+    return true;
+}
+
+static std::string library_dir() {
+    Dl_info info;
+    if (dladdr((void*)&library_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.rfind('/');
+        return s == std::string::npos ? "." : p.substr(0, s);
+    }
+    return ".";
+}
+
+// <dir>/badread/<name>.<kind>.gz, first hit in [built-in models dir, $TKSM_MODELS...] wins
+// (src/sequence.cpp:38-52 prepends the compile-time path; py/sequence.py:21 lets earlier dirs shadow later).
+std::string resolve_model(const std::string& name, const char* kind) {
+    if (file_exists(name)) return name;
+    std::vector<std::string> dirs;
+    if (const char* bi = getenv("TKSMSEQ_BUILTIN_MODELS")) dirs.push_back(bi);
+    dirs.push_back(library_dir() + "/../models");
+    dirs.push_back(library_dir() + "/models");
+    if (const char* env = getenv("TKSM_MODELS")) {
+        std::string v = env; size_t a = 0;
+        while (a <= v.size()) { size_t b = v.find(':', a); if (b == std::string::npos) b = v.size(); if (b > a) dirs.push_back(v.substr(a, b - a)); a = b + 1; }
+    }
+    for (auto& d : dirs) {
+        std::string p = d + "/badread/" + name + "." + kind + ".gz";
+        if (file_exists(p)) return p;
+    }
+    return name;   // fall through: treated as a path (the reference does the same, py/tksm_badread.py:88-89)
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiny global alignment with path for align_kmers (strings of length <= ~12)
+// ---------------------------------------------------------------------------------------------
+static std::string nw_ops(const std::string& q, const std::string& t) {
+    const int n = (int)q.size(), m = (int)t.size();
+    std::vector<int> H((size_t)(n + 1) * (m + 1));
+    auto at = [&](int i, int j) -> int& { return H[(size_t)i * (m + 1) + j]; };
+    for (int j = 0; j <= m; j++) at(0, j) = j;
+    for (int i = 1; i <= n; i++) {
+        at(i, 0) = i;
+        for (int j = 1; j <= m; j++) {
+            int d = at(i - 1, j - 1) + (q[i - 1] != t[j - 1]), u = at(i - 1, j) + 1, l = at(i, j - 1) + 1;
+            at(i, j) = std::min(d, std::min(u, l));
+        }
+    }
+    std::string ops;
+    int i = n, j = m;
+    while (i > 0 || j > 0) {
+        int cur = at(i, j);
+        if (i > 0 && at(i - 1, j) + 1 == cur) { ops.push_back('I'); i--; }
+        else if (j > 0 && at(i, j - 1) + 1 == cur) { ops.push_back('D'); j--; }
+        else { ops.push_back(at(i - 1, j - 1) == cur ? '=' : 'X'); i--; j--; }
+    }
+    return std::string(ops.rbegin(), ops.rend());
+}
+
+static bool align_kmers(const std::string& kmer_in, const std::string& alt_in, std::vector<std::string>& result) {
+    if (kmer_in.size() <= 2 || alt_in.size() <= 1) return false;
+    if (kmer_in.front() != alt_in.front() || kmer_in.back() != alt_in.back()) return false;
+    const size_t k = kmer_in.size();
+    result.assign(k, std::string());
+    result[0] = std::string(1, kmer_in.front());
+    result[k - 1] = std::string(1, kmer_in.back());
+    std::vector<bool> set(k, false);
+    std::string kmer = kmer_in.substr(1, k - 2), alt = alt_in.substr(1, alt_in.size() - 2);
+    std::string ops = alt.empty() ? std::string(kmer.size(), 'D') : nw_ops(alt, kmer);
+    size_t kp = 0, ap = 0;
+    for (char c : ops) {
+        if (c == '=' || c == 'X') { result[kp + 1] = std::string(1, alt[ap]); ap++; kp++; }
+        else if (c == 'D') { result[kp + 1] = ""; kp++; }
+        else { result[kp] += alt[ap]; ap++; }
+    }
+    if (result[0].size() == 2) {           // insertion landed on the first base: shift it to the second
+        std::string ins(1, result[0][1]);
+        result[0] = result[0].substr(0, 1);
+        result[1] = ins + result[1];
+    }
+    return true;
+}
+
+static int base_code(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+
+void cdf_thresholds(const std::vector<double>& probs, bool residual_to_one, std::vector<uint32_t>& out) {
+    double s = 0.0;
+    for (double p : probs) s += p;
+    const double total = (residual_to_one && s < 1.0) ? 1.0 : s;
+    double cum = 0.0;
+    for (double p : probs) {
+        cum += p;
+        double x = cum / total * 4294967296.0;
+        out.push_back(x >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)x);
+    }
+}
+
+static void split(const std::string& s, char sep, std::vector<std::string>& out) {
+    out.clear();
+    size_t a = 0;
+    for (;;) { size_t b = s.find(sep, a); if (b == std::string::npos) { out.push_back(s.substr(a)); break; } out.push_back(s.substr(a, b - a)); a = b + 1; }
+}
+static std::string strip(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) a++;
+    while (b > a && isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+
+bool load_error_model(const std::string& name_or_path, ErrorModelHost& m, std::string& err) {
+    m = ErrorModelHost();
+    if (name_or_path == "random") {        // py/tksm_badread.py:80-83
+        m.type = 0; m.k = 1; m.max_alts = 1;
+        m.cdf.assign(4, 0); m.alts.assign(4, 0); m.nalts.assign(4, 0);
+        return true;
+    }
+    std::string text;
+    if (!read_text_file(resolve_model(name_or_path, "error"), text, err)) return false;
+    struct Row { std::string kmer; std::vector<uint64_t> alts; std::vector<uint32_t> thr; };
+    std::vector<Row> rows;
+    size_t a = 0; int k = -1; size_t A = 0;
+    std::vector<std::string> parts, kv, slots;
+    while (a < text.size()) {
+        size_t b = text.find('\n', a);
+        if (b == std::string::npos) b = text.size();
+        std::string line = strip(text.substr(a, b - a));
+        a = b + 1;
+        if (line.empty()) continue;
+        split(line, ';', parts);
+        Row row; std::vector<double> probs;
+        for (auto& part : parts) {
+            if (part.empty()) continue;
+            split(part, ',', kv);
+            if (kv.size() < 2) { err = "malformed error model line"; return false; }
+            if (row.kmer.empty() && row.alts.empty()) {
+                row.kmer = kv[0];
+                if (k < 0) k = (int)row.kmer.size();
+                if ((int)row.kmer.size() != k) { err = "error model k-mers differ in size"; return false; }
+                if (k > 8) { err = "error model k-mer longer than 8 is not supported"; return false; }
+            }
+            if (!align_kmers(row.kmer, kv[0], slots)) { err = "cannot align alternative " + kv[0] + " to " + row.kmer; return false; }
+            uint64_t v = 0; int nbases = 0;
+            for (size_t j = 0; j < slots.size(); j++) {
+                if (slots[j].size() > 7) { err = "alternative slot too long"; return false; }
+                v |= (uint64_t)slots[j].size() << (3 * j);
+                for (char ch : slots[j]) {
+                    int c = base_code(ch);
+                    if (c < 0 || nbases >= 19) { err = "alternative not representable: " + kv[0]; return false; }
+                    v |= (uint64_t)c << (24 + 2 * nbases); nbases++;
+                }
+            }
+            if (kv[0] == row.kmer) v |= 1ull << 63;
+            row.alts.push_back(v);
+            char* endp = nullptr;
+            probs.push_back(strtod(kv[1].c_str(), &endp));
+        }
+        if (row.alts.empty()) continue;
+        cdf_thresholds(probs, true, row.thr);
+        A = std::max(A, row.alts.size());
+        rows.push_back(std::move(row));
+    }
+    if (k < 3) { err = "error model has no usable k-mers"; return false; }
+    if (A > 255) { err = "too many alternatives per k-mer"; return false; }
+    const size_t n = (size_t)1 << (2 * k);
+    m.type = 1; m.k = k; m.max_alts = (int)A;
+    m.cdf.assign(n * A, 0); m.alts.assign(n * A, 0); m.nalts.assign(n, 0);
+    for (auto& row : rows) {
+        size_t idx = 0;
+        for (char ch : row.kmer) { int c = base_code(ch); if (c < 0) { err = "non-ACGT k-mer in error model"; return false; } idx = idx * 4 + (size_t)c; }
+        m.nalts[idx] = (uint8_t)row.alts.size();
+        for (size_t j = 0; j < A; j++) {
+            m.alts[idx * A + j] = j < row.alts.size() ? row.alts[j] : 0;
+            m.cdf[idx * A + j] = j < row.thr.size() ? row.thr[j] : row.thr.back();
+        }
+    }
+    return true;
+}
+
+static uint64_t qs_hash(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+static bool encode_key(const std::string& cigar, uint64_t& key) {
+    if (cigar.empty() || cigar.size() > 29) return false;
+    key = 0;
+    for (size_t i = 0; i < cigar.size(); i++) {
+        int op = cigar[i] == '=' ? 0 : cigar[i] == 'X' ? 1 : cigar[i] == 'I' ? 2 : cigar[i] == 'D' ? 3 : -1;
+        if (op < 0) return false;
+        key |= (uint64_t)op << (2 * i);
+    }
+    key |= (uint64_t)cigar.size() << 58;
+    return true;
+}
+
+bool load_qscore_model(const std::string& name_or_path, QScoreModelHost& m, std::string& err) {
+    m = QScoreModelHost();
+    struct Row { std::string cigar; std::vector<int> scores; std::vector<double> probs; };
+    std::vector<Row> rows;
+    m.kmer_size = 1;
+    auto uniform = [&](const std::string& c, int lo, int hi) {
+        Row r; r.cigar = c;
+        int cnt = hi - lo + 1;
+        for (int q = lo; q <= hi; q++) { r.scores.push_back(q); r.probs.push_back(1.0 / cnt); }
+        rows.push_back(r);
+    };
+    if (name_or_path == "random") {          // py/tksm_badread.py:487-497
+        uniform("=", 1, 20); uniform("X", 1, 20); uniform("I", 1, 20);
+    } else if (name_or_path == "ideal") {    // py/tksm_badread.py:499-544
+        m.kmer_size = 9;
+        uniform("X", 1, 3); uniform("I", 1, 3); uniform("=", 4, 7); uniform("===", 8, 20); uniform("=====", 21, 30);
+        uniform("=======", 31, 40); uniform("=========", 41, 50);
+    } else {
+        std::string text;
+        if (!read_text_file(resolve_model(name_or_path, "qscore"), text, err)) return false;
+        size_t a = 0;
+        std::vector<std::string> parts, sp, qp;
+        while (a < text.size()) {
+            size_t b = text.find('\n', a);
+            if (b == std::string::npos) b = text.size();
+            std::string line = strip(text.substr(a, b - a));
+            a = b + 1;
+            if (line.empty()) continue;
+            split(line, ';', parts);
+            if (parts[0] == "overall") continue;
+            if (parts.size() < 3) { err = name_or_path + " does not seem to be a valid qscore model file"; return false; }
+            Row r; r.cigar = parts[0];
+            int kk = 0;
+            for (char c : r.cigar) kk += c != 'D';
+            m.kmer_size = std::max(m.kmer_size, kk);
+            split(parts[2], ',', sp);
+            for (auto& x : sp) {
+                if (x.empty()) continue;
+                split(x, ':', qp);
+                if (qp.size() < 2) { err = name_or_path + " does not seem to be a valid qscore model file"; return false; }
+                r.scores.push_back(atoi(qp[0].c_str()));
+                r.probs.push_back(strtod(qp[1].c_str(), nullptr));
+            }
+            // a later line with the same cigar replaces the earlier one (dict semantics)
+            bool replaced = false;
+            for (auto& e : rows) if (e.cigar == r.cigar) { e = r; replaced = true; break; }
+            if (!replaced) rows.push_back(std::move(r));
+        }
+    }
+    bool has_eq = false, has_x = false, has_i = false;
+    for (auto& r : rows) { has_eq |= r.cigar == "="; has_x |= r.cigar == "X"; has_i |= r.cigar == "I"; }
+    if (!(has_eq && has_x && has_i)) { err = "qscore model lacks one of the 1-mer cigars =, X, I"; return false; }
+    size_t n_slots = 1;
+    while (n_slots < 2 * rows.size()) n_slots *= 2;
+    m.n_slots = (int)n_slots;
+    m.keys.assign(n_slots, 0); m.row_off.assign(n_slots, 0); m.row_cnt.assign(n_slots, 0);
+    for (auto& r : rows) {
+        uint64_t key;
+        if (!encode_key(r.cigar, key)) { err = "q-score key not representable (longer than 29 ops): " + r.cigar; return false; }
+        size_t s = (size_t)(qs_hash(key) & (n_slots - 1));
+        while (m.keys[s] != 0) s = (s + 1) & (n_slots - 1);
+        m.keys[s] = key;
+        m.row_off[s] = (uint32_t)m.q_pool.size();
+        m.row_cnt[s] = (uint32_t)r.scores.size();
+        cdf_thresholds(r.probs, false, m.cdf_pool);
+        for (int q : r.scores) m.q_pool.push_back((uint8_t)q);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// identity distribution: max * Beta(a, b), tabulated as 65537 quantiles
+// ---------------------------------------------------------------------------------------------
+static double betacf(double a, double b, double x) {     // continued fraction of the incomplete beta (Lentz)
+    const double tiny = 1e-300, eps = 1e-16;
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0, c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 10000; m++) {
+        int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d; h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        double del = d * c; h *= del;
+        if (fabs(del - 1.0) < eps) break;
+    }
+    return h;
+}
+static double betainc(double a, double b, double x) {    // regularized I_x(a, b)
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    double lbt = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
+    if (x < (a + 1.0) / (a + b + 2.0)) return exp(lbt) * betacf(a, b, x) / a;
+    return 1.0 - exp(lbt) * betacf(b, a, 1.0 - x) / b;
+}
+static double beta_pdf(double a, double b, double x) {
+    if (x <= 0.0 || x >= 1.0) return 0.0;
+    return exp(lgamma(a + b) - lgamma(a) - lgamma(b) + (a - 1.0) * log(x) + (b - 1.0) * log1p(-x));
+}
+
+bool make_identity(double mean, double max, double stdev, IdentityHost& id, std::string& err) {
+    id = IdentityHost();
+    id.mean = mean / 100.0; id.stdev = stdev / 100.0; id.max_identity = max / 100.0;
+    if (id.mean == id.max_identity) { id.constant = true; id.value = id.mean; return true; }
+    if (id.stdev == 0.0) { id.max_identity = id.mean; id.constant = true; id.value = id.mean; return true; }
+    // beta_parameters, py/tksm_badread.py:747-757 (percent units, exactly as the reference calls it)
+    const double u = mean, s = stdev, m = max;
+    id.beta_a = (((1 - (u / m)) / ((s / m) * (s / m))) - (m / u)) * ((u / m) * (u / m));
+    id.beta_b = id.beta_a * ((m / u) - 1);
+    if (id.beta_a < 0.0 || id.beta_b < 0.0) {
+        err = "Error: invalid beta parameters for identity distribution - trying increasing the maximum identity or "
+              "reducing the standard deviation";
+        return false;
+    }
+    id.constant = false; id.value = id.max_identity;
+    id.qtab.assign(65537, 0.0);
+    const double a = id.beta_a, b = id.beta_b;
+    id.qtab[0] = 0.0; id.qtab[65536] = 1.0;
+    double x = 0.5 * std::min(1.0, a / (a + b));
+    for (int i = 1; i < 65536; i++) {
+        const double p = (double)i / 65536.0;
+        double lo = id.qtab[i - 1], hi = 1.0;
+        if (x <= lo || x >= hi) x = 0.5 * (lo + hi);
+        for (int it = 0; it < 200; it++) {
+            const double f = betainc(a, b, x) - p;
+            if (f > 0) hi = x; else lo = x;
+            const double d = beta_pdf(a, b, x);
+            double nx = d > 0 ? x - f / d : 0.5 * (lo + hi);
+            if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
+            if (fabs(nx - x) <= 1e-15 * fabs(x) || hi - lo <= 1e-16) { x = nx; break; }
+            x = nx;
+        }
+        id.qtab[i] = x;
+    }
+    return true;
+}
+
+}  // namespace tkh

@@ -1,0 +1,15 @@
+// tksm_main.cpp -- minimal dispatcher with the reference's calling convention (src/tksm.cpp:118-200):
+// `tksm sequence [args]` constructs the module with (argc - 1, argv + 1) and returns run().
+// Only the Seq exit module exists in this build; every other module name is reported as unknown.
+#include <cstdio>
+#include <cstring>
+
+#include "sequencer_module.h"
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s sequence [options]\n", argv[0]); return 1; }
+    if (!strcmp(argv[1], "sequence")) return Sequencer_module{argc - 1, argv + 1}.run();
+    if (!strcmp(argv[1], "list")) { printf("sequence\n"); return 0; }
+    fprintf(stderr, "Unknown kisim: %s (this build provides only `sequence`)\n", argv[1]);
+    return 1;
+}
