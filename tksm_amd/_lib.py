@@ -1,0 +1,93 @@
+"""ctypes binding of libtksmseq.so -- the C-ABI declared in include/tksmseq.h.
+
+The shared library is the product; this module only loads it.  There is no fallback: if the
+library is missing or was not built, importing the compute path raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtksmseq.so")
+
+OK, EINVAL, EIO, EDEVICE, ENOMEM, ESTATE, ELIMIT = range(7)
+MODE_PERFECT, MODE_BADREAD = 0, 1
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_intervals", C.c_uint64), ("n_mods", C.c_uint64),
+                ("n_literals", C.c_uint64), ("literal_bytes", C.c_uint64), ("id_bytes", C.c_uint64),
+                ("reads", C.c_void_p), ("intervals", C.c_void_p), ("mods", C.c_void_p), ("literals", C.c_void_p),
+                ("literal_pool", C.c_void_p), ("ids", C.c_void_p), ("id_pool", C.c_void_p)]
+
+
+class RunParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_read_index", C.c_uint64), ("read_index_stride", C.c_uint64),
+                ("mode", C.c_int32), ("fastq", C.c_int32), ("compute_qual", C.c_int32), ("collect_stats", C.c_int32),
+                ("perfect_of_badread", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("records", C.c_void_p), ("record_offsets", C.c_void_p), ("records_bytes", C.c_uint64),
+                ("n_reads", C.c_uint64), ("bases_in", C.c_uint64), ("bases_out", C.c_uint64),
+                ("kernel_ms", C.c_float * 8)]
+
+
+# every symbol include/tksmseq.h declares (checked by tests/test_abi.py without a GPU)
+SYMBOLS = [
+    "tksmseq_create", "tksmseq_destroy", "tksmseq_last_error", "tksmseq_version", "tksmseq_set_stream",
+    "tksmseq_synchronize", "tksmseq_reference_add_fasta", "tksmseq_reference_add_contig",
+    "tksmseq_reference_contig_id", "tksmseq_reference_info", "tksmseq_load_error_model",
+    "tksmseq_load_qscore_model", "tksmseq_set_identity", "tksmseq_get_error_model", "tksmseq_get_qscore_model",
+    "tksmseq_get_identity", "tksmseq_batch_create", "tksmseq_batch_from_mdf_text", "tksmseq_batch_info",
+    "tksmseq_batch_free", "tksmseq_run", "tksmseq_set_output_buffer", "tksmseq_set_timing",
+    "tksmseq_result_download", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
+]
+
+_lib = None
+
+
+def load():
+    """Loads libtksmseq.so (raises if it has not been built: there is no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C tksm_amd/csrc).  tksm_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    P = C.POINTER
+    sig = {
+        "tksmseq_create": (C.c_int, [C.c_int, P(vp)]),
+        "tksmseq_destroy": (None, [vp]),
+        "tksmseq_last_error": (C.c_char_p, [vp]),
+        "tksmseq_version": (C.c_char_p, []),
+        "tksmseq_set_stream": (C.c_int, [vp, vp]),
+        "tksmseq_synchronize": (C.c_int, [vp]),
+        "tksmseq_reference_add_fasta": (C.c_int, [vp, C.c_char_p]),
+        "tksmseq_reference_add_contig": (C.c_int, [vp, C.c_char_p, vp, u64, C.c_int]),
+        "tksmseq_reference_contig_id": (C.c_int, [vp, C.c_char_p]),
+        "tksmseq_reference_info": (C.c_int, [vp, P(u64), P(u64), P(u64)]),
+        "tksmseq_load_error_model": (C.c_int, [vp, C.c_char_p]),
+        "tksmseq_load_qscore_model": (C.c_int, [vp, C.c_char_p]),
+        "tksmseq_set_identity": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
+        "tksmseq_get_error_model": (C.c_int, [vp, P(i32), P(i32), P(i32), vp, vp, vp]),
+        "tksmseq_get_qscore_model": (C.c_int, [vp, P(i32), P(i32), P(u64), vp, vp, vp, vp, vp]),
+        "tksmseq_get_identity": (C.c_int, [vp, P(i32), P(C.c_double), P(C.c_double), P(C.c_double), vp]),
+        "tksmseq_batch_create": (C.c_int, [vp, P(BatchDesc), P(vp)]),
+        "tksmseq_batch_from_mdf_text": (C.c_int, [vp, C.c_char_p, u64, P(vp)]),
+        "tksmseq_batch_info": (C.c_int, [vp, P(u64), P(u64), P(u64)]),
+        "tksmseq_batch_free": (None, [vp, vp]),
+        "tksmseq_run": (C.c_int, [vp, vp, P(RunParams), P(Result)]),
+        "tksmseq_set_output_buffer": (C.c_int, [vp, vp, u64]),
+        "tksmseq_set_timing": (C.c_int, [vp, C.c_int]),
+        "tksmseq_result_download": (C.c_int, [vp, vp, vp]),
+        "tksmseq_stats_download": (C.c_int, [vp, vp, vp]),
+        "tksmseq_interleave_records": (C.c_int, [vp, C.c_int, P(vp), P(vp), P(u64), vp, u64, P(u64)]),
+        "tksmseq_sequence_main": (C.c_int, [C.c_int, P(C.c_char_p)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib
