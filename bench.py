@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Seq hot path (BASELINE.json: sequenced reads/s + Gbases/s, %HBM roofline).
+
+A "step" = one pass of the hot path (splice -> Badread errors -> q-scores -> FASTQ records) over one batch of
+synthetic molecules with inputs resident in HBM.  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
+Badread error+qual model" -- synthetic 24 x 128 Mb genome (GRCh38 is not available offline), nanopore2020 error +
+q-score models, identity 84,99,5.5, FASTQ with computed qualities; the 10 M molecules are processed as steps of
+--batch molecules each (default steps x batch is smaller so the default run finishes in minutes).
+
+N>1 (torchrun, one rank per GPU): molecules are sharded round-robin (global read g -> rank g mod P, counter-based
+RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RCCL gather of the per-rank record
+streams to rank 0 and the device-side interleave into global read order (the FASTQ-order exchange step).
+
+Prints ONE JSON line on rank 0 (contract in the round instructions), including `roofline` (dominant kernel
+k_simulate: algorithmic bytes per launch / its HIP-event duration) and `cpu_baseline` (the CPU oracle on a bounded
+sample of the same workload, all host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline_worker(args):
+    """Oracle leg: splice + badread record for a slice of the sample (runs in a forked worker)."""
+    lo, hi = args
+    po, S = _CB["po"], _CB
+    t0 = time.time()
+    nb = 0
+    for i in range(lo, hi):
+        raw = po.splice(S["ref"], S["mols"][i][1])
+        rec, _ = po.badread_record(True, 42, i, raw, S["ident"], S["em"], S["qm"], True, S["mols"][i][0])
+        nb += len(raw)
+    return hi - lo, nb, time.time() - t0
+
+
+_CB = {}
+
+
+def host_cores():
+    """Worker count for the CPU leg: the affinity mask, capped at the 16-core share a one-GPU box gives us."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("TKSM_BENCH_CORES", "16"))))
+
+
+def cpu_baseline(n_reads, mean_len, seconds_budget=20.0):
+    """Times the CPU oracle (oracle/tksm_oracle.c, kind "port") on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from multiprocessing import Pool
+    from tksm_amd import synthetic
+    cores = host_cores()
+    rs = np.random.RandomState(11)
+    lens = [1_000_000] * 24
+    ref = {f"chr{i + 1}": rs.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes().decode() for i, n in enumerate(lens)}
+    m = synthetic.make_molecules(rs, lens, n_reads, mean_len, mean_len * 0.2)
+    text = synthetic.mdf_text(m, list(ref))
+    mols = list(po.mdf_generator(text.splitlines(keepends=True)))
+    models = os.path.join(ROOT, "tksm_amd", "models", "badread")
+    _CB.update(po=po, ref=ref, mols=mols, em=po.ErrorModel(os.path.join(models, "nanopore2020.error.gz")),
+               qm=po.QScoreModel(os.path.join(models, "nanopore2020.qscore.gz")), ident=po.Identities(84.0, 5.5, 99.0))
+    chunks = [(i * n_reads // cores, (i + 1) * n_reads // cores) for i in range(cores)]
+    t0 = time.time()
+    with Pool(cores) as p:
+        res = p.map(cpu_baseline_worker, chunks)
+    wall = time.time() - t0
+    n = sum(r[0] for r in res)
+    return {"value": n / wall, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"{n} reads of the same synthetic bulk workload (mean {mean_len} b, 24 x 1 Mb host genome), "
+                      f"CPU oracle oracle/tksm_oracle.c on {cores} processes, {wall:.1f} s wall",
+            "gbases_per_s": sum(r[1] for r in res) / wall / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=262144, help="molecules per GPU per step")
+    ap.add_argument("--mean-len", type=int, default=1000)
+    ap.add_argument("--genome-contigs", type=int, default=24)
+    ap.add_argument("--contig-mb", type=int, default=128)
+    ap.add_argument("--kind", default="bulk", choices=["bulk", "scrna"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU sample (0 = sized for ~20 s)")
+    ap.add_argument("--skip-qual", action="store_true")
+    ap.add_argument("--perfect", action="store_true", help="bench the integer splice path only (--perfect)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline and not args.perfect:
+        # oracle leg first, before this process touches the GPU (it forks worker processes)
+        cores = host_cores()
+        n_cpu = args.cpu_sample or max(64, int(cores * 15.0 / 0.0055 * (1000.0 / args.mean_len)))
+        cpu_base = cpu_baseline(n_cpu, args.mean_len)
+
+    import torch
+    import torch.distributed as dist
+    from tksm_amd import synthetic
+    from tksm_amd.sequence import Sequencer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the Seq hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    seqr = Sequencer(local_rank, stream=stream)
+
+    # ---- inputs resident in HBM before the timed region: genome packed on the device, models, one batch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    clen = args.contig_mb * 1_000_000
+    for c in range(args.genome_contigs):
+        codes = torch.randint(0, 4, (clen,), dtype=torch.uint8, device=dev, generator=gen)
+        ascii_t = lut[codes.long()]
+        seqr.add_contig(f"chr{c + 1}", ascii_t)
+        del codes, ascii_t
+    models = os.path.join(ROOT, "tksm_amd", "models", "badread")
+    target = "perfect" if args.perfect else "badread"
+    if not args.perfect:
+        seqr.set_identity(84.0, 99.0, 5.5)
+        seqr.load_error_model(os.path.join(models, "nanopore2020.error.gz"))
+        seqr.load_qscore_model(os.path.join(models, "nanopore2020.qscore.gz"))
+    rs = np.random.RandomState(2 + rank)
+    m = synthetic.make_molecules(rs, [clen] * args.genome_contigs, args.batch, args.mean_len, args.mean_len * 0.2, kind=args.kind,
+                                 id_prefix=f"m{rank}")
+    batch = seqr.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+    cap = int(args.batch * (2.6 * (args.mean_len + 60) + 256))
+    out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+    seqr.set_output_buffer(out_t.data_ptr(), cap)
+    off_t = torch.empty(args.batch + 1, dtype=torch.int64, device=dev)
+    seqr.set_timing(True)
+    compute_q = not args.skip_qual
+
+    gathered = None
+
+    def step(t):
+        res = seqr.run(batch, target=target, fastq=True, compute_qual=compute_q, seed=42,
+                       first_read_index=t * args.batch * world + rank, stride=world)
+        if world > 1:
+            # FASTQ ordering: sizes -> padded gather of record bytes + offsets to rank 0 -> interleave on device
+            res.copy_to_device(None, off_t.data_ptr())
+            nbytes = torch.tensor([res.records_bytes], dtype=torch.int64, device=dev)
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(sizes, nbytes)
+            mx = int(max(int(s.item()) for s in sizes))
+            nonlocal gathered
+            if rank == 0:
+                if gathered is None or gathered[0][0].numel() < mx:
+                    gathered = ([torch.empty(mx + mx // 8, dtype=torch.uint8, device=dev) for _ in range(world)],
+                                [torch.empty(args.batch + 1, dtype=torch.int64, device=dev) for _ in range(world)],
+                                torch.empty(int(cap * world), dtype=torch.uint8, device=dev))
+                width = gathered[0][0].numel()
+            else:
+                width = 0
+            wt = torch.tensor([width], dtype=torch.int64, device=dev)
+            dist.broadcast(wt, 0)
+            width = int(wt.item())
+            dist.gather(out_t[:width], gathered[0] if rank == 0 else None, dst=0)
+            dist.gather(off_t, gathered[1] if rank == 0 else None, dst=0)
+            if rank == 0:
+                seqr.interleave_records([g.data_ptr() for g in gathered[0]], [g.data_ptr() for g in gathered[1]],
+                                        [args.batch] * world, gathered[2].data_ptr(), gathered[2].numel())
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        step(t)
+    fence()
+    t0 = time.perf_counter()
+    sim_ms, tot_ms, rec_bytes, bases_in, bases_out = [], [], 0, 0, 0
+    for t in range(args.warmup, args.warmup + args.steps):
+        res = step(t)
+        sim_ms.append(res.kernel_ms[1])
+        tot_ms.append(res.kernel_ms[4])
+        rec_bytes += res.records_bytes
+        bases_in += res.bases_in
+        bases_out += res.bases_out
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        agg = torch.tensor([bases_in, bases_out], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg)
+        bases_in_all, bases_out_all = float(agg[0].item()), float(agg[1].item())
+    else:
+        bases_in_all, bases_out_all = float(bases_in), float(bases_out)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    reads = args.batch * world * args.steps
+    value = reads / elapsed
+    alg = synthetic.algorithmic_bytes(m, rec_bytes / args.steps)
+    sim_avg_ms = float(np.mean(sim_ms))
+    achieved = alg / (sim_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("batch") == args.batch and tj.get("kind", "bulk") == args.kind:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "sequenced reads/s", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"Bulk molecules, Badread error+qual model (nanopore2020, identity 84,99,5.5), "
+                               f"{args.genome_contigs} x {args.contig_mb} Mb random genome, FASTQ"
+                               if not args.perfect else "Bulk molecules, --perfect splice path, FASTQ",
+                   "kind": args.kind, "molecules_per_gpu_per_step": args.batch, "mean_len": args.mean_len,
+                   "compute_qual": bool(compute_q and not args.perfect), "sharding": f"round-robin x{world}",
+                   "ordering_gather": world > 1},
+        "gbases_per_s": bases_in_all / elapsed / 1e9,
+        "gbases_out_per_s": bases_out_all / elapsed / 1e9,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_simulate",
+                     "kernel_ms": sim_avg_ms, "algorithmic_bytes_per_launch": alg,
+                     "all_kernels_ms": float(np.mean(tot_ms))},
+    }
+    out["cpu_baseline"] = cpu_base
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,6 +146,9 @@ int tksmseq_set_output_buffer(tksmseq_ctx* ctx, void* device_ptr, uint64_t capac
 int tksmseq_set_timing(tksmseq_ctx* ctx, int enable);   /* hipEvent per stage, read via result.kernel_ms */
 /* Copies the last result to host memory (records: records_bytes, offsets: n_reads + 1). */
 int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets);
+/* Device-to-device copies of the last result into caller buffers (either may be NULL): records_bytes bytes and
+ * n_reads + 1 u64 offsets.  Asynchronous on the context's stream. */
+int tksmseq_result_copy_device(tksmseq_ctx* ctx, void* records_dst, void* offsets_dst);
 /* Per-read debug statistics of the last badread run with collect_stats = 1: int32[n_reads][16]
  * {n_draws, change_count, n_aligns, frag_len, new_len, start_trim, end_trim, status, ...} +
  * double[n_reads][2] {errors, target_identity}. */

@@ -40,7 +40,7 @@ SYMBOLS = [
     "tksmseq_load_qscore_model", "tksmseq_set_identity", "tksmseq_get_error_model", "tksmseq_get_qscore_model",
     "tksmseq_get_identity", "tksmseq_batch_create", "tksmseq_batch_from_mdf_text", "tksmseq_batch_info",
     "tksmseq_batch_free", "tksmseq_run", "tksmseq_set_output_buffer", "tksmseq_set_timing",
-    "tksmseq_result_download", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
+    "tksmseq_result_download", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def load():
         "tksmseq_set_output_buffer": (C.c_int, [vp, vp, u64]),
         "tksmseq_set_timing": (C.c_int, [vp, C.c_int]),
         "tksmseq_result_download": (C.c_int, [vp, vp, vp]),
+        "tksmseq_result_copy_device": (C.c_int, [vp, vp, vp]),
         "tksmseq_stats_download": (C.c_int, [vp, vp, vp]),
         "tksmseq_interleave_records": (C.c_int, [vp, C.c_int, P(vp), P(vp), P(u64), vp, u64, P(u64)]),
         "tksmseq_sequence_main": (C.c_int, [C.c_int, P(C.c_char_p)]),

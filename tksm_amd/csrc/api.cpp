@@ -569,6 +569,15 @@ int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offset
     return TKSMSEQ_OK;
 }
 
+int tksmseq_result_copy_device(tksmseq_ctx* ctx, void* records_dst, void* offsets_dst) {
+    if (!ctx || !ctx->have_last) return TKSMSEQ_ESTATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (records_dst && ctx->last.records_bytes && records_dst != ctx->last.records)
+        HIPCHK(ctx, hipMemcpyAsync(records_dst, ctx->last.records, ctx->last.records_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (offsets_dst) HIPCHK(ctx, hipMemcpyAsync(offsets_dst, ctx->last.record_offsets, (ctx->last.n_reads + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return TKSMSEQ_OK;
+}
+
 int tksmseq_stats_download(tksmseq_ctx* ctx, int32_t* istats, double* dstats) {
     if (!ctx || !ctx->have_last || !ctx->have_stats) return TKSMSEQ_ESTATE;
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -59,6 +59,10 @@ class RunResult:
         self._seq._chk(self._seq._lib.tksmseq_result_download(self._seq._ctx, rec.ctypes.data, off.ctypes.data))
         return rec.tobytes(), off
 
+    def copy_to_device(self, records_ptr=None, offsets_ptr=None):
+        self._seq._chk(self._seq._lib.tksmseq_result_copy_device(
+            self._seq._ctx, C.c_void_p(records_ptr) if records_ptr else None, C.c_void_p(offsets_ptr) if offsets_ptr else None))
+
     def records(self):
         rec, off = self.download()
         return [rec[int(off[i]):int(off[i + 1])] for i in range(self.n_reads)]

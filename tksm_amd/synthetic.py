@@ -1,0 +1,103 @@
+"""Seeded synthetic inputs for the benchmark configurations of BASELINE.json.
+
+GRCh38 / GENCODE are not available offline, so the genome is i.i.d. uniform ACGT and the molecules
+are transcript-like multi-interval records:
+  lengths  ~ round(Normal(mean, sd)) clipped to >= 200           ("1 kb mean")
+  bulk     S ~ U{1..4} intervals on random contigs, one strand per molecule, 10 % of intervals
+           carry one substitution
+  scrna    + 16-base barcode literal + 10-base UMI literal + polyA literal ~ Normal(15, 7.5)
+           clipped to [0, 5000] (README.md:150-157 pattern; src/scb.cpp:73-82, src/polyA.cpp:133-148)
+Arrays are produced directly in the binary batch layout of include/tksmseq.h.
+"""
+import numpy as np
+
+
+def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", id_prefix="mol"):
+    """Returns dict(reads, intervals, mods, literals, literal_pool, ids, id_pool, raw_len) as numpy arrays."""
+    contig_lens = np.asarray(contig_lens, np.int64)
+    length = np.maximum(200, np.rint(rs.normal(mean_len, sd_len, n))).astype(np.int64)
+    S = rs.randint(1, 5, n)
+    minus = rs.randint(0, 2, n).astype(np.uint32)
+    n_gen = int(S.sum())
+    mol_of = np.repeat(np.arange(n), S)
+    first = np.concatenate([[0], np.cumsum(S)[:-1]])
+    j_in = np.arange(n_gen) - first[mol_of]
+    base = length[mol_of] // S[mol_of]
+    ilen = base + (j_in == S[mol_of] - 1) * (length[mol_of] - base * S[mol_of])
+    contig = rs.randint(0, len(contig_lens), n_gen)
+    start = (rs.random_sample(n_gen) * (contig_lens[contig] - ilen)).astype(np.int64)
+    has_mod = rs.random_sample(n_gen) < 0.10
+    mod_pos = (rs.random_sample(n_gen) * ilen).astype(np.int64)[has_mod]
+    mod_chr = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, int(has_mod.sum()))]
+
+    lit_per_mol = 0
+    literals, pool = np.zeros((0, 2), np.uint64), b""
+    if kind == "scrna":
+        lit_per_mol = 3
+        # barcode whitelist of 4096 16-mers, UMIs unique per molecule, polyA of variable length
+        wl = rs.choice(np.frombuffer(b"ACGT", np.uint8), (4096, 16))
+        umi = rs.choice(np.frombuffer(b"ACGT", np.uint8), (n, 10))
+        pa_len = np.clip(np.rint(rs.normal(15, 7.5, n)), 0, 5000).astype(np.int64)
+        max_pa = int(pa_len.max()) if n else 0
+        pool_arr = np.concatenate([wl.reshape(-1), umi.reshape(-1), np.full(max_pa, ord("A"), np.uint8)])
+        pool = pool_arr.tobytes()
+        lit = [(i * 16, 16) for i in range(4096)] + [(4096 * 16 + i * 10, 10) for i in range(n)] + [(4096 * 16 + n * 10, max_pa)]
+        literals = np.array(lit, np.uint64)
+        bc_of = rs.randint(0, 4096, n)
+    tot_iv = n_gen + lit_per_mol * n
+    intervals = np.zeros((tot_iv, 4), np.uint32)
+    ivl_count = S + lit_per_mol
+    ivl_begin = np.concatenate([[0], np.cumsum(ivl_count)[:-1]])
+    gpos = ivl_begin[mol_of] + j_in
+    mods_per_iv = np.zeros(tot_iv, np.int64)
+    mods_per_iv[gpos] = has_mod
+    mod_begin = np.concatenate([[0], np.cumsum(mods_per_iv)[:-1]])
+    intervals[gpos, 0] = contig
+    intervals[gpos, 1] = start
+    intervals[gpos, 2] = start + ilen
+    intervals[:, 3] = mod_begin
+    intervals[gpos, 3] |= (minus[mol_of] << 31)
+    if kind == "scrna":
+        lp = ivl_begin + S
+        intervals[lp, 0] = 0x80000000 | bc_of.astype(np.uint32)
+        intervals[lp, 2] = 16
+        intervals[lp + 1, 0] = 0x80000000 | (4096 + np.arange(n)).astype(np.uint32)
+        intervals[lp + 1, 2] = 10
+        intervals[lp + 2, 0] = 0x80000000 | np.uint32(4096 + n)
+        intervals[lp + 2, 2] = pa_len
+        length = length + 26 + pa_len
+    mods = np.stack([mod_pos, mod_chr.astype(np.int64)], 1).astype(np.uint32) if has_mod.any() else np.zeros((0, 2), np.uint32)
+    reads = np.stack([ivl_begin, ivl_count], 1).astype(np.uint32)
+    id_strs = [f"{id_prefix}_{i}".encode() for i in range(n)]
+    id_len = np.array([len(s) for s in id_strs], np.uint32)
+    id_off = np.concatenate([[0], np.cumsum(id_len)[:-1]]).astype(np.uint32)
+    return dict(reads=reads, intervals=intervals, mods=mods, literals=literals, literal_pool=pool,
+                ids=np.stack([id_off, id_len], 1).astype(np.uint32), id_pool=b"".join(id_strs), raw_len=length,
+                n_intervals_per_read=ivl_count, n_mods=len(mods))
+
+
+def algorithmic_bytes(m, records_bytes):
+    """B = B_mdf + B_ref + B_out per launch.
+    B_mdf = 8 + 16 S + 8 M per read (+ literal bytes / 4), B_ref = ceil(L / 4), B_out = the emitted record bytes."""
+    b_mdf = 8 * len(m["reads"]) + 16 * len(m["intervals"]) + 8 * len(m["mods"])
+    b_ref = int(np.sum((m["raw_len"] + 3) // 4))
+    return b_mdf + b_ref + int(records_bytes)
+
+
+def mdf_text(m, contig_names, literal_strings=None):
+    """The same molecules as MDF text (for the CPU oracle / text-path tests).  Small inputs only."""
+    out = []
+    ids, pool = m["ids"], m["id_pool"]
+    lits = m["literals"]
+    lp = m["literal_pool"]
+    nm = len(m["mods"])
+    for r, (b, c) in enumerate(m["reads"]):
+        out.append(f"+{pool[ids[r, 0]:ids[r, 0] + ids[r, 1]].decode()}\t1\t\n")
+        for i in range(b, b + c):
+            cg, st, en, mi = (int(x) for x in m["intervals"][i])
+            mb = mi & 0x7fffffff
+            me = int(m["intervals"][i + 1][3]) & 0x7fffffff if i + 1 < len(m["intervals"]) else nm
+            name = contig_names[cg] if not cg >> 31 else lp[int(lits[cg & 0x7fffffff, 0]):int(lits[cg & 0x7fffffff, 0]) + int(lits[cg & 0x7fffffff, 1])].decode()
+            mods = ",".join(f"{int(p)}{chr(int(ch))}" for p, ch in m["mods"][mb:me])
+            out.append(f"{name}\t{st}\t{en}\t{'-' if mi >> 31 else '+'}\t{mods}\n")
+    return "".join(out)
