@@ -1,0 +1,68 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/tksmseq.h declares, fails
+loudly without a GPU, and the CLI module keeps the reference's argument validation and exit codes.  No GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from tksm_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "tksmseq.h")).read()
+    declared = set(re.findall(r"\b(tksmseq_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.tksmseq_version()
+
+
+def test_no_cpu_fallback():
+    """without a usable device the product refuses to run (no routing through the oracle or any CPU path)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tksm_amd.sequence import Sequencer, TksmSeqError
+    with pytest.raises(TksmSeqError) as e:
+        Sequencer(0)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_the_oracle():
+    """the oracle is test infrastructure: nothing under tksm_amd/ may import, include, link or load it"""
+    bad = re.compile(r"import\s+pyoracle|from\s+oracle|from\s+pyoracle|#include\s+[\"<][^\">]*oracle|libtksm_oracle|dlopen\([^)]*oracle")
+    for root, _, files in os.walk(os.path.join(ROOT, "tksm_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert not bad.search(text), f
+
+
+def _cli(*args):
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    p = subprocess.run([exe, "sequence", *args], capture_output=True, text=True)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_cli_validation_matches_reference_messages():
+    # py/sequence.py:134-164 messages; argparse usage errors exit 2, sys.exit(msg) exits 1
+    assert _cli()[0] == 2
+    rc, _, err = _cli("-i", "x.mdf")
+    assert rc == 2 and "Must specify either --output or --perfect." in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fastq", "--badread-identity", "abc")
+    assert rc == 1 and "Error: could not parse --identity values" in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fastq", "--badread-identity", "101,99,5")
+    assert rc == 1 and "Error: mean read identity cannot be more than 100" in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fastq", "--badread-identity", "40,99,5")
+    assert rc == 1 and "Error: mean read identity must be at least 50" in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fastq", "--badread-identity", "95,90,5")
+    assert rc == 1 and "cannot be larger than max" in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fastq", "--badread-identity", "90,95,-1")
+    assert rc == 1 and "Error: read identity stdev cannot be negative" in err
+    rc, out, _ = _cli("--list")
+    assert rc == 0 and "badread_identity" in out.split() and "input" in out.split()
+    rc, _, err = _cli("-i", "x.mdf", "-O", "bam", "-o", "o.fq")
+    assert rc == 2 and "invalid choice" in err
