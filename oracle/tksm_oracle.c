@@ -190,62 +190,74 @@ static inline int code_of(uint8_t c) {
     switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
 }
 
-/* guided banded alignment, rows = fragment window [p0,p0+n), cols = joined new bases of the same
- * window (length m).  Row r (0..n) owns columns c_r-31 .. c_r+32 where c_r = joined length of the
- * first r slots (the generative path).  Cells outside the band are unreachable (INF).
- * mode 0: query = fragment (loop re-estimation, py/tksm_badread.py:409,:422): pred preference
- *         up (fragment-only 'I'), left (new-only 'D'), diagonal.
- * mode 1: query = new sequence (q-scores, py/tksm_badread.py:613): preference left (new-only,
- *         'I' in that cigar), up (fragment-only, 'D'), diagonal.
- * Returns matches and columns of the preferred optimal path; if trace != NULL also stores per
- * cell 2 bits (bit0 = up ok, bit1 = left ok) at trace[r*64 + lane]. */
+/* guided banded alignment of the fragment window F[0,n) (rows) against the joined new bases N[0,m) (columns),
+ * column by column.  Column j (1-based) belongs to slot owner[j-1] (0-based row of the slot that emitted that
+ * base; the generative path); it owns the 64 rows t_j .. t_j+63 (1-based), t_j = max(1, owner+1 - 31).
+ * Cells above a column's window are unreachable (INF); cells below it are "virtual": value of the window's bottom
+ * cell + distance, predecessor = up.  Row 0 (H[0][j] = j) is the real boundary while t_j == 1.
+ * mode 0: query = fragment (loop re-estimation, py/tksm_badread.py:409,:422): predecessor preference
+ *         up (fragment-only, 'I'), left (new-only, 'D'), diagonal.
+ * mode 1: query = new sequence (q-scores, py/tksm_badread.py:613): preference left (read-only, 'I' in that
+ *         cigar), up (fragment-only, 'D'), diagonal.
+ * Returns the distance and matches / columns of the preferred optimal path; if trace != NULL stores per column
+ * j (1..m) at trace[j*64 + b] bit0 = up ok, bit1 = left ok and the window top in ttop[j]. */
 #define BW 32
 #define INF 0x3fffffff
 typedef struct { int32_t h, m, c; } cell;
 
-static int band_align(const uint8_t* F, int n, const uint8_t* N, int m, const uint32_t* cen /* n+1 */,
-                      int mode, int* out_match, int* out_cols, uint8_t* trace) {
-    cell prev[2 * BW], cur[2 * BW];
-    for (int l = 0; l < 2 * BW; l++) {
-        int j = (int)cen[0] - (BW - 1) + l;
-        if (j >= 0 && j <= m) { prev[l].h = j; prev[l].m = 0; prev[l].c = j; }
-        else prev[l].h = INF;
-        if (trace) trace[l] = (j >= 1 && j <= m) ? 2 : 0;
-    }
-    for (int r = 1; r <= n; r++) {
-        int delta = (int)cen[r] - (int)cen[r - 1];
-        uint8_t fc = F[r - 1];
-        for (int l = 0; l < 2 * BW; l++) {
-            int j = (int)cen[r] - (BW - 1) + l;
-            if (j < 0 || j > m) { cur[l].h = INF; if (trace) trace[(size_t)r * 64 + l] = 0; continue; }
-            int lu = l + delta, ld = l + delta - 1;
-            int32_t hu = (lu >= 0 && lu < 2 * BW) ? prev[lu].h : INF;
-            int32_t hd = (j >= 1 && ld >= 0 && ld < 2 * BW) ? prev[ld].h : INF;
-            int32_t hl = (l >= 1) ? cur[l - 1].h : INF;
-            int match = (j >= 1) && (fc == N[j - 1]);
-            int32_t vd = hd >= INF ? INF : hd + (match ? 0 : 1);
-            int32_t vu = hu >= INF ? INF : hu + 1;
-            int32_t vl = hl >= INF ? INF : hl + 1;
+static inline cell col_cell(const cell* col, int t, int i, int jcol) {
+    /* value of row i (1-based, i >= 1) in a finished column whose window starts at row t; jcol = column index */
+    cell r;
+    if (i == 0) { if (t == 1) { r.h = jcol; r.m = 0; r.c = jcol; } else r.h = INF; return r; }
+    int b = i - t;
+    if (b < 0) { r.h = INF; return r; }
+    if (b <= 63) return col[b];
+    r = col[63];
+    if (r.h < INF) { r.h += b - 63; r.c += b - 63; }
+    return r;
+}
+
+static int band_align(const uint8_t* F, int n, const uint8_t* N, int m, const uint32_t* owner /* m */,
+                      int mode, int* out_match, int* out_cols, uint8_t* trace, int32_t* ttop) {
+    cell prev[64], cur[64];
+    int tp = 1;
+    for (int b = 0; b < 64; b++) { prev[b].h = 1 + b; prev[b].m = 0; prev[b].c = 1 + b; }
+    for (int j = 1; j <= m; j++) {
+        int g = (int)owner[j - 1] + 1;
+        int t = g - (BW - 1) > 1 ? g - (BW - 1) : 1;
+        uint8_t nc = N[j - 1];
+        if (ttop) ttop[j] = t;
+        for (int b = 0; b < 64; b++) {
+            int i = t + b;
+            if (i > n) { cur[b].h = INF; if (trace) trace[(size_t)j * 64 + b] = 0; continue; }
+            cell up;
+            if (b >= 1) up = cur[b - 1];
+            else if (t == 1) { up.h = j; up.m = 0; up.c = j; }
+            else up.h = INF;
+            cell dg = col_cell(prev, tp, i - 1, j - 1);
+            cell lf = col_cell(prev, tp, i, j - 1);
+            int match = F[i - 1] == nc;
+            int32_t vd = dg.h >= INF ? INF : dg.h + (match ? 0 : 1);
+            int32_t vu = up.h >= INF ? INF : up.h + 1;
+            int32_t vl = lf.h >= INF ? INF : lf.h + 1;
             int32_t h = vd < vu ? vd : vu;
             if (vl < h) h = vl;
-            cur[l].h = h;
-            if (h >= INF) { if (trace) trace[(size_t)r * 64 + l] = 0; continue; }
+            cur[b].h = h;
+            if (h >= INF) { if (trace) trace[(size_t)j * 64 + b] = 0; continue; }
             int upok = (vu == h), leftok = (vl == h);
-            if (trace) trace[(size_t)r * 64 + l] = (uint8_t)(upok | (leftok << 1));
-            int first_up = (mode == 0);
-            int take; /* 0 up, 1 left, 2 diag */
-            if (first_up) take = upok ? 0 : (leftok ? 1 : 2);
-            else take = leftok ? 1 : (upok ? 0 : 2);
-            if (take == 0) { cur[l].m = prev[lu].m; cur[l].c = prev[lu].c + 1; }
-            else if (take == 1) { cur[l].m = cur[l - 1].m; cur[l].c = cur[l - 1].c + 1; }
-            else { cur[l].m = prev[ld].m + match; cur[l].c = prev[ld].c + 1; }
+            if (trace) trace[(size_t)j * 64 + b] = (uint8_t)(upok | (leftok << 1));
+            int take = mode == 0 ? (upok ? 0 : (leftok ? 1 : 2)) : (leftok ? 1 : (upok ? 0 : 2));
+            if (take == 0) { cur[b].m = up.m; cur[b].c = up.c + 1; }
+            else if (take == 1) { cur[b].m = lf.m; cur[b].c = lf.c + 1; }
+            else { cur[b].m = dg.m + match; cur[b].c = dg.c + 1; }
         }
         memcpy(prev, cur, sizeof(cur));
+        tp = t;
     }
-    int lf = m - (int)cen[n] + (BW - 1);
-    if (lf < 0 || lf >= 2 * BW || prev[lf].h >= INF) return -1;
-    *out_match = prev[lf].m; *out_cols = prev[lf].c;
-    return prev[lf].h;
+    cell f = col_cell(prev, tp, n, m);
+    if (n - tp > 63 || f.h >= INF) return -1;
+    *out_match = f.m; *out_cols = f.c;
+    return f.h;
 }
 
 /* full-matrix version of the same recurrence and preference (no band) -- used by tests to show
@@ -292,14 +304,11 @@ static int full_align(const uint8_t* F, int n, const uint8_t* N, int m, int mode
     return dist;
 }
 
-/* join new bases of window [p0,p0+n) into buf, fill centres; returns joined length */
-static int join_window(const fstate* s, int p0, int n, uint8_t* buf, uint32_t* cen) {
+/* join new bases of window [p0,p0+n) into buf; owner[j] = window-relative slot of joined base j; returns joined length */
+static int join_window(const fstate* s, int p0, int n, uint8_t* buf, uint32_t* owner) {
     int m = 0;
-    for (int r = 0; r < n; r++) {
-        cen[r] = (uint32_t)m;
-        for (int b = 0; b < s->slen[p0 + r]; b++) buf[m++] = s->sb[p0 + r][b];
-    }
-    cen[n] = (uint32_t)m;
+    for (int r = 0; r < n; r++)
+        for (int b = 0; b < s->slen[p0 + r]; b++) { owner[m] = (uint32_t)r; buf[m++] = s->sb[p0 + r][b]; }
     return m;
 }
 
@@ -345,7 +354,7 @@ int oracle_sequence_fragment(const uint8_t* raw, int raw_len, double target_iden
     s.sb = (uint8_t(*)[8])malloc((size_t)L * 8);
     s.changed = (uint8_t*)calloc((size_t)L, 1);
     uint8_t* joined = (uint8_t*)malloc((size_t)L * 6 + 16);
-    uint32_t* cen = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)L + 1));
+    uint32_t* cen = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)L * 6 + 16));   /* owner of each joined base */
     memset(st, 0, sizeof(*st));
     /* :334-341 pad with k random bases each side (tail noise: no_noise) */
     ph4 pad = rng(seed, read, ST_PAD, 0);
@@ -423,7 +432,7 @@ int oracle_sequence_fragment(const uint8_t* raw, int raw_len, double target_iden
                 if (L <= 1000) {                                    /* ALIGNMENT_SIZE */
                     int m = join_window(&s, 0, L, joined, cen);
                     dist = use_full ? full_align(s.frag, L, joined, m, 0, &mt, &cols, NULL, NULL)
-                                    : band_align(s.frag, L, joined, m, cen, 0, &mt, &cols, NULL);
+                                    : band_align(s.frag, L, joined, m, cen, 0, &mt, &cols, NULL, NULL);
                     if (dist < 0) { st->band_fail++; dist = full_align(s.frag, L, joined, m, 0, &mt, &cols, NULL, NULL); }
                     double ident = cols ? (double)mt / (double)cols : 0.0;
                     errors = (1.0 - ident) * frag_len;
@@ -432,7 +441,7 @@ int oracle_sequence_fragment(const uint8_t* raw, int raw_len, double target_iden
                     int pos = (int)mulhi32(w, (uint32_t)(L - 1000 + 1));
                     int m = join_window(&s, pos, 1000, joined, cen);
                     dist = use_full ? full_align(s.frag + pos, 1000, joined, m, 0, &mt, &cols, NULL, NULL)
-                                    : band_align(s.frag + pos, 1000, joined, m, cen, 0, &mt, &cols, NULL);
+                                    : band_align(s.frag + pos, 1000, joined, m, cen, 0, &mt, &cols, NULL, NULL);
                     if (dist < 0) { st->band_fail++; dist = full_align(s.frag + pos, 1000, joined, m, 0, &mt, &cols, NULL, NULL); }
                     double ident = cols ? (double)mt / (double)cols : 0.0;
                     double estimated = (1.0 - ident) * frag_len;
@@ -457,21 +466,29 @@ int oracle_sequence_fragment(const uint8_t* raw, int raw_len, double target_iden
         int nops = 0, mt = 0, cols = 0;
         if (use_full) full_align(s.frag, L, joined, m, 1, &mt, &cols, ops, &nops);
         else {
-            uint8_t* trace = (uint8_t*)malloc((size_t)(L + 1) * 64);
-            int dist = band_align(s.frag, L, joined, m, cen, 1, &mt, &cols, trace);
+            uint8_t* trace = (uint8_t*)malloc((size_t)(m + 1) * 64);
+            int32_t* ttop = (int32_t*)malloc(sizeof(int32_t) * ((size_t)m + 1));
+            int dist = band_align(s.frag, L, joined, m, cen, 1, &mt, &cols, trace, ttop);
             if (dist < 0) { st->band_fail++; full_align(s.frag, L, joined, m, 1, &mt, &cols, ops, &nops); }
             else {
                 int r = L, j = m, kk = 0;
                 while (r > 0 || j > 0) {
-                    int l = j - (int)cen[r] + (BW - 1);
-                    uint8_t tb = trace[(size_t)r * 64 + l];
-                    if (tb & 2) { ops[kk++] = 'I'; j--; }
-                    else if (tb & 1) { ops[kk++] = 'D'; r--; }
+                    int mv;                                  /* 0 up, 1 left, 2 diag */
+                    if (j == 0) mv = 0;
+                    else if (r == 0) mv = 1;
+                    else {
+                        int bb = r - ttop[j];
+                        if (bb > 63) mv = 0;                 /* virtual cell below the window */
+                        else { uint8_t tb = trace[(size_t)j * 64 + bb]; mv = (tb & 2) ? 1 : ((tb & 1) ? 0 : 2); }
+                    }
+                    if (mv == 1) { ops[kk++] = 'I'; j--; }
+                    else if (mv == 0) { ops[kk++] = 'D'; r--; }
                     else { ops[kk++] = (s.frag[r - 1] == joined[j - 1]) ? '=' : 'X'; r--; j--; }
                 }
                 for (int a = 0, b = kk - 1; a < b; a++, b--) { uint8_t x = ops[a]; ops[a] = ops[b]; ops[b] = x; }
                 nops = kk;
             }
+            free(ttop);
             free(trace);
         }
         actual_identity = cols ? (double)mt / (double)cols : 0.0;

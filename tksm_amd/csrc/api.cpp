@@ -447,7 +447,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     int wgs_per_cu = std::min(std::min(32 / wpw, 16), std::max(1, (160 * 1024) / std::max(lds, 1)));
     const uint64_t want = (n + wpw - 1) / wpw;
     const int n_wgs = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->n_cus * wgs_per_cu));
-    const int trace_words = ((lcap >> 4) + 2) * 64;
+    const int trace_words = (ncap + 2) * 4;   // {up mask, left mask} u64 per column of the final alignment
 
     HIPCHK(ctx, ctx->w_rawlen.ensure(n * 4 + 16));
     HIPCHK(ctx, ctx->w_slotcap.ensure(n * 8 + 16));

@@ -160,67 +160,74 @@ __global__ void k_read_lengths(BatchView B, RefView R, int k, int cap_num, int c
 }
 
 // ------------------------------------------------------------------------------------------------
-// S4/S5: guided banded global alignment on one wave.
-// rows = fragment window (n), cols = joined new bases (m); lane l of row r is column
-// c_r - 31 + l, c_r = joined length of the first r slots (the generative path).
+// S4/S5: guided banded global alignment on one wave (the byte-exact path; also the slow path for
+// reads with non-ACGT bytes).  Column-major: column j (1-based, joined new base N[j-1]) belongs to
+// slot owner[j-1] and owns the 64 fragment rows t_j .. t_j+63 (1-based), t_j = max(1, owner+1-31);
+// lane b = row t_j + b.  Above the window: unreachable.  Below: value of the bottom cell + distance,
+// predecessor up.  Row 0 (H[0][j] = j) is the real boundary while t_j == 1.
 // MODE 0: predecessor preference up, left, diagonal (query = fragment).
 // MODE 1: left, up, diagonal (query = new sequence; q-score cigar).
 // stat = matches << 16 | columns of the preferred optimal path.
+// TRACE: per column j the masks {up ok, left ok} are stored at trace[2*j], trace[2*j+1] (u64).
 // ------------------------------------------------------------------------------------------------
 struct AlnOut { int dist; uint32_t stat; };
 
 template <int MODE, bool TRACE>
-DEV AlnOut band_align(const uint8_t* F, const uint16_t* nbw, int n, const uint8_t* N, int m, int lane,
-                      uint32_t* trace) {
-    int c = 0, j = lane - 31;
-    bool inb = j >= 0 && j <= m;
-    int H = inb ? j : BIG;
-    uint32_t st = inb ? (uint32_t)j : 0u;
-    uint32_t tw = (TRACE && j >= 1 && j <= m) ? 2u : 0u;
-    for (int r = 1; r <= n; r++) {
-        const uint32_t code = nbw[r - 1];
-        const int d = slot_len(code);
-        const int fc = F[r - 1];
-        c += d; j = c - 31 + lane;
-        const int lu = lane + d, ld = lu - 1;
-        int hu = __shfl(H, lu & 63, 64); uint32_t su = __shfl(st, lu & 63, 64);
+DEV AlnOut band_align(const uint8_t* F, int n, const uint8_t* N, const uint16_t* owner, int m, int lane,
+                      unsigned long long* trace) {
+    int tp = 1;
+    int H = 1 + lane;                         // column 0: H[i][0] = i
+    uint32_t st = (uint32_t)(1 + lane);
+    for (int j = 1; j <= m; j++) {
+        const int g = (int)owner[j - 1] + 1;
+        const int t = max(1, g - 31);
+        const int sh = t - tp;
+        const int nc = N[j - 1];
+        const int i = t + lane;
+        const bool valid = i <= n;
+        const int fc = valid ? (int)F[i - 1] : 257;
+        const int match = fc == nc;
+        // previous column at rows i-1 (diag) and i (left)
+        const int ld = lane + sh - 1, ll = lane + sh;
+        const int hbot = __shfl(H, 63, 64); const uint32_t sbot = __shfl(st, 63, 64);
         int hd = __shfl(H, ld & 63, 64); uint32_t sd = __shfl(st, ld & 63, 64);
-        if (lu > 63) hu = BIG;
-        if (ld > 63 || ld < 0) hd = BIG;
-        inb = j >= 0 && j <= m;
-        const int tch = (j >= 1 && j <= m) ? (int)N[j - 1] : 256;
-        const int match = tch == fc;
-        const int vd = (j >= 1 && !is_inf(hd)) ? hd + 1 - match : BIG;
-        const int vu = !is_inf(hu) ? hu + 1 : BIG;
-        const int t = inb ? min(vd, vu) : BIG;
-        const int x = scan_min_incl(t - lane, lane) + lane;
-        const int h = (inb && !is_inf(x)) ? x : BIG;
-        int hl = __shfl_up(h, 1, 64);
-        if (lane == 0) hl = BIG;
+        int hl = __shfl(H, ll & 63, 64); uint32_t sl = __shfl(st, ll & 63, 64);
+        if (ld > 63) { hd = is_inf(hbot) ? BIG : hbot + (ld - 63); sd = sbot + (uint32_t)(ld - 63); }
+        else if (ld < 0) { if (tp == 1) { hd = j - 1; sd = (uint32_t)(j - 1); } else hd = BIG; }
+        if (ll > 63) { hl = is_inf(hbot) ? BIG : hbot + (ll - 63); sl = sbot + (uint32_t)(ll - 63); }
+        const int vd = !is_inf(hd) ? hd + 1 - match : BIG;
+        const int vl = !is_inf(hl) ? hl + 1 : BIG;
+        const int vu0 = (lane == 0 && t == 1) ? j + 1 : BIG;      // boundary row 0 above lane 0
+        const int tmin = valid ? min(min(vd, vl), vu0) : BIG;
+        const int x = scan_min_incl(tmin - lane, lane) + lane;
+        const int h = (valid && !is_inf(x)) ? x : BIG;
+        int hup = __shfl_up(h, 1, 64);
+        if (lane == 0) hup = BIG;
         const bool ok = !is_inf(h);
-        const bool upok = ok && vu == h;
-        const bool leftok = ok && !is_inf(hl) && hl + 1 == h;
+        const bool upok = ok && (lane == 0 ? vu0 == h : (!is_inf(hup) && hup + 1 == h));
+        const bool leftok = ok && vl == h;
         const int take = MODE == 0 ? (upok ? 0 : (leftok ? 1 : 2)) : (leftok ? 1 : (upok ? 0 : 2));
-        const uint32_t sb = take == 0 ? su + 1u : sd + ((uint32_t)match << 16) + 1u;
-        const int srcl = scan_max_incl(take != 1 ? lane : -1, lane);
+        const bool base = take != 0 || lane == 0;
+        const uint32_t sb = take == 0 ? (uint32_t)(j + 1) : (take == 1 ? sl + 1u : sd + ((uint32_t)match << 16) + 1u);
+        const int srcl = scan_max_incl(base ? lane : -1, lane);
         const uint32_t ss = __shfl(sb, srcl & 63, 64);
-        st = take == 1 ? ss + (uint32_t)(lane - srcl) : sb;
-        H = h;
+        st = base ? sb : ss + (uint32_t)(lane - srcl);
+        H = h; tp = t;
         if (TRACE) {
-            tw |= ((upok ? 1u : 0u) | (leftok ? 2u : 0u)) << (2 * (r & 15));
-            if ((r & 15) == 15 || r == n) { trace[(r >> 4) * 64 + lane] = tw; tw = 0; }
+            const unsigned long long um = __ballot(upok), lm = __ballot(leftok);
+            if (lane == 0) { trace[2 * j] = um; trace[2 * j + 1] = lm; }
         }
     }
-    const int lf = m - c + 31;
     AlnOut o;
-    if (lf < 0 || lf > 63) { o.dist = BIG; o.stat = 0; return o; }
-    o.dist = __shfl(H, lf, 64); o.stat = __shfl(st, lf, 64);
+    const int bf = n - tp;
+    if (bf < 0 || bf > 63) { o.dist = BIG; o.stat = 0; return o; }
+    o.dist = __shfl(H, bf, 64); o.stat = __shfl(st, bf, 64);
     return o;
 }
 
-// joins slots [p0, p0+n) into N; returns the joined length (may exceed ncap: nothing is written
-// past ncap and the caller flags the overflow).
-DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint8_t* N, int ncap, int lane) {
+// joins slots [p0, p0+n) into N, owner[j] = window-relative slot of joined base j; returns the joined length
+// (may exceed ncap: nothing is written past ncap and the caller flags the overflow).
+DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint8_t* N, uint16_t* owner, int ncap, int lane) {
     int base = 0;
     for (int q = 0; q < n; q += 64) {
         const int p = q + lane;
@@ -229,7 +236,7 @@ DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint
         const int incl = scan_add_incl(len, lane);
         const int off = base + incl - len;
         if (off + len <= ncap)
-            for (int x2 = 0; x2 < len; x2++) N[off + x2] = slot_sym(code, x2, orig);
+            for (int x2 = 0; x2 < len; x2++) { N[off + x2] = slot_sym(code, x2, orig); owner[off + x2] = (uint16_t)p; }
         base += __shfl(incl, 63, 64);
     }
     return base;
@@ -254,7 +261,7 @@ DEV int ndigits(unsigned long long v) { int d = 1; while (v >= 10) { v /= 10; d+
 
 // ------------------------------------------------------------------------------------------------
 // S1..S6 main kernel: persistent waves pull reads from a global counter.
-// LDS per wave: frag[lcap] | nb[lcap] (u16) | N[ncap] | popd[ncap]
+// LDS per wave: frag[lcap] | nb[lcap] (u16) | N[ncap] | popd[ncap] | owner[ncap] (u16)
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 
@@ -262,13 +269,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                                                                  QsModelView QM, IdentView IM, SimParams P,
                                                                  SimBuffers O) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per_wave = P.lcap * 3 + P.ncap * 2;
+    const int per_wave = P.lcap * 3 + P.ncap * 4;
     const int wpw = blockDim.x >> 6;
     uint8_t* frag = lds_raw + (size_t)wave * per_wave;
     uint16_t* nb = reinterpret_cast<uint16_t*>(frag + P.lcap);
     uint8_t* N = frag + 3 * (size_t)P.lcap;
     uint8_t* popd = N + P.ncap;
-    uint32_t* trace = O.trace + ((size_t)blockIdx.x * wpw + wave) * (size_t)P.trace_words;
+    uint16_t* owner = reinterpret_cast<uint16_t*>(popd + P.ncap);
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(O.trace) + ((size_t)blockIdx.x * wpw + wave) * (size_t)(P.trace_words / 2);
     const int k = EM.k;
 
     for (;;) {
@@ -427,11 +435,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                                 p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
                                 nrows = 1000;
                             }
-                            const int m = join_window(frag, nb, p0, nrows, N, P.ncap, lane);
+                            const int m = join_window(frag, nb, p0, nrows, N, owner, P.ncap, lane);
                             wave_sync();
                             if (m > P.ncap) status |= 1;
                             else {
-                                const AlnOut a = band_align<0, false>(frag + p0, nb + p0, nrows, N, m, lane, nullptr);
+                                const AlnOut a = band_align<0, false>(frag + p0, nrows, N, owner, m, lane, nullptr);
                                 if (is_inf(a.dist)) status |= 4;
                                 const int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
                                 const double ident = cols ? (double)mt / (double)cols : 0.0;
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                 start_trim = __shfl(scan_add_incl(v1, lane), 63, 64);
                 end_trim = __shfl(scan_add_incl(v2, lane), 63, 64);
             }
-            const int m = join_window(frag, nb, 0, L, N, min(P.ncap, cap), lane);
+            const int m = join_window(frag, nb, 0, L, N, owner, min(P.ncap, cap), lane);
             wave_sync();
             st_newlen = m; st_strim = start_trim; st_etrim = end_trim;
             int lo = start_trim, hi = end_trim == 0 ? 0 : m - end_trim;   // seq[start_trim:-end_trim]
@@ -474,32 +482,37 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
             out_len = hi - lo;
             if (P.compute_q && m > 0 && !(status & 1)) {
                 // ---- S5 q-scores (py/tksm_badread.py:607-655): align read vs fragment with path
-                const AlnOut a = band_align<1, true>(frag, nb, L, N, m, lane, trace);
+                const AlnOut a = band_align<1, true>(frag, L, N, owner, m, lane, trace);
                 if (is_inf(a.dist)) status |= 4;
                 wave_sync();
                 int mt = 0, cols = 0;
                 if (!(status & 4)) {
-                    int rr2 = L, j = m, c = m, grp = -1, dpend = 0;
-                    uint32_t tw = 0;
+                    int rr2 = L, j = m, dpend = 0;
                     while (rr2 > 0 || j > 0) {
-                        if ((rr2 >> 4) != grp) { grp = rr2 >> 4; tw = trace[grp * 64 + lane]; }
-                        const int l = j - c + 31;
-                        const uint32_t tb = ((uint32_t)__shfl((int)tw, l & 63, 64) >> (2 * (rr2 & 15))) & 3u;
-                        // a consistent trace never asks for a move that leaves the matrix; bound the
-                        // walk anyway so that a corrupted trace cannot hang the wave
-                        if (cols > L + m || ((tb & 2u) && j == 0) || (!(tb & 2u) && (tb & 1u) && rr2 == 0) ||
-                            (!(tb & 3u) && (rr2 == 0 || j == 0))) { status |= 4; break; }
+                        int mv;                                  // 0 up, 1 left, 2 diagonal
+                        if (j == 0) mv = 0;
+                        else if (rr2 == 0) mv = 1;
+                        else {
+                            const int t = max(1, (int)owner[j - 1] + 1 - 31);
+                            const int bb = rr2 - t;
+                            if (bb > 63) mv = 0;                 // virtual cell below the window
+                            else {
+                                const unsigned long long um = trace[2 * j], lm = trace[2 * j + 1];
+                                mv = ((lm >> bb) & 1ull) ? 1 : (((um >> bb) & 1ull) ? 0 : 2);
+                            }
+                        }
+                        if (cols > L + m) { status |= 4; break; }   // cannot happen with a consistent trace
                         cols++;
-                        if (tb & 2u) {                          // read-only base: 'I'
+                        if (mv == 1) {                           // read-only base: 'I'
                             if (lane == 0) popd[j - 1] = (uint8_t)(2 | (min(dpend, 63) << 2));
                             dpend = 0; j--;
-                        } else if (tb & 1u) {                   // fragment-only base: 'D'
-                            dpend++; rr2--; c -= slot_len(nb[rr2]);
+                        } else if (mv == 0) {                    // fragment-only base: 'D'
+                            dpend++; rr2--;
                         } else {
                             const bool eq = frag[rr2 - 1] == N[j - 1];
                             mt += eq;
                             if (lane == 0) popd[j - 1] = (uint8_t)((eq ? 0 : 1) | (min(dpend, 63) << 2));
-                            dpend = 0; rr2--; j--; c -= slot_len(nb[rr2]);
+                            dpend = 0; rr2--; j--;
                         }
                     }
                 }
@@ -742,7 +755,7 @@ hipError_t launch_read_lengths(const BatchView& b, const RefView& r, int k, int 
                        cap_add, raw_len, slot_cap, status);
     return hipGetLastError();
 }
-int simulate_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap * 2); }
+int simulate_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap * 4); }
 int simulate_max_wgs(int lds_bytes) {
     int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 8;
     if (per_cu > 8) per_cu = 8;
