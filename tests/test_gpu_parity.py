@@ -128,10 +128,13 @@ def _make_molecules(rs, ref, n, mean_len, literal=True):
     return mols
 
 
+@pytest.mark.parametrize("path", ["fast", "slow"])
 @pytest.mark.parametrize("mean_len,n,compute_q", [(300, 96, True), (1000, 64, True), (1000, 32, False), (2600, 24, True)])
-def test_badread_bit_exact_vs_oracle(oracle_models, po, mean_len, n, compute_q):
+def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n, compute_q, path):
     """whole records of the stochastic path, GPU vs oracle, same (seed, read index).  mean_len 2600 exercises
-    the random 1000-base window re-estimation (py/tksm_badread.py:417-432)."""
+    the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = k_err + bit-parallel
+    k_aln (reads touching N / IUPAC bytes still take the wave-wide kernel), "slow" = wave-wide kernel for all."""
+    monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
     s, ref, rs = _random_genome_seqr()
     s.set_identity(84.0, 99.0, 5.5)
     s.load_error_model(ERR_MODEL)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <string>
 
@@ -87,6 +88,11 @@ struct tksmseq_ctx : ContigLookup {
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
+    // fast Badread pipeline state (see kernels.h FastBuffers)
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow;
+    bool force_slow = false;
+    std::vector<hipEvent_t> evpool;
+    uint32_t last_rounds = 0, last_slow = 0;
     void* user_out = nullptr; uint64_t user_out_cap = 0;
     bool timing = false;
     hipEvent_t ev[6] = {};
@@ -122,6 +128,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return TKSMSEQ_EDEVICE; }
     std::unique_ptr<tksmseq_ctx> c(new tksmseq_ctx());
     c->device = device;
+    if (const char* fs = getenv("TKSMSEQ_FORCE_SLOW")) c->force_slow = fs[0] == '1';
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -137,6 +144,7 @@ void tksmseq_destroy(tksmseq_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->evpool) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -492,13 +500,93 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     O.dstats = p->collect_stats ? ctx->w_dstats.as<double>() : nullptr;
 
     const bool T = ctx->timing;
+    O.read_list = nullptr; O.n_work = n;
+    float ms_err = 0, ms_aln = 0, ms_other = 0;
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
     HIPCHK(ctx, hipMemsetAsync(ctx->w_counter.p, 0, 8, s));
     HIPCHK(ctx, tk::launch_read_lengths(B, R, k, cap_num, cap_den, cap_add, ctx->w_rawlen.as<uint32_t>(), ctx->w_slotcap.as<uint64_t>(),
                                         ctx->w_status.as<uint32_t>(), s));
     HIPCHK(ctx, tk::launch_scan(ctx->w_slotcap.as<uint64_t>(), ctx->w_slotoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
-    HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O, n_wgs, wpw, s));
+    const bool fast = badread && !ctx->force_slow && n > 0;
+    if (!fast) {
+        HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O, n_wgs, wpw, s));
+    } else {
+        // ---- fast pipeline: k_init, then rounds of k_err (wave per read) + k_aln (lane per alignment)
+        tk::FastBuffers FB{};
+        FB.fw = lcap / 64 + 2; FB.nw = ncap / 64 + 2; FB.shw = ncap / 8 + 16;
+        const uint64_t groups = (n + 63) / 64;
+        HIPCHK(ctx, ctx->f_state.ensure(n * sizeof(tk::ReadState) + 64));
+        HIPCHK(ctx, ctx->f_frag.ensure(n * (size_t)lcap + 64));
+        HIPCHK(ctx, ctx->f_nb.ensure(n * (size_t)lcap * 2 + 64));
+        HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
+        HIPCHK(ctx, ctx->f_jmeta.ensure(n * 16 + 64));
+        HIPCHK(ctx, ctx->f_jn.ensure(n * (size_t)FB.nw * 16 + 64));
+        HIPCHK(ctx, ctx->f_jsh.ensure(n * (size_t)FB.shw * 4 + 64));
+        HIPCHK(ctx, ctx->f_jpopd.ensure(n * (size_t)ncap + 64));
+        HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
+        HIPCHK(ctx, ctx->f_trace.ensure(groups * (size_t)(ncap + 1) * 64 * 16 + 64));
+        HIPCHK(ctx, ctx->f_counters.ensure(64));
+        HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
+        FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
+        FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.job_meta = ctx->f_jmeta.as<uint32_t>();
+        FB.job_n = ctx->f_jn.as<unsigned long long>(); FB.job_sh = ctx->f_jsh.as<uint32_t>(); FB.job_popd = ctx->f_jpopd.as<uint8_t>();
+        FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
+        FB.slow_list = ctx->f_slow.as<uint32_t>();
+        int ewpw = tk::WAVES_PER_WG;
+        while (ewpw > 1 && tk::err_lds_bytes(lcap, ncap, ewpw) > 64 * 1024) ewpw >>= 1;
+        size_t evi = 0;
+        auto tick = [&]() -> int {
+            if (!T) return 0;
+            if (evi >= ctx->evpool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return 1; ctx->evpool.push_back(e); }
+            return hipEventRecord(ctx->evpool[evi++], s) == hipSuccess ? 0 : 1;
+        };
+        std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other, 1 err, 2 aln, -1 host gap
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, n * (size_t)lcap * 2, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 16, s));
+        if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+        HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, tk::WAVES_PER_WG, s));
+        if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+        kinds.push_back(0);
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        uint32_t rounds = 0;
+        for (;; rounds++) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 8, s));
+            if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+            kinds.push_back(-1);
+            HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, ewpw, s));
+            if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+            kinds.push_back(1);
+            HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
+            if (cnt[0] == 0) break;
+            if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
+            if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+            kinds.push_back(-1);
+            HIPCHK(ctx, tk::launch_aln(P, FB, cnt[0], s));
+            if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+            kinds.push_back(2);
+        }
+        ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
+        if (cnt[2]) {
+            // reads with non-ACGT bytes (or an alignment outside the band representation): byte-exact wave-wide path
+            O.read_list = ctx->f_slow.as<uint32_t>(); O.n_work = cnt[2];
+            const uint64_t want2 = (cnt[2] + wpw - 1) / wpw;
+            const int n_wgs2 = (int)std::max<uint64_t>(1, std::min<uint64_t>(want2, (uint64_t)n_wgs));
+            if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+            kinds.push_back(-1);
+            HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O, n_wgs2, wpw, s));
+            if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+            kinds.push_back(0);
+        }
+        if (T) {
+            HIPCHK(ctx, hipStreamSynchronize(s));
+            for (size_t i = 0; i + 1 < evi && i < kinds.size(); i++) {
+                float ms = 0; (void)hipEventElapsedTime(&ms, ctx->evpool[i], ctx->evpool[i + 1]);
+                if (kinds[i] == 1) ms_err += ms; else if (kinds[i] == 2) ms_aln += ms; else if (kinds[i] == 0) ms_other += ms;
+            }
+        }
+    }
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     HIPCHK(ctx, tk::launch_scan(ctx->w_reclen.as<uint64_t>(), ctx->w_recoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
     unsigned long long* sums = ctx->w_sums.as<unsigned long long>();
@@ -532,6 +620,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, hipEventSynchronize(ctx->ev[4]));
         for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&res->kernel_ms[i], ctx->ev[i], ctx->ev[i + 1]);
         (void)hipEventElapsedTime(&res->kernel_ms[4], ctx->ev[0], ctx->ev[4]);
+        res->kernel_ms[5] = ms_err; res->kernel_ms[6] = ms_aln; res->kernel_ms[7] = ms_other;
     }
     res->records = records; res->record_offsets = ctx->w_recoff.p; res->records_bytes = total; res->n_reads = n;
     res->bases_in = b->total_raw; res->bases_out = hs[1];

@@ -72,6 +72,37 @@ struct SimBuffers {
     unsigned long long* work_counter;
     int32_t* istats;             // optional [n_reads][16]
     double* dstats;              // optional [n_reads][2]
+    const uint32_t* read_list;   // k_simulate only: optional list of reads to process (slow path), else all
+    uint64_t n_work;             // k_simulate only: number of work items (list length or n_reads)
+};
+
+// per-read state of the fast Badread pipeline between k_err rounds
+struct ReadState {
+    double errors, target, est;
+    int32_t change_count;
+    uint32_t n_base, aln_no;
+    int16_t resume_src, resume_j;   // draw (lane of its round) and slot to resume at; src < 0: none in progress
+    uint8_t stage;                  // 0 error loop, 1 waiting for the q-score alignment, 2 done
+    uint8_t pending, slow, pad;
+    int32_t st_draws, st_aligns;
+    uint32_t job;
+    int32_t pad2;
+};
+
+struct FastBuffers {
+    ReadState* state;                 // [n_reads]
+    uint8_t* st_frag;                 // [n_reads][lcap]
+    uint16_t* st_nb;                  // [n_reads][lcap]
+    unsigned long long* st_fplanes;   // [n_reads][2][fw] 2-bit planes of the padded fragment
+    uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, m}
+    unsigned long long* job_n;        // [n_reads][2][nw] 2-bit planes of the joined window
+    uint32_t* job_sh;                 // [n_reads][shw] 4-bit window shift per column
+    uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
+    uint32_t* aln_res;                // [n_reads][4] {matches, columns, fail, -}
+    void* trace;                      // [n_groups][ncap + 1][64] x 16 B
+    uint32_t* counters;               // [0] jobs this round, [1] reads still running, [2] slow reads
+    uint32_t* slow_list;              // [n_reads]
+    int fw, nw, shw;
 };
 
 hipError_t launch_pack(const uint8_t* ascii, uint64_t n, uint64_t gstart, uint32_t* packed, uint32_t* blockflag,
@@ -83,6 +114,12 @@ hipError_t launch_read_lengths(const BatchView& b, const RefView& r, int k, int 
 hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
                            const IdentView& im, const SimParams& p, const SimBuffers& o, int n_wgs,
                            int waves_per_wg, hipStream_t s);
+hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView& em, const IdentView& im, const SimParams& p,
+                       const SimBuffers& o, const FastBuffers& fb, int waves_per_wg, hipStream_t s);
+int err_lds_bytes(int lcap, int ncap, int waves_per_wg);
+hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
+                      const FastBuffers& fb, int waves_per_wg, hipStream_t s);
+hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, hipStream_t s);
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off,
                        uint8_t* records, hipStream_t s);
 hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank,

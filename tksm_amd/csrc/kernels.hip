@@ -283,8 +283,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
         unsigned long long rr = 0;
         if (lane == 0) rr = atomicAdd(O.work_counter, 1ull);
         rr = __shfl((long long)rr, 0, 64);
-        if (rr >= B.n_reads) break;               // every wave reaches this exit
-        const uint64_t r = rr;
+        if (rr >= O.n_work) break;                // every wave reaches this exit
+        const uint64_t r = O.read_list ? (uint64_t)O.read_list[rr] : rr;
         const uint64_t g = P.first_read + r * P.stride;
         const int raw_len = (int)O.raw_len[r];
         const int L = raw_len + 2 * k;
@@ -590,6 +590,520 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
     }
 }
 
+// ================================================================================================
+// Fast Badread pipeline: k_init -> rounds of { k_err (one wave per read, error loop up to the next
+// identity re-estimation) -> k_aln (bit-parallel banded alignment, one LANE per alignment) }.
+// Reads whose fragment holds a non-ACGT byte (or whose alignment leaves the band representation)
+// are routed to the byte-exact wave-wide path (k_simulate over slow_list).  Same specification,
+// same results, bit for bit.
+// ================================================================================================
+DEV void go_slow(const FastBuffers& FB, uint64_t r, int lane) {
+    if (lane == 0) {
+        FB.state[r].slow = 1;
+        const uint32_t idx = atomicAdd(&FB.counters[2], 1u);
+        FB.slow_list[idx] = (uint32_t)r;
+    }
+}
+
+// ---- k_init: splice (S1), flanks, target identity, 2-bit planes of the fragment, classification
+__global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
+                                               SimBuffers O, FastBuffers FB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6;
+    const uint64_t r = (uint64_t)blockIdx.x * wpw + wave;
+    if (r >= B.n_reads) return;
+    uint8_t* frag = lds_raw + (size_t)wave * P.lcap;
+    const int k = EM.k;
+    const uint64_t g = P.first_read + r * P.stride;
+    const int raw_len = (int)O.raw_len[r];
+    const int L = raw_len + 2 * k;
+    uint32_t status = 0;
+    {
+        const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+        int o = k;
+        for (uint32_t ii = 0; ii < ic; ii++) {
+            const Ivl iv = load_interval(B, R, ib + ii);
+            const int len = (int)iv.len;
+            for (int t = lane; t < len; t += 64) {
+                const uint32_t src = iv.minus ? iv.s + (uint32_t)(len - 1 - t) : iv.s + (uint32_t)t;
+                uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + src]) : ref_base(R, iv.gbase + src);
+                frag[o + t] = iv.minus ? comp(b) : b;
+            }
+            wave_sync();
+            for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++) {
+                const uint32_t mp = B.mods[2ull * mi], mc = B.mods[2ull * mi + 1];
+                if (mp >= (uint32_t)len) { status |= 2; continue; }
+                if (lane == 0) frag[o + (iv.minus ? len - 1 - (int)mp : (int)mp)] = iv.minus ? comp((uint8_t)mc) : (uint8_t)mc;
+            }
+            o += len;
+        }
+    }
+    {
+        const Ph4 pad = philox(P.seed, g, ST_PAD, 0);
+        if (lane < k) {
+            frag[lane] = base_char((int)(pad.x >> (2 * lane)));
+            frag[k + raw_len + lane] = base_char((int)(pad.y >> (2 * lane)));
+        }
+    }
+    double target;
+    if (IM.constant) target = IM.value;
+    else {
+        const uint32_t u = philox(P.seed, g, ST_IDENT, 0).x;
+        const uint32_t idx = u >> 16;
+        const double fr = (double)(u & 0xffffu) * (1.0 / 65536.0);
+        const double qa = IM.qtab[idx], qb = IM.qtab[idx + 1];
+        target = IM.value * (qa + (qb - qa) * fr);
+    }
+    wave_sync();
+    uint8_t* gfrag = FB.st_frag + r * (size_t)P.lcap;
+    unsigned long long* fpl = FB.st_fplanes + r * 2ull * FB.fw;
+    bool dirty = false;
+    for (int q = 0; q < FB.fw; q++) {
+        const int p = q * 64 + lane;
+        const bool valid = p < L;
+        const uint8_t c = valid ? frag[p] : (uint8_t)'A';
+        if (valid) gfrag[p] = c;
+        const int code = code_of(c);
+        dirty |= code < 0;
+        const unsigned long long lo = __ballot(valid && (code & 1)), hi = __ballot(valid && (code & 2));
+        if (lane == 0) { fpl[q] = lo; fpl[FB.fw + q] = hi; }
+    }
+    const bool slow = __ballot(dirty) != 0ull;
+    if (lane == 0) {
+        ReadState S;
+        S.errors = 0.0; S.target = target; S.est = 0.0; S.change_count = 0; S.n_base = 0; S.aln_no = 0;
+        S.resume_src = -1; S.resume_j = 0; S.stage = 0; S.pending = 0; S.slow = slow ? 1 : 0; S.pad = 0;
+        S.st_draws = 0; S.st_aligns = 0; S.job = 0; S.pad2 = 0;
+        FB.state[r] = S;
+        O.status[r] |= status;
+        if (slow) { const uint32_t idx = atomicAdd(&FB.counters[2], 1u); FB.slow_list[idx] = (uint32_t)r; }
+    }
+}
+
+// packs the joined window into an alignment job: 2-bit planes of N, 4-bit window-shift per column
+DEV uint32_t build_job(const FastBuffers& FB, uint64_t r, int mode, int p0, int n, int m, const uint8_t* N,
+                       const uint16_t* owner, int lane) {
+    uint32_t idx = 0;
+    if (lane == 0) idx = atomicAdd(&FB.counters[0], 1u);
+    idx = __shfl(idx, 0, 64);
+    if (lane == 0) {
+        uint32_t* meta = FB.job_meta + 4ull * idx;
+        meta[0] = (uint32_t)r; meta[1] = (uint32_t)p0; meta[2] = (uint32_t)n | ((uint32_t)mode << 31); meta[3] = (uint32_t)m;
+    }
+    unsigned long long* jn = FB.job_n + (size_t)idx * 2 * FB.nw;
+    uint32_t* jsh = FB.job_sh + (size_t)idx * FB.shw;
+    bool fail = false;
+    for (int q = 0; q * 64 < m + 64; q++) {
+        const int c = q * 64 + lane;
+        const bool valid = c < m;
+        const int code = valid ? code_of(N[c]) : 0;
+        const unsigned long long lo = __ballot(valid && (code & 1)), hi = __ballot(valid && (code & 2));
+        if (lane == 0) { jn[q] = lo; jn[FB.nw + q] = hi; }
+        int sh = 0;
+        if (valid) {
+            const int tj = max(1, (int)owner[c] + 1 - 31);
+            const int tprev = c == 0 ? 1 : max(1, (int)owner[c - 1] + 1 - 31);
+            sh = tj - tprev;
+            if (sh > 15) fail = true;
+        }
+        uint32_t v = (uint32_t)(sh & 15) << (4 * (lane & 7));
+        v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); v |= __shfl_xor(v, 4, 64);
+        if ((lane & 7) == 0) jsh[q * 8 + (lane >> 3)] = v;
+    }
+    return idx | (__ballot(fail) ? 0x80000000u : 0u);
+}
+
+// per-read results shared by both stages of k_err (py/sequence.py:252-288 record length)
+DEV void finish_read(const BatchView& B, const SimParams& P, const SimBuffers& O, uint64_t r, int raw_len, int out_len,
+                     double identity, uint32_t status, int st_draws, int st_changes, int st_aligns, int L, int st_newlen,
+                     int st_strim, int st_etrim, double errors, double target, int lane) {
+    if (lane != 0) return;
+    const long long h = pct_hundredths(identity);
+    const uint32_t idl = B.ids[2 * r + 1];
+    uint64_t rec = 1 + 36 + 8 + ndigits((unsigned)out_len) + 19 + ndigits((unsigned)raw_len) + 15 +
+                   ndigits((unsigned long long)(h / 100)) + 3 + 14 + idl + 1;
+    rec += (uint64_t)out_len + 1;
+    if (P.fastq) rec += 2 + (uint64_t)out_len + 1;
+    O.out_len[r] = (uint32_t)out_len;
+    O.identity[r] = identity;
+    O.rec_len[r] = rec;
+    O.status[r] |= status;
+    if (O.istats) {
+        int32_t* s = O.istats + 16 * r;
+        s[0] = st_draws; s[1] = st_changes; s[2] = st_aligns; s[3] = L; s[4] = st_newlen;
+        s[5] = st_strim; s[6] = st_etrim; s[7] = (int32_t)status;
+        O.dstats[2 * r] = errors; O.dstats[2 * r + 1] = target;
+    }
+}
+
+// ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | N[ncap] | aux[2*ncap] (owner u16 / popd)
+__global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
+                                              FastBuffers FB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6;
+    const uint64_t r = (uint64_t)blockIdx.x * wpw + wave;
+    if (r >= B.n_reads) return;
+    ReadState S = FB.state[r];
+    if (S.stage == 2 || S.slow) return;
+    const int per_wave = P.lcap * 3 + P.ncap * 3;
+    uint8_t* frag = lds_raw + (size_t)wave * per_wave;
+    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + P.lcap);
+    uint8_t* N = frag + 3 * (size_t)P.lcap;
+    uint16_t* owner = reinterpret_cast<uint16_t*>(N + P.ncap);
+    uint8_t* popd = reinterpret_cast<uint8_t*>(owner);
+    const int k = EM.k;
+    const uint64_t g = P.first_read + r * P.stride;
+    const int raw_len = (int)O.raw_len[r];
+    const int L = raw_len + 2 * k;
+    const uint64_t slot = O.slot_off[r];
+    const int cap = (int)((O.slot_off[r + 1] - slot) >> 1);
+    uint8_t* out_seq = O.scratch + slot;
+    uint8_t* out_qual = out_seq + cap;
+    uint8_t* gfrag = FB.st_frag + r * (size_t)P.lcap;
+    uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
+    for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag + t);
+    for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
+    wave_sync();
+    uint32_t status = 0;
+    const double frag_len = (double)L;
+    double errors = S.errors;
+    const double target = S.target;
+    int change_count = S.change_count, st_draws = S.st_draws, st_aligns = S.st_aligns;
+    uint32_t n_base = S.n_base, aln_no = S.aln_no;
+    double identity = 1.0;
+
+    if (S.stage == 0) {
+        bool resume = S.resume_src >= 0;
+        if (S.pending) {                                   // apply the re-estimation result (py/tksm_badread.py:412-432)
+            const uint32_t mt = FB.aln_res[4 * r], cols = FB.aln_res[4 * r + 1], fail = FB.aln_res[4 * r + 2];
+            if (fail) { go_slow(FB, r, lane); return; }
+            const double ident = cols ? (double)mt / (double)cols : 0.0;
+            if (L <= 1000) errors = (1.0 - ident) * frag_len;
+            else {
+                const double estimated = (1.0 - ident) * frag_len;
+                const double weight = 1000.0 / frag_len;
+                errors = estimated * weight + errors * (1.0 - weight);
+            }
+            aln_no++;
+        }
+        const int max_kmer_index = L - 1 - k;
+        const long long loop_limit = 100ll * L;
+        bool done = false, need_aln = false;
+        int r_src = 0, r_j = 0; double r_est = 0.0;
+        if (!resume && !S.pending)
+            if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
+        while (!done && !need_aln) {
+            const uint32_t n = n_base + (uint32_t)lane;
+            const bool live = (long long)n + 1 <= loop_limit;
+            const Ph4 d = philox(P.seed, g, ST_DRAW, n);
+            const int i = (int)__umulhi(d.x, (uint32_t)(max_kmer_index + 1));
+            int kind = 0;
+            uint64_t alt = 0;
+            if (live) {
+                int kidx = 0; bool valid = true;
+                for (int jj = 0; jj < k; jj++) { const int cc = code_of(frag[i + jj]); valid &= cc >= 0; kidx = (kidx << 2) | (cc & 3); }
+                if (EM.type == 0 || !valid) kind = 2;
+                else {
+                    const uint32_t* cdf = EM.cdf + (size_t)kidx * EM.max_alts;
+                    const int na = EM.nalts[kidx];
+                    int a = 0;
+                    while (a < na && !(d.y < cdf[a])) a++;
+                    if (a == na) kind = 2;
+                    else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
+                }
+                if (kind == 2) {
+                    const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
+                    const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
+                    const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
+                    alt = type | (pos << 2) | (base4 << 8) | (side << 10) | (r3 << 12);
+                }
+            }
+            unsigned long long mask = __ballot(live && kind != 0);
+            const unsigned long long dead = __ballot(!live);
+            if (resume) mask &= ~((1ull << S.resume_src) - 1ull);
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                const int ai = __shfl(i, src, 64);
+                const int akind = __shfl(kind, src, 64);
+                const uint64_t aalt = ((uint64_t)(uint32_t)__shfl((int)(alt >> 32), src, 64) << 32) |
+                                      (uint32_t)__shfl((int)(uint32_t)alt, src, 64);
+                int jj0 = 0; double est;
+                if (resume) { jj0 = S.resume_j; est = S.est; resume = false; }
+                else est = 1.0 - errors / frag_len;
+                int boff = 0;
+                if (akind == 1) for (int x2 = 0; x2 < jj0; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
+                for (int jj = jj0; jj < k; jj++) {
+                    const int p = ai + jj;
+                    const uint8_t orig = frag[p];
+                    uint32_t enc; int len; bool differs;
+                    if (akind == 1) {
+                        len = (int)((aalt >> (3 * jj)) & 7);
+                        const uint32_t codes = (uint32_t)((aalt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u));
+                        boff += len;
+                        differs = !(len == 1 && base_char((int)codes) == orig);
+                        enc = 0x8000u | ((uint32_t)len << 12) | codes;
+                    } else {
+                        const int type = (int)(aalt & 3), pos = (int)((aalt >> 2) & 15);
+                        const uint32_t base4 = (uint32_t)((aalt >> 8) & 3), side = (uint32_t)((aalt >> 10) & 1);
+                        const int r3 = (int)((aalt >> 12) & 3);
+                        if (jj != pos) continue;
+                        differs = true;
+                        if (type == 0) {
+                            const int cc = code_of(orig);
+                            len = 1; enc = 0x8000u | (1u << 12) | (uint32_t)(cc < 0 ? (int)base4 : ((cc + r3) & 3));
+                        } else if (type == 1) {
+                            len = 2;
+                            enc = side ? (0x8000u | (2u << 12) | (1u << 10) | (base4 << 2))
+                                       : (0x8000u | (2u << 12) | (2u << 10) | base4);
+                        } else { len = 0; enc = 0x8000u; }
+                    }
+                    if (!differs || nb[p] != 0) continue;
+                    if (lane == 0) nb[p] = (uint16_t)enc;
+                    change_count++;
+                    const int new_errors = len < 2 ? 1 : len - 1;
+                    errors += (double)new_errors * (est * sqrt(est));
+                    if (change_count % 25 == 0) { need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
+                }
+                if (need_aln) break;
+                mask &= mask - 1;
+                wave_sync();
+                if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) {
+                    done = true; st_draws = (int)n_base + src + 1; break;
+                }
+            }
+            if (!done && !need_aln) {
+                if (dead) { done = true; st_draws = (int)loop_limit; }
+                else n_base += 64;
+            }
+        }
+        wave_sync();
+        if (need_aln) {
+            st_aligns++;
+            int p0 = 0, nrows = L;
+            if (L > 1000) {
+                const uint32_t w = philox(P.seed, g, ST_ALNPOS, aln_no).x;
+                p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
+                nrows = 1000;
+            }
+            const int m = join_window(frag, nb, p0, nrows, N, owner, P.ncap, lane);
+            wave_sync();
+            if (m > P.ncap) {                              // output slot overflow: the host reruns with larger slots
+                finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
+                if (lane == 0) FB.state[r].stage = 2;
+                return;
+            }
+            const uint32_t job = build_job(FB, r, 0, p0, nrows, m, N, owner, lane);
+            if (job >> 31) { go_slow(FB, r, lane); return; }
+            for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
+            if (lane == 0) {
+                S.errors = errors; S.est = r_est; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
+                S.resume_src = (int16_t)r_src; S.resume_j = (int16_t)r_j; S.pending = 1; S.stage = 0;
+                S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
+                FB.state[r] = S;
+                atomicAdd(&FB.counters[1], 1u);
+            }
+            return;
+        }
+        // the loop has ended: write the final slots back once (the FINAL stage re-joins from them)
+        for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
+    } else {
+        st_draws = S.st_draws;
+    }
+
+    // ---- :434-437 trims and the joined sequence (both stages)
+    int start_trim, end_trim;
+    {
+        int v1 = lane < k ? slot_len(nb[lane]) : 0, v2 = lane < k ? slot_len(nb[L - k + lane]) : 0;
+        start_trim = __shfl(scan_add_incl(v1, lane), 63, 64);
+        end_trim = __shfl(scan_add_incl(v2, lane), 63, 64);
+    }
+    const int jcap = min(P.ncap, cap);
+    const int m = join_window(frag, nb, 0, L, N, owner, jcap, lane);
+    wave_sync();
+    int lo = start_trim, hi = end_trim == 0 ? 0 : m - end_trim;
+    lo = min(lo, m); hi = max(hi, lo);
+    if (m > jcap) { status |= 1; lo = hi = 0; }
+    const int out_len = hi - lo;
+    const bool want_q = P.compute_q && m > 0 && !(status & 1);
+    if (S.stage == 0 && want_q) {
+        const uint32_t job = build_job(FB, r, 1, 0, L, m, N, owner, lane);
+        if (job >> 31) { go_slow(FB, r, lane); return; }
+        if (lane == 0) {
+            S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
+            S.resume_src = -1; S.pending = 1; S.stage = 1; S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
+            FB.state[r] = S;
+            atomicAdd(&FB.counters[1], 1u);
+        }
+        return;
+    }
+    if (want_q) {
+        // ---- S5 q-scores from the alignment k_aln left in job_popd (py/tksm_badread.py:607-655)
+        const uint32_t mt = FB.aln_res[4 * r], cols = FB.aln_res[4 * r + 1], fail = FB.aln_res[4 * r + 2];
+        if (fail) { go_slow(FB, r, lane); return; }
+        identity = cols ? (double)mt / (double)cols : 0.0;
+        const uint8_t* gp = FB.job_popd + (size_t)S.job * P.ncap;
+        wave_sync();
+        for (int t = lane; t < m; t += 64) popd[t] = gp[t];
+        wave_sync();
+        const int margins = (QM.kmer_size - 1) / 2;
+        const uint32_t hmask = (uint32_t)QM.n_slots - 1u;
+        for (int i2 = lo + lane; i2 < hi; i2 += 64) {
+            int s0 = i2 - margins, e0 = i2 + margins;
+            while (s0 < 0 || e0 >= m) { s0++; e0--; }
+            int row = -1;
+            for (;;) {
+                uint64_t key = 0; int len = 0; bool ok = true;
+                for (int x2 = s0; x2 <= e0; x2++) {
+                    if (x2 > s0) {
+                        const int dd = popd[x2 - 1] >> 2;
+                        if (len + dd > 29) { ok = false; break; }
+                        key |= ((1ull << (2 * dd)) - 1ull) << (2 * len); len += dd;
+                    }
+                    if (len >= 29) { ok = false; break; }
+                    key |= (uint64_t)(popd[x2] & 3) << (2 * len); len++;
+                }
+                if (ok) {
+                    key |= (uint64_t)len << 58;
+                    uint32_t s = (uint32_t)qs_hash(key) & hmask;
+                    for (;;) {
+                        const uint64_t kk = QM.keys[s];
+                        if (kk == key) { row = (int)s; break; }
+                        if (kk == 0) break;
+                        s = (s + 1) & hmask;
+                    }
+                }
+                if (row >= 0 || s0 == e0) break;
+                s0++; e0--;
+            }
+            uint8_t q = 0;
+            if (row >= 0) {
+                const uint32_t w = philox(P.seed, g, ST_QUAL, (uint32_t)i2).x;
+                const uint32_t off = QM.row_off[row], cnt = QM.row_cnt[row];
+                uint32_t a = 0;
+                while (a + 1 < cnt && !(w < QM.cdf_pool[off + a])) a++;
+                q = QM.q_pool[off + a];
+            }
+            out_qual[i2 - lo] = (uint8_t)(q + 33);
+        }
+    } else {
+        identity = 1.0 - errors / frag_len;
+    }
+    for (int t = lo + lane; t < hi; t += 64) out_seq[t - lo] = N[t];
+    if (P.quirk_perfect) identity = 1.0;
+    finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
+                start_trim, end_trim, errors, target, lane);
+    if (lane == 0) FB.state[r].stage = 2;
+}
+
+// ---- k_aln: bit-parallel (Myers / Hyyro) banded global alignment, one lane per job.
+// Column j of the joined sequence owns fragment rows t_j .. t_j+63 (bit b = row t_j + b); t advances by the
+// 4-bit shift the job carries.  Entering rows take vertical delta +1 (virtual cells below the previous window),
+// the row above the window is unreachable (horizontal delta in = +1), and when the window does not move the
+// top row can only be reached from the left (vertical delta forced to -1).  Per column the resolved predecessor
+// of every cell is stored as 2 bits {w0, w1}: 0 up, 1 left, 2 diagonal mismatch, 3 diagonal match; the walk
+// back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
+__global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
+    const int lane = threadIdx.x;
+    const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;
+    const bool act = job < n_jobs;
+    uint32_t r = 0; int p0 = 0, n = 0, m = 0, mode = 0;
+    if (act) {
+        const uint32_t* meta = FB.job_meta + 4ull * job;
+        r = meta[0]; p0 = (int)meta[1]; n = (int)(meta[2] & 0x7fffffffu); mode = (int)(meta[2] >> 31); m = (int)meta[3];
+    }
+    const unsigned long long* fl = FB.st_fplanes + (size_t)r * 2 * FB.fw;
+    const unsigned long long* fh = fl + FB.fw;
+    const unsigned long long* nl = FB.job_n + (size_t)job * 2 * FB.nw;
+    const unsigned long long* nh = nl + FB.nw;
+    const uint32_t* jsh = FB.job_sh + (size_t)job * FB.shw;
+    ulonglong2* trace = reinterpret_cast<ulonglong2*>(FB.trace) + (size_t)blockIdx.x * (size_t)(P.ncap + 1) * 64;
+    int mmax = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
+
+    unsigned long long Pv = ~0ull, Mv = 0ull;
+    int t = 1, fwi = -1;
+    unsigned long long flo0 = 0, flo1 = 0, fhi0 = 0, fhi1 = 0, nlo = 0, nhi = 0;
+    uint32_t shw = 0;
+    for (int j = 1; j <= mmax; j++) {
+        if (act && j <= m) {
+            const int c = j - 1;
+            if ((c & 7) == 0) shw = jsh[c >> 3];
+            const int sh = (int)((shw >> (4 * (c & 7))) & 15u);
+            t += sh;
+            if (sh) { Pv = (Pv >> sh) | (~0ull << (64 - sh)); Mv >>= sh; }
+            else if (t > 1) { Pv &= ~1ull; Mv |= 1ull; }
+            const int o = p0 + t - 1, wi = o >> 6, s = o & 63;
+            if (wi != fwi) { fwi = wi; flo0 = fl[wi]; flo1 = fl[wi + 1]; fhi0 = fh[wi]; fhi1 = fh[wi + 1]; }
+            const unsigned long long lo = s ? (flo0 >> s) | (flo1 << (64 - s)) : flo0;
+            const unsigned long long hi = s ? (fhi0 >> s) | (fhi1 << (64 - s)) : fhi0;
+            const int nbv = n - t;
+            const unsigned long long vm = nbv >= 63 ? ~0ull : (nbv < 0 ? 0ull : ((2ull << nbv) - 1ull));
+            if ((c & 63) == 0) { nlo = nl[c >> 6]; nhi = nh[c >> 6]; }
+            const unsigned long long cl = 0ull - ((nlo >> (c & 63)) & 1ull), ch = 0ull - ((nhi >> (c & 63)) & 1ull);
+            const unsigned long long Eq = ~((lo ^ cl) | (hi ^ ch)) & vm;
+            const unsigned long long Xv = Eq | Mv;
+            const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            const unsigned long long Ph = Mv | ~(Xh | Pv);
+            const unsigned long long Mh = Pv & Xh;
+            const unsigned long long D0 = Xh | Mv;
+            const unsigned long long Phs = (Ph << 1) | 1ull, Mhs = Mh << 1;
+            Pv = Mhs | ~(Xv | Phs);
+            Mv = Phs & Xv;
+            unsigned long long upv = Pv;
+            if (t > 1) upv &= ~1ull;
+            const unsigned long long is_up = mode ? (upv & ~Ph) : upv;
+            const unsigned long long is_left = mode ? Ph : (Ph & ~upv);
+            const unsigned long long is_diag = ~(is_up | is_left);
+            ulonglong2 tw;
+            tw.x = is_left | (is_diag & D0); tw.y = is_diag;
+            trace[(size_t)j * 64 + lane] = tw;
+        }
+    }
+    // walk back from (n, m)
+    int i = n, j = m, tt = t, jc = -1;
+    uint32_t mt = 0, cols = 0;
+    int dpend = 0;
+    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0);
+    unsigned long long w0 = 0, w1 = 0;
+    uint8_t* popd = FB.job_popd + (size_t)job * P.ncap;
+    int shc = -1;
+    bool go = act && !fail && (i > 0 || j > 0);
+    while (__ballot(go)) {
+        if (go) {
+            int mv, match = 0;                               // 0 up, 1 left, 2 diagonal
+            if (j == 0) mv = 0;
+            else if (i == 0) mv = 1;
+            else {
+                const int b = i - tt;
+                if (b < 0) { fail = true; mv = 0; }
+                else if (b > 63) mv = 0;
+                else {
+                    if (j != jc) { jc = j; const ulonglong2 tw = trace[(size_t)j * 64 + lane]; w0 = tw.x; w1 = tw.y; }
+                    const int code = (int)((w0 >> b) & 1ull) | ((int)((w1 >> b) & 1ull) << 1);
+                    mv = code == 0 ? 0 : (code == 1 ? 1 : 2);
+                    match = code == 3;
+                }
+            }
+            cols++;
+            if (mv == 0) { i--; dpend++; }
+            else {
+                if (mode) popd[j - 1] = (uint8_t)((mv == 1 ? 2 : (match ? 0 : 1)) | (min(dpend, 63) << 2));
+                dpend = 0;
+                if (mv == 2) { i--; mt += (uint32_t)match; }
+                const int c = j - 1;
+                if ((c >> 3) != shc) { shc = c >> 3; shw = jsh[shc]; }
+                tt -= (int)((shw >> (4 * (c & 7))) & 15u);
+                j--;
+            }
+            go = (i > 0 || j > 0) && !fail;
+            if (cols > (uint32_t)(n + m)) { fail = true; go = false; }   // cannot happen with a consistent trace
+        }
+    }
+    if (act) {
+        uint32_t* res = FB.aln_res + 4ull * r;
+        res[0] = mt; res[1] = cols; res[2] = fail ? 1u : 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // S6 emit: one wave formats one record at its scanned offset
 // ------------------------------------------------------------------------------------------------
@@ -769,6 +1283,30 @@ hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelV
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_simulate), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_simulate, dim3(n_wgs), dim3(64 * wpw), lds, s, b, r, em, qm, im, p, o);
+    return hipGetLastError();
+}
+hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView& em, const IdentView& im, const SimParams& p,
+                       const SimBuffers& o, const FastBuffers& fb, int wpw, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    const int lds = wpw * p.lcap;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_init), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_init, dim3((unsigned)((b.n_reads + wpw - 1) / wpw)), dim3(64 * wpw), lds, s, b, r, em, im, p, o, fb);
+    return hipGetLastError();
+}
+int err_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap * 3); }
+hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
+                      const FastBuffers& fb, int wpw, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    const int lds = err_lds_bytes(p.lcap, p.ncap, wpw);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_err), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_err, dim3((unsigned)((b.n_reads + wpw - 1) / wpw)), dim3(64 * wpw), lds, s, b, em, qm, p, o, fb);
+    return hipGetLastError();
+}
+hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, hipStream_t s) {
+    if (!n_jobs) return hipSuccess;
+    hipLaunchKernelGGL(k_aln, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
     return hipGetLastError();
 }
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records, hipStream_t s) {
