@@ -525,7 +525,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_jsh.ensure(n * (size_t)FB.shw * 4 + 64));
         HIPCHK(ctx, ctx->f_jpopd.ensure(n * (size_t)ncap + 64));
         HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
-        HIPCHK(ctx, ctx->f_trace.ensure(groups * (size_t)(ncap + 1) * 64 * 16 + 64));
+        HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(64));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();

@@ -597,6 +597,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
 // are routed to the byte-exact wave-wide path (k_simulate over slow_list).  Same specification,
 // same results, bit for bit.
 // ================================================================================================
+// first alternative a with w < cdf[a] (cumulative, non-decreasing), or na if none: the row is fetched with
+// independent 16-byte loads instead of a dependent scalar scan
+DEV int cdf_pick(const uint32_t* cdf, int na, int stride, uint32_t w) {
+    int a = 0;
+    if (((stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(cdf) & 7) == 0)) {
+        const int n2 = (na + 1) >> 1;
+        const uint2* c2 = reinterpret_cast<const uint2*>(cdf);
+        uint2 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = q < n2 ? c2[q] : make_uint2(0xffffffffu, 0xffffffffu);
+#pragma unroll
+        for (int q = 0; q < 16; q++) { a += (2 * q < na && !(w < v[q].x)) ? 1 : 0; a += (2 * q + 1 < na && !(w < v[q].y)) ? 1 : 0; }
+        if (na <= 32) return a;
+        a = 32;
+    }
+    while (a < na && !(w < cdf[a])) a++;
+    return a;
+}
+
 DEV void go_slow(const FastBuffers& FB, uint64_t r, int lane) {
     if (lane == 0) {
         FB.state[r].slow = 1;
@@ -804,8 +823,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 else {
                     const uint32_t* cdf = EM.cdf + (size_t)kidx * EM.max_alts;
                     const int na = EM.nalts[kidx];
-                    int a = 0;
-                    while (a < na && !(d.y < cdf[a])) a++;
+                    const int a = cdf_pick(cdf, na, EM.max_alts, d.y);
                     if (a == na) kind = 2;
                     else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
                 }
@@ -828,24 +846,25 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 int jj0 = 0; double est;
                 if (resume) { jj0 = S.resume_j; est = S.est; resume = false; }
                 else est = 1.0 - errors / frag_len;
-                int boff = 0;
-                if (akind == 1) for (int x2 = 0; x2 < jj0; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
-                for (int jj = jj0; jj < k; jj++) {
-                    const int p = ai + jj;
+                // lanes 0..k-1 evaluate the k slots of this draw in parallel (distinct positions); the applied ones
+                // are then accounted for one by one, in slot order, exactly like the reference's inner loop
+                uint32_t enc = 0; int len = 1; bool app = false;
+                if (lane < k && lane >= jj0) {
+                    const int p = ai + lane;
                     const uint8_t orig = frag[p];
-                    uint32_t enc; int len; bool differs;
+                    bool differs;
                     if (akind == 1) {
-                        len = (int)((aalt >> (3 * jj)) & 7);
+                        int boff = 0;
+                        for (int x2 = 0; x2 < lane; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
+                        len = (int)((aalt >> (3 * lane)) & 7);
                         const uint32_t codes = (uint32_t)((aalt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u));
-                        boff += len;
                         differs = !(len == 1 && base_char((int)codes) == orig);
                         enc = 0x8000u | ((uint32_t)len << 12) | codes;
                     } else {
                         const int type = (int)(aalt & 3), pos = (int)((aalt >> 2) & 15);
                         const uint32_t base4 = (uint32_t)((aalt >> 8) & 3), side = (uint32_t)((aalt >> 10) & 1);
                         const int r3 = (int)((aalt >> 12) & 3);
-                        if (jj != pos) continue;
-                        differs = true;
+                        differs = lane == pos;
                         if (type == 0) {
                             const int cc = code_of(orig);
                             len = 1; enc = 0x8000u | (1u << 12) | (uint32_t)(cc < 0 ? (int)base4 : ((cc + r3) & 3));
@@ -855,11 +874,19 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                                        : (0x8000u | (2u << 12) | (2u << 10) | base4);
                         } else { len = 0; enc = 0x8000u; }
                     }
-                    if (!differs || nb[p] != 0) continue;
-                    if (lane == 0) nb[p] = (uint16_t)enc;
+                    app = differs && nb[p] == 0;
+                }
+                unsigned long long amask = __ballot(app);
+                const unsigned long long lens2 = __ballot(app && len >= 2);
+                const double f15 = est * sqrt(est);
+                while (amask) {
+                    const int jj = __builtin_ctzll(amask);
+                    amask &= amask - 1;
+                    if (lane == jj) nb[ai + jj] = (uint16_t)enc;
                     change_count++;
-                    const int new_errors = len < 2 ? 1 : len - 1;
-                    errors += (double)new_errors * (est * sqrt(est));
+                    int new_errors = 1;
+                    if ((lens2 >> jj) & 1ull) new_errors = __shfl(len, jj, 64) - 1;
+                    errors += (double)new_errors * f15;
                     if (change_count % 25 == 0) { need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
                 }
                 if (need_aln) break;
@@ -977,9 +1004,10 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
             if (row >= 0) {
                 const uint32_t w = philox(P.seed, g, ST_QUAL, (uint32_t)i2).x;
                 const uint32_t off = QM.row_off[row], cnt = QM.row_cnt[row];
-                uint32_t a = 0;
-                while (a + 1 < cnt && !(w < QM.cdf_pool[off + a])) a++;
-                q = QM.q_pool[off + a];
+                // first a with w < cdf[a], else the last entry (thresholds are non-decreasing)
+                uint32_t lo2 = 0, hi2 = cnt - 1;
+                while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (w < QM.cdf_pool[off + mid]) hi2 = mid; else lo2 = mid + 1; }
+                q = QM.q_pool[off + lo2];
             }
             out_qual[i2 - lo] = (uint8_t)(q + 33);
         }
@@ -1001,6 +1029,8 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
 // of every cell is stored as 2 bits {w0, w1}: 0 up, 1 left, 2 diagonal mismatch, 3 diagonal match; the walk
 // back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
 __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
+    // per-lane staging of 8 trace columns (16 B each), [column & 7][lane]: only the owning lane touches its slots
+    __shared__ ulonglong2 tr_lds[8 * 64];
     const int lane = threadIdx.x;
     const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;
     const bool act = job < n_jobs;
@@ -1014,7 +1044,9 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     const unsigned long long* nl = FB.job_n + (size_t)job * 2 * FB.nw;
     const unsigned long long* nh = nl + FB.nw;
     const uint32_t* jsh = FB.job_sh + (size_t)job * FB.shw;
-    ulonglong2* trace = reinterpret_cast<ulonglong2*>(FB.trace) + (size_t)blockIdx.x * (size_t)(P.ncap + 1) * 64;
+    // lane-major trace: every job owns ncap + 16 consecutive 16-byte columns (column c = j - 1), written and read
+    // back in whole 128-byte blocks of 8 columns
+    ulonglong2* trace = reinterpret_cast<ulonglong2*>(FB.trace) + (size_t)job * (size_t)(P.ncap + 16);
     int mmax = m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
@@ -1022,11 +1054,9 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1, fwi = -1;
     unsigned long long flo0 = 0, flo1 = 0, fhi0 = 0, fhi1 = 0, nlo = 0, nhi = 0;
-    uint32_t shw = 0;
-    for (int j = 1; j <= mmax; j++) {
-        if (act && j <= m) {
-            const int c = j - 1;
-            if ((c & 7) == 0) shw = jsh[c >> 3];
+    uint32_t shw = (act && m > 0) ? jsh[0] : 0u;
+    for (int c = 0; c < mmax; c++) {
+        if (act && c < m) {
             const int sh = (int)((shw >> (4 * (c & 7))) & 15u);
             t += sh;
             if (sh) { Pv = (Pv >> sh) | (~0ull << (64 - sh)); Mv >>= sh; }
@@ -1055,49 +1085,88 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
             const unsigned long long is_diag = ~(is_up | is_left);
             ulonglong2 tw;
             tw.x = is_left | (is_diag & D0); tw.y = is_diag;
-            trace[(size_t)j * 64 + lane] = tw;
+            tr_lds[(c & 7) * 64 + lane] = tw;
+        }
+        if ((c & 7) == 7 || c == mmax - 1) {
+            // the next block's shift word is requested BEFORE the stores: gfx9 counts stores in vmcnt, in issue
+            // order, so a load issued after them could only be waited for together with them
+            const uint32_t shn = (act && c + 1 < m) ? jsh[(c + 1) >> 3] : 0u;
+            const int c0 = c & ~7;
+            if (act && c0 < m) {
+#pragma unroll
+                for (int x = 0; x < 8; x++) trace[c0 + x] = tr_lds[x * 64 + lane];
+            }
+            shw = shn;
         }
     }
-    // walk back from (n, m)
-    int i = n, j = m, tt = t, jc = -1;
+    // ---- walk back from (n, m), block by block (uniform block index; every lane walks its own job)
+    int i = n, j = m, tt = t;
     uint32_t mt = 0, cols = 0;
     int dpend = 0;
     bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0);
-    unsigned long long w0 = 0, w1 = 0;
-    uint8_t* popd = FB.job_popd + (size_t)job * P.ncap;
-    int shc = -1;
-    bool go = act && !fail && (i > 0 || j > 0);
-    while (__ballot(go)) {
-        if (go) {
-            int mv, match = 0;                               // 0 up, 1 left, 2 diagonal
-            if (j == 0) mv = 0;
-            else if (i == 0) mv = 1;
-            else {
-                const int b = i - tt;
-                if (b < 0) { fail = true; mv = 0; }
-                else if (b > 63) mv = 0;
-                else {
-                    if (j != jc) { jc = j; const ulonglong2 tw = trace[(size_t)j * 64 + lane]; w0 = tw.x; w1 = tw.y; }
-                    const int code = (int)((w0 >> b) & 1ull) | ((int)((w1 >> b) & 1ull) << 1);
-                    mv = code == 0 ? 0 : (code == 1 ? 1 : 2);
-                    match = code == 3;
-                }
-            }
-            cols++;
-            if (mv == 0) { i--; dpend++; }
-            else {
-                if (mode) popd[j - 1] = (uint8_t)((mv == 1 ? 2 : (match ? 0 : 1)) | (min(dpend, 63) << 2));
-                dpend = 0;
-                if (mv == 2) { i--; mt += (uint32_t)match; }
+    unsigned long long* popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + (size_t)job * P.ncap);
+    const int topblk = (mmax - 1) >> 3;
+    ulonglong2 pre[8];
+    uint32_t pre_sh = 0, cur_sh = 0;
+    if (mmax > 0) {
+        const bool have = act && topblk * 8 < m;
+#pragma unroll
+        for (int x = 0; x < 8; x++) { pre[x].x = 0; pre[x].y = 0; if (have) pre[x] = trace[topblk * 8 + x]; }
+        pre_sh = have ? jsh[topblk] : 0u;
+#pragma unroll
+        for (int x = 0; x < 8; x++) tr_lds[x * 64 + lane] = pre[x];
+        cur_sh = pre_sh;
+    }
+    for (int blk = topblk; blk >= 0 && mmax > 0; blk--) {
+        if (blk > 0) {                                       // prefetch the next (lower) block into registers
+            const bool have = act && (blk - 1) * 8 < m;
+#pragma unroll
+            for (int x = 0; x < 8; x++) if (have) pre[x] = trace[(blk - 1) * 8 + x];
+            pre_sh = have ? jsh[blk - 1] : 0u;
+        }
+        unsigned long long pp = 0ull;
+        bool touched = false;
+        bool go = act && !fail && j > 0 && ((j - 1) >> 3) == blk;
+        while (__ballot(go)) {
+            if (go) {
                 const int c = j - 1;
-                if ((c >> 3) != shc) { shc = c >> 3; shw = jsh[shc]; }
-                tt -= (int)((shw >> (4 * (c & 7))) & 15u);
-                j--;
+                int mv, match = 0;                           // 0 up, 1 left, 2 diagonal
+                if (i == 0) mv = 1;
+                else {
+                    const int b = i - tt;
+                    if (b < 0) { fail = true; mv = 0; }
+                    else if (b > 63) mv = 0;                 // virtual cell below the window
+                    else {
+                        const ulonglong2 tw = tr_lds[(c & 7) * 64 + lane];
+                        const int code = (int)((tw.x >> b) & 1ull) | ((int)((tw.y >> b) & 1ull) << 1);
+                        mv = code == 0 ? 0 : (code == 1 ? 1 : 2);
+                        match = code == 3;
+                    }
+                }
+                cols++;
+                if (mv == 0) { i--; dpend++; }
+                else {
+                    if (mode) {
+                        pp |= (unsigned long long)((mv == 1 ? 2 : (match ? 0 : 1)) | (min(dpend, 63) << 2)) << (8 * (c & 7));
+                        touched = true;
+                    }
+                    dpend = 0;
+                    if (mv == 2) { i--; mt += (uint32_t)match; }
+                    tt -= (int)((cur_sh >> (4 * (c & 7))) & 15u);
+                    j--;
+                }
+                if (cols > (uint32_t)(n + m)) fail = true;   // cannot happen with a consistent trace
+                go = !fail && j > 0 && ((j - 1) >> 3) == blk;
             }
-            go = (i > 0 || j > 0) && !fail;
-            if (cols > (uint32_t)(n + m)) { fail = true; go = false; }   // cannot happen with a consistent trace
+        }
+        if (touched) popd8[blk] = pp;
+        if (blk > 0) {
+#pragma unroll
+            for (int x = 0; x < 8; x++) tr_lds[x * 64 + lane] = pre[x];
+            cur_sh = pre_sh;
         }
     }
+    if (act && !fail && i > 0) { cols += (uint32_t)i; i = 0; }   // column 0: only fragment-only moves remain
     if (act) {
         uint32_t* res = FB.aln_res + 4ull * r;
         res[0] = mt; res[1] = cols; res[2] = fail ? 1u : 0u;
