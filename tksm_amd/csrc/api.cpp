@@ -58,6 +58,8 @@ struct tksmseq_batch {
     uint64_t n_reads = 0, n_intervals = 0, n_mods = 0, n_literals = 0;
     DevBuf reads, intervals, mods, literals, litpool, ids, idpool;
     std::vector<uint32_t> raw_len;       // host copy, for sizing
+    std::vector<uint32_t> order;         // reads sorted by raw length (bucketed k_err launches)
+    DevBuf d_order;
     uint32_t max_raw = 0;
     uint64_t total_raw = 0;
     // cached scratch sizing, keyed by (k, cap_num, cap_den, cap_add)
@@ -83,14 +85,16 @@ struct tksmseq_ctx : ContigLookup {
 
     // models
     ErrorModelHost em; QScoreModelHost qm; IdentityHost idm;
+    bool em_uniform = false;
     DevBuf d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab;
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow, f_jobcnt;
     bool force_slow = false;
+    uint32_t tail_cut = 4096;
     std::vector<hipEvent_t> evpool;
     uint32_t last_rounds = 0, last_slow = 0;
     void* user_out = nullptr; uint64_t user_out_cap = 0;
@@ -129,6 +133,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     std::unique_ptr<tksmseq_ctx> c(new tksmseq_ctx());
     c->device = device;
     if (const char* fs = getenv("TKSMSEQ_FORCE_SLOW")) c->force_slow = fs[0] == '1';
+    if (const char* tc = getenv("TKSMSEQ_TAIL_CUT")) c->tail_cut = (uint32_t)atoi(tc);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -254,6 +259,8 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
     ErrorModelHost m;
     if (!load_error_model(name_or_path, m, ctx->err)) return TKSMSEQ_EIO;
     ctx->em = std::move(m);
+    ctx->em_uniform = ctx->em.type == 1;
+    for (uint8_t v : ctx->em.nalts) if ((int)v != ctx->em.max_alts) { ctx->em_uniform = false; break; }
     int rc;
     if ((rc = upload(ctx, ctx->d_cdf, ctx->em.cdf))) return rc;
     if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
@@ -370,6 +377,9 @@ static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmse
         b->total_raw += t;
         if ((uint64_t)d->ids[2 * r] + d->ids[2 * r + 1] > d->id_bytes) { ctx->err = "molecule id outside the id pool"; return TKSMSEQ_EINVAL; }
     }
+    b->order.resize(d->n_reads);
+    for (uint64_t r = 0; r < d->n_reads; r++) b->order[r] = (uint32_t)r;
+    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) { return b->raw_len[x] < b->raw_len[y]; });
     auto up = [&](DevBuf& buf, const void* src, size_t bytes) -> int {
         HIPCHK(ctx, buf.ensure(bytes + 64));
         if (bytes) HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -386,6 +396,7 @@ static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmse
     if ((rc = up(b->litpool, d->literal_pool, d->literal_bytes))) return rc;
     if ((rc = up(b->ids, d->ids, d->n_reads * 8))) return rc;
     if ((rc = up(b->idpool, d->id_pool, d->id_bytes))) return rc;
+    if ((rc = up(b->d_order, b->order.data(), b->order.size() * 4))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out = b.release();
     return TKSMSEQ_OK;
@@ -481,7 +492,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), n, (uint32_t)b->n_literals};
     tk::RefView R{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
                   ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>()};
     tk::IdentView IM{ctx->idm.constant ? 1 : 0, ctx->idm.value, ctx->d_qtab.as<double>()};
@@ -514,27 +525,53 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     } else {
         // ---- fast pipeline: k_init, then rounds of k_err (wave per read) + k_aln (lane per alignment)
         tk::FastBuffers FB{};
-        FB.fw = lcap / 64 + 2; FB.nw = ncap / 64 + 2; FB.shw = ncap / 8 + 16;
-        const uint64_t groups = (n + 63) / 64;
+        FB.fw = lcap / 64 + 5; FB.nw = ncap / 64 + 2; FB.shw = ncap / 8 + 16;
+        // job-id ranges: ~256 ranges of rs (multiple of 64) consecutive reads of the sorted order
+        FB.rs = (uint32_t)((((n + 255) / 256) + 63) & ~63ull);
+        FB.n_ranges = (uint32_t)((n + FB.rs - 1) / FB.rs);
+        const uint64_t jcap = (uint64_t)FB.n_ranges * FB.rs;     // job slots (>= n)
+        const uint64_t groups = jcap / 64;
         HIPCHK(ctx, ctx->f_state.ensure(n * sizeof(tk::ReadState) + 64));
         HIPCHK(ctx, ctx->f_frag.ensure(n * (size_t)lcap + 64));
         HIPCHK(ctx, ctx->f_nb.ensure(n * (size_t)lcap * 2 + 64));
         HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
-        HIPCHK(ctx, ctx->f_jmeta.ensure(n * 16 + 64));
-        HIPCHK(ctx, ctx->f_jn.ensure(n * (size_t)FB.nw * 16 + 64));
-        HIPCHK(ctx, ctx->f_jsh.ensure(n * (size_t)FB.shw * 4 + 64));
-        HIPCHK(ctx, ctx->f_jpopd.ensure(n * (size_t)ncap + 64));
+        HIPCHK(ctx, ctx->f_jmeta.ensure(jcap * 16 + 64));
+        HIPCHK(ctx, ctx->f_jn.ensure(jcap * (size_t)FB.nw * 16 + 64));
+        HIPCHK(ctx, ctx->f_jsh.ensure(jcap * (size_t)FB.shw * 4 + 64));
+        HIPCHK(ctx, ctx->f_jpopd.ensure(jcap * (size_t)ncap + 64));
         HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
         HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(64));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
+        HIPCHK(ctx, ctx->f_jobcnt.ensure((size_t)FB.n_ranges * 128 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.job_meta = ctx->f_jmeta.as<uint32_t>();
         FB.job_n = ctx->f_jn.as<unsigned long long>(); FB.job_sh = ctx->f_jsh.as<uint32_t>(); FB.job_popd = ctx->f_jpopd.as<uint8_t>();
         FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
-        int ewpw = tk::WAVES_PER_WG;
-        while (ewpw > 1 && tk::err_lds_bytes(lcap, ncap, ewpw) > 64 * 1024) ewpw >>= 1;
+        FB.job_cnt = ctx->f_jobcnt.as<uint32_t>();
+        std::vector<uint32_t> hcnt((size_t)FB.n_ranges * 32);
+        // length buckets over the sorted read order: each bucket gets its own LDS geometry
+        struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; };
+        std::vector<Bucket> buckets;
+        {
+            const uint32_t minr = b->raw_len[b->order.front()], maxr = b->raw_len[b->order.back()];
+            const uint32_t step = std::max<uint32_t>(128, ((maxr - minr) / 16 + 63) & ~63u);
+            uint64_t i0 = 0;
+            while (i0 < n) {
+                const uint32_t lim = (b->raw_len[b->order[i0]] / step + 1) * step;
+                uint64_t i1 = i0;
+                while (i1 < n && b->raw_len[b->order[i1]] < lim) i1++;
+                const uint32_t mx = b->raw_len[b->order[i1 - 1]];
+                Bucket bk;
+                bk.begin = (uint32_t)i0; bk.count = (uint32_t)(i1 - i0);
+                bk.lcap = (int)((mx + 2 * k + 3) & ~3u); bk.ncap = (int)capf(mx);
+                bk.wpw = tk::WAVES_PER_WG;
+                while (bk.wpw > 1 && tk::err_lds_bytes(bk.lcap, bk.ncap, bk.wpw) > 64 * 1024) bk.wpw >>= 1;
+                buckets.push_back(bk);
+                i0 = i1;
+            }
+        }
         size_t evi = 0;
         auto tick = [&]() -> int {
             if (!T) return 0;
@@ -551,19 +588,31 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         uint32_t cnt[4] = {0, 0, 0, 0};
         uint32_t rounds = 0;
         for (;; rounds++) {
-            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 8, s));
+            HIPCHK(ctx, hipMemsetAsync(ctx->f_jobcnt.p, 0, (size_t)FB.n_ranges * 128, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, ewpw, s));
+            for (const Bucket& bk : buckets)
+                HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, bk.wpw, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(1);
             HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), ctx->f_jobcnt.p, (size_t)FB.n_ranges * 128, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
+            cnt[0] = 0;
+            for (uint32_t c = 0; c < FB.n_ranges; c++) cnt[0] += hcnt[(size_t)c * 32];
             if (cnt[0] == 0) break;
+            if (cnt[0] < ctx->tail_cut && cnt[0] * 64ull < n) {
+                // tail: every further round costs a full alignment latency for a handful of reads; finish the
+                // stragglers in one launch of the wave-wide kernel instead (same results: it recomputes them)
+                HIPCHK(ctx, tk::launch_collect_unfinished(FB, n, s));
+                HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
+                HIPCHK(ctx, hipStreamSynchronize(s));
+                break;
+            }
             if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            HIPCHK(ctx, tk::launch_aln(P, FB, cnt[0], s));
+            HIPCHK(ctx, tk::launch_aln(P, FB, (uint32_t)jcap, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
         }

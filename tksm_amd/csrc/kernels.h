@@ -31,6 +31,7 @@ struct BatchView {
 
 struct ErrModelView {
     int type, k, max_alts;
+    int uniform_nalts;     // every k-mer row has exactly max_alts alternatives: nalts need not be read
     const uint32_t* cdf;
     const uint64_t* alts;
     const uint8_t* nalts;
@@ -100,7 +101,9 @@ struct FastBuffers {
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
     uint32_t* aln_res;                // [n_reads][4] {matches, columns, fail, -}
     void* trace;                      // [n_groups][ncap + 1][64] x 16 B
-    uint32_t* counters;               // [0] jobs this round, [1] reads still running, [2] slow reads
+    uint32_t* counters;               // [2] slow reads
+    uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
+    uint32_t rs, n_ranges;
     uint32_t* slow_list;              // [n_reads]
     int fw, nw, shw;
 };
@@ -118,7 +121,9 @@ hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView&
                        const SimBuffers& o, const FastBuffers& fb, int waves_per_wg, hipStream_t s);
 int err_lds_bytes(int lcap, int ncap, int waves_per_wg);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
-                      const FastBuffers& fb, int waves_per_wg, hipStream_t s);
+                      const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
+                      int waves_per_wg, hipStream_t s);
+hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, hipStream_t s);
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off,
                        uint8_t* records, hipStream_t s);

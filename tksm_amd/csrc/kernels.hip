@@ -63,6 +63,16 @@ DEV int scan_add_incl(int x, int lane) {
     for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
     return x;
 }
+// exclusive prefix sum over the wave of a small value (0..7) from three ballots: no cross-lane shuffles
+DEV int prefix_small(int v, int& total) {
+    const unsigned long long b0 = __ballot(v & 1), b1 = __ballot(v & 2), b2 = __ballot(v & 4);
+    const int e0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
+    const int e1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+    const int e2 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+    total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    return e0 + 2 * e1 + 4 * e2;
+}
+
 DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -233,11 +243,11 @@ DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint
         const int p = q + lane;
         uint32_t code = 0; int len = 0; uint8_t orig = 0;
         if (p < n) { code = nb[p0 + p]; len = slot_len(code); orig = frag[p0 + p]; }
-        const int incl = scan_add_incl(len, lane);
-        const int off = base + incl - len;
+        int total;
+        const int off = base + prefix_small(len, total);
         if (off + len <= ncap)
             for (int x2 = 0; x2 < len; x2++) { N[off + x2] = slot_sym(code, x2, orig); owner[off + x2] = (uint16_t)p; }
-        base += __shfl(incl, 63, 64);
+        base += total;
     }
     return base;
 }
@@ -699,10 +709,12 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
 }
 
 // packs the joined window into an alignment job: 2-bit planes of N, 4-bit window-shift per column
-DEV uint32_t build_job(const FastBuffers& FB, uint64_t r, int mode, int p0, int n, int m, const uint8_t* N,
+DEV uint32_t build_job(const FastBuffers& FB, uint64_t r, uint32_t pos, int mode, int p0, int n, int m, const uint8_t* N,
                        const uint16_t* owner, int lane) {
+    // job ids are handed out by one counter per contiguous range of `rs` reads of the sorted order (one hot word
+    // for the whole chip would cap the kernel at ~88 allocations per microsecond); range c owns ids [c*rs, (c+1)*rs)
     uint32_t idx = 0;
-    if (lane == 0) idx = atomicAdd(&FB.counters[0], 1u);
+    if (lane == 0) { const uint32_t c = pos / FB.rs; idx = c * FB.rs + atomicAdd(&FB.job_cnt[c * 32u], 1u); }
     idx = __shfl(idx, 0, 64);
     if (lane == 0) {
         uint32_t* meta = FB.job_meta + 4ull * idx;
@@ -754,19 +766,79 @@ DEV void finish_read(const BatchView& B, const SimParams& P, const SimBuffers& O
     }
 }
 
+// one slot of one draw: new length / encoding and whether it is applied (differs from the original base and the
+// position is still pristine), py/tksm_badread.py:378-390
+DEV bool eval_slot(const uint8_t* frag, const uint16_t* nb, int ai, int jj, int akind, uint64_t aalt, int& len, uint32_t& enc) {
+    const int p = ai + jj;
+    const uint8_t orig = frag[p];
+    bool differs;
+    if (akind == 1) {
+        int boff = 0;
+        for (int x2 = 0; x2 < jj; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
+        len = (int)((aalt >> (3 * jj)) & 7);
+        const uint32_t codes = (uint32_t)((aalt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u));
+        differs = !(len == 1 && base_char((int)codes) == orig);
+        enc = 0x8000u | ((uint32_t)len << 12) | codes;
+    } else {
+        const int type = (int)(aalt & 3), pos = (int)((aalt >> 2) & 15);
+        const uint32_t base4 = (uint32_t)((aalt >> 8) & 3), side = (uint32_t)((aalt >> 10) & 1);
+        const int r3 = (int)((aalt >> 12) & 3);
+        differs = jj == pos;
+        if (type == 0) {
+            const int cc = code_of(orig);
+            len = 1; enc = 0x8000u | (1u << 12) | (uint32_t)(cc < 0 ? (int)base4 : ((cc + r3) & 3));
+        } else if (type == 1) {
+            len = 2;
+            enc = side ? (0x8000u | (2u << 12) | (1u << 10) | (base4 << 2)) : (0x8000u | (2u << 12) | (2u << 10) | base4);
+        } else { len = 0; enc = 0x8000u; }
+    }
+    return differs && nb[p] == 0;
+}
+
+// all k slots of a lane's own draw: am = applied mask, lens = 3 bits per slot, e = 16-bit encodings
+struct SlotEval { uint32_t am, lens; uint32_t e[4]; };
+DEV SlotEval eval_draw(const uint8_t* frag, const uint16_t* nb, int k, int i, int kind, uint64_t alt, bool acc) {
+    SlotEval r;
+    r.am = 0; r.lens = 0; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0;
+    if (acc) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            if (jj < k) {
+                int len = 1; uint32_t enc = 0;
+                const bool app = eval_slot(frag, nb, i, jj, kind, alt, len, enc);
+                if (app) r.am |= 1u << jj;
+                r.lens |= (uint32_t)len << (3 * jj);
+                r.e[jj >> 1] |= (enc & 0xffffu) << (16 * (jj & 1));
+            }
+        }
+    }
+    return r;
+}
+
+#ifdef TKSM_PROF
+#define PROF_T(x) unsigned long long x = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(slot, t0, t1) do { if (lane == 0) atomicAdd(&FB.prof[slot], (t1) - (t0)); } while (0)
+#else
+#define PROF_T(x)
+#define PROF_ADD(slot, t0, t1)
+#endif
 // ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | N[ncap] | aux[2*ncap] (owner u16 / popd)
 __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
-                                              FastBuffers FB) {
+                                              FastBuffers FB, const uint32_t* __restrict__ order, uint32_t begin, uint32_t count,
+                                              int lds_lcap, int lds_ncap) {
+    // one launch per length bucket: reads order[begin .. begin+count) share the LDS geometry (lds_lcap, lds_ncap),
+    // so a batch with a few long molecules does not cost everyone its occupancy
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6;
-    const uint64_t r = (uint64_t)blockIdx.x * wpw + wave;
-    if (r >= B.n_reads) return;
+    const uint32_t widx = blockIdx.x * (uint32_t)wpw + (uint32_t)wave;
+    if (widx >= count) return;
+    const uint64_t r = order[begin + widx];
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
-    const int per_wave = P.lcap * 3 + P.ncap * 3;
+    const int per_wave = lds_lcap * 3 + lds_ncap * 3;
     uint8_t* frag = lds_raw + (size_t)wave * per_wave;
-    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + P.lcap);
-    uint8_t* N = frag + 3 * (size_t)P.lcap;
-    uint16_t* owner = reinterpret_cast<uint16_t*>(N + P.ncap);
+    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + lds_lcap);
+    uint8_t* N = frag + 3 * (size_t)lds_lcap;
+    uint16_t* owner = reinterpret_cast<uint16_t*>(N + lds_ncap);
     uint8_t* popd = reinterpret_cast<uint8_t*>(owner);
     const int k = EM.k;
     const uint64_t g = P.first_read + r * P.stride;
@@ -822,7 +894,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 if (EM.type == 0 || !valid) kind = 2;
                 else {
                     const uint32_t* cdf = EM.cdf + (size_t)kidx * EM.max_alts;
-                    const int na = EM.nalts[kidx];
+                    const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
                     const int a = cdf_pick(cdf, na, EM.max_alts, d.y);
                     if (a == na) kind = 2;
                     else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
@@ -837,65 +909,94 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
             unsigned long long mask = __ballot(live && kind != 0);
             const unsigned long long dead = __ballot(!live);
             if (resume) mask &= ~((1ull << S.resume_src) - 1ull);
+            // ---- every accepted draw is evaluated by its own lane against the slots as they are now ...
+            wave_sync();
+            const bool acc = (mask >> lane) & 1ull;
+            SlotEval ev = eval_draw(frag, nb, k, i, kind, alt, acc);
+            // ... which is exact unless an earlier accepted draw of this round touches an overlapping window (rare);
+            // those, and the draw being resumed, are re-evaluated at their turn
+            unsigned long long depm = 0ull;
+            {
+                bool dep = false;
+                unsigned long long mm = mask;
+                while (mm) {
+                    const int s2 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mm));
+                    mm &= mm - 1;
+                    const int i2 = __builtin_amdgcn_readlane(i, s2);
+                    dep |= lane > s2 && abs(i - i2) < k;
+                }
+                depm = __ballot(acc && dep);
+                if (resume) depm |= 1ull << S.resume_src;
+            }
+            double est_cur = 1.0 - errors / frag_len;
             while (mask) {
-                const int src = __builtin_ctzll(mask);
-                const int ai = __shfl(i, src, 64);
-                const int akind = __shfl(kind, src, 64);
-                const uint64_t aalt = ((uint64_t)(uint32_t)__shfl((int)(alt >> 32), src, 64) << 32) |
-                                      (uint32_t)__shfl((int)(uint32_t)alt, src, 64);
-                int jj0 = 0; double est;
-                if (resume) { jj0 = S.resume_j; est = S.est; resume = false; }
-                else est = 1.0 - errors / frag_len;
-                // lanes 0..k-1 evaluate the k slots of this draw in parallel (distinct positions); the applied ones
-                // are then accounted for one by one, in slot order, exactly like the reference's inner loop
-                uint32_t enc = 0; int len = 1; bool app = false;
-                if (lane < k && lane >= jj0) {
-                    const int p = ai + lane;
-                    const uint8_t orig = frag[p];
-                    bool differs;
-                    if (akind == 1) {
-                        int boff = 0;
-                        for (int x2 = 0; x2 < lane; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
-                        len = (int)((aalt >> (3 * lane)) & 7);
-                        const uint32_t codes = (uint32_t)((aalt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u));
-                        differs = !(len == 1 && base_char((int)codes) == orig);
-                        enc = 0x8000u | ((uint32_t)len << 12) | codes;
-                    } else {
-                        const int type = (int)(aalt & 3), pos = (int)((aalt >> 2) & 15);
-                        const uint32_t base4 = (uint32_t)((aalt >> 8) & 3), side = (uint32_t)((aalt >> 10) & 1);
-                        const int r3 = (int)((aalt >> 12) & 3);
-                        differs = lane == pos;
-                        if (type == 0) {
-                            const int cc = code_of(orig);
-                            len = 1; enc = 0x8000u | (1u << 12) | (uint32_t)(cc < 0 ? (int)base4 : ((cc + r3) & 3));
-                        } else if (type == 1) {
-                            len = 2;
-                            enc = side ? (0x8000u | (2u << 12) | (1u << 10) | (base4 << 2))
-                                       : (0x8000u | (2u << 12) | (2u << 10) | base4);
-                        } else { len = 0; enc = 0x8000u; }
+                const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+                uint32_t am_s, lens_s;
+                double est = est_cur;
+                int jj0 = 0;
+                const bool isdep = (depm >> src) & 1ull;
+                if (isdep) {
+                    // sequential evaluation of this one draw: lanes 0..k-1 take its k slots
+                    wave_sync();
+                    const int ai = __builtin_amdgcn_readlane(i, src);
+                    const int akind = __builtin_amdgcn_readlane(kind, src);
+                    const uint64_t aalt = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(alt >> 32), src) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)alt, src);
+                    if (resume) { jj0 = S.resume_j; est = S.est; resume = false; }
+                    uint32_t enc = 0; int len = 1; bool app = false;
+                    if (lane < k && lane >= jj0) app = eval_slot(frag, nb, ai, lane, akind, aalt, len, enc);
+                    am_s = (uint32_t)__ballot(app);
+                    // lengths of the applied slots, 3 bits each
+                    uint32_t lv = app ? (uint32_t)len << (3 * lane) : 0u;
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) lv |= __shfl_xor(lv, o, 64);
+                    lens_s = __builtin_amdgcn_readfirstlane(lv);
+                    // hand the encodings to lane src so that the common write path below applies
+                    const uint32_t myenc = enc;
+                    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                    {
+                        const uint32_t a0 = __builtin_amdgcn_readlane(myenc, 0), a1 = __builtin_amdgcn_readlane(myenc, 1);
+                        const uint32_t a2 = __builtin_amdgcn_readlane(myenc, 2), a3 = __builtin_amdgcn_readlane(myenc, 3);
+                        const uint32_t a4 = __builtin_amdgcn_readlane(myenc, 4), a5 = __builtin_amdgcn_readlane(myenc, 5);
+                        const uint32_t a6 = __builtin_amdgcn_readlane(myenc, 6), a7 = __builtin_amdgcn_readlane(myenc, 7);
+                        e0 = a0 | (a1 << 16); e1 = a2 | (a3 << 16); e2 = a4 | (a5 << 16); e3 = a6 | (a7 << 16);
                     }
-                    app = differs && nb[p] == 0;
+                    if (lane == src) { ev.e[0] = e0; ev.e[1] = e1; ev.e[2] = e2; ev.e[3] = e3; }
+                } else {
+                    am_s = __builtin_amdgcn_readlane(ev.am, src);
+                    lens_s = __builtin_amdgcn_readlane(ev.lens, src);
                 }
-                unsigned long long amask = __ballot(app);
-                const unsigned long long lens2 = __ballot(app && len >= 2);
-                const double f15 = est * sqrt(est);
-                while (amask) {
-                    const int jj = __builtin_ctzll(amask);
-                    amask &= amask - 1;
-                    if (lane == jj) nb[ai + jj] = (uint16_t)enc;
-                    change_count++;
-                    int new_errors = 1;
-                    if ((lens2 >> jj) & 1ull) new_errors = __shfl(len, jj, 64) - 1;
-                    errors += (double)new_errors * f15;
-                    if (change_count % 25 == 0) { need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
+                if (am_s) {
+                    const double f15 = est * sqrt(est);
+                    uint32_t rem = am_s;
+                    int last = -1;
+                    while (rem) {
+                        const int jj = __builtin_ctz(rem);
+                        rem &= rem - 1;
+                        last = jj;
+                        change_count++;
+                        const int len_j = (int)((lens_s >> (3 * jj)) & 7u);
+                        const int new_errors = len_j < 2 ? 1 : len_j - 1;
+                        errors += (double)new_errors * f15;
+                        if (change_count % 25 == 0) { need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
+                    }
+                    if (lane == src) {
+                        const uint32_t wm = am_s & ((2u << last) - 1u);
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++)
+                            if ((wm >> jj) & 1u) nb[i + jj] = (uint16_t)((ev.e[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
+                    }
+                    if (need_aln) break;
+                    est_cur = 1.0 - errors / frag_len;
                 }
-                if (need_aln) break;
-                mask &= mask - 1;
-                wave_sync();
-                if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) {
+                // stop rules at the top of the next iteration (also after a resumed draw that applied nothing more:
+                // the re-estimation changed `errors`)
+                if ((double)change_count > 0.9 * frag_len || est_cur <= target) {
                     done = true; st_draws = (int)n_base + src + 1; break;
                 }
+                mask &= mask - 1;
             }
+            wave_sync();
             if (!done && !need_aln) {
                 if (dead) { done = true; st_draws = (int)loop_limit; }
                 else n_base += 64;
@@ -910,14 +1011,14 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
                 nrows = 1000;
             }
-            const int m = join_window(frag, nb, p0, nrows, N, owner, P.ncap, lane);
+            const int m = join_window(frag, nb, p0, nrows, N, owner, lds_ncap, lane);
             wave_sync();
-            if (m > P.ncap) {                              // output slot overflow: the host reruns with larger slots
+            if (m > lds_ncap) {                              // output slot overflow: the host reruns with larger slots
                 finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
                 if (lane == 0) FB.state[r].stage = 2;
                 return;
             }
-            const uint32_t job = build_job(FB, r, 0, p0, nrows, m, N, owner, lane);
+            const uint32_t job = build_job(FB, r, begin + widx, 0, p0, nrows, m, N, owner, lane);
             if (job >> 31) { go_slow(FB, r, lane); return; }
             for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
             if (lane == 0) {
@@ -925,7 +1026,6 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 S.resume_src = (int16_t)r_src; S.resume_j = (int16_t)r_j; S.pending = 1; S.stage = 0;
                 S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
                 FB.state[r] = S;
-                atomicAdd(&FB.counters[1], 1u);
             }
             return;
         }
@@ -939,10 +1039,10 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     int start_trim, end_trim;
     {
         int v1 = lane < k ? slot_len(nb[lane]) : 0, v2 = lane < k ? slot_len(nb[L - k + lane]) : 0;
-        start_trim = __shfl(scan_add_incl(v1, lane), 63, 64);
-        end_trim = __shfl(scan_add_incl(v2, lane), 63, 64);
+        (void)prefix_small(v1, start_trim);
+        (void)prefix_small(v2, end_trim);
     }
-    const int jcap = min(P.ncap, cap);
+    const int jcap = min(lds_ncap, cap);
     const int m = join_window(frag, nb, 0, L, N, owner, jcap, lane);
     wave_sync();
     int lo = start_trim, hi = end_trim == 0 ? 0 : m - end_trim;
@@ -951,13 +1051,12 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
     if (S.stage == 0 && want_q) {
-        const uint32_t job = build_job(FB, r, 1, 0, L, m, N, owner, lane);
+        const uint32_t job = build_job(FB, r, begin + widx, 1, 0, L, m, N, owner, lane);
         if (job >> 31) { go_slow(FB, r, lane); return; }
         if (lane == 0) {
             S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
             S.resume_src = -1; S.pending = 1; S.stage = 1; S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
             FB.state[r] = S;
-            atomicAdd(&FB.counters[1], 1u);
         }
         return;
     }
@@ -1021,6 +1120,18 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     if (lane == 0) FB.state[r].stage = 2;
 }
 
+// ---- tail cut: reads still in the error loop when few are left are finished by the wave-wide kernel in one launch
+__global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    ReadState S = FB.state[r];
+    if (S.stage != 2 && !S.slow) {
+        FB.state[r].slow = 1;
+        const uint32_t idx = atomicAdd(&FB.counters[2], 1u);
+        FB.slow_list[idx] = (uint32_t)r;
+    }
+}
+
 // ---- k_aln: bit-parallel (Myers / Hyyro) banded global alignment, one lane per job.
 // Column j of the joined sequence owns fragment rows t_j .. t_j+63 (bit b = row t_j + b); t advances by the
 // 4-bit shift the job carries.  Entering rows take vertical delta +1 (virtual cells below the previous window),
@@ -1032,8 +1143,11 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     // per-lane staging of 8 trace columns (16 B each), [column & 7][lane]: only the owning lane touches its slots
     __shared__ ulonglong2 tr_lds[8 * 64];
     const int lane = threadIdx.x;
-    const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;
-    const bool act = job < n_jobs;
+    const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;          // wave-aligned ranges of rs ids
+    const uint32_t rng = job / FB.rs;
+    const uint32_t in_rng = FB.job_cnt[rng * 32u];
+    if (in_rng <= (blockIdx.x * 64u) % FB.rs) return;                // whole wave beyond the range's job count
+    const bool act = job < n_jobs && (job % FB.rs) < in_rng;
     uint32_t r = 0; int p0 = 0, n = 0, m = 0, mode = 0;
     if (act) {
         const uint32_t* meta = FB.job_meta + 4ull * job;
@@ -1052,17 +1166,29 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
 
     unsigned long long Pv = ~0ull, Mv = 0ull;
-    int t = 1, fwi = -1;
-    unsigned long long flo0 = 0, flo1 = 0, fhi0 = 0, fhi1 = 0, nlo = 0, nhi = 0;
+    int t = 1, fbase = -1;
+    // 4-word register window of each fragment plane, re-based only at block boundaries (uniform time for the
+    // whole wave): inside a block of 8 columns the band moves by at most 8 * 15 = 120 rows, so bits
+    // [o, o + 63] always lie inside words fbase .. fbase + 3
+    unsigned long long fl0 = 0, fl1 = 0, fl2 = 0, fl3 = 0, fh0 = 0, fh1 = 0, fh2 = 0, fh3 = 0, nlo = 0, nhi = 0;
     uint32_t shw = (act && m > 0) ? jsh[0] : 0u;
     for (int c = 0; c < mmax; c++) {
+        if ((c & 7) == 0 && act && c < m) {
+            const int nbase = (p0 + t - 1) >> 6;
+            if (nbase != fbase) {
+                fbase = nbase;
+                fl0 = fl[nbase]; fl1 = fl[nbase + 1]; fl2 = fl[nbase + 2]; fl3 = fl[nbase + 3];
+                fh0 = fh[nbase]; fh1 = fh[nbase + 1]; fh2 = fh[nbase + 2]; fh3 = fh[nbase + 3];
+            }
+        }
         if (act && c < m) {
             const int sh = (int)((shw >> (4 * (c & 7))) & 15u);
             t += sh;
             if (sh) { Pv = (Pv >> sh) | (~0ull << (64 - sh)); Mv >>= sh; }
             else if (t > 1) { Pv &= ~1ull; Mv |= 1ull; }
-            const int o = p0 + t - 1, wi = o >> 6, s = o & 63;
-            if (wi != fwi) { fwi = wi; flo0 = fl[wi]; flo1 = fl[wi + 1]; fhi0 = fh[wi]; fhi1 = fh[wi + 1]; }
+            const int o = p0 + t - 1, kx = (o >> 6) - fbase, s = o & 63;
+            const unsigned long long flo0 = kx == 0 ? fl0 : (kx == 1 ? fl1 : fl2), flo1 = kx == 0 ? fl1 : (kx == 1 ? fl2 : fl3);
+            const unsigned long long fhi0 = kx == 0 ? fh0 : (kx == 1 ? fh1 : fh2), fhi1 = kx == 0 ? fh1 : (kx == 1 ? fh2 : fh3);
             const unsigned long long lo = s ? (flo0 >> s) | (flo1 << (64 - s)) : flo0;
             const unsigned long long hi = s ? (fhi0 >> s) | (fhi1 << (64 - s)) : fhi0;
             const int nbv = n - t;
@@ -1365,12 +1491,19 @@ hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView&
 }
 int err_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap * 3); }
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
-                      const FastBuffers& fb, int wpw, hipStream_t s) {
-    if (!b.n_reads) return hipSuccess;
-    const int lds = err_lds_bytes(p.lcap, p.ncap, wpw);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_err), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                      const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
+                      int wpw, hipStream_t s) {
+    if (!count) return hipSuccess;
+    const int lds = err_lds_bytes(lds_lcap, lds_ncap, wpw);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_err), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_err, dim3((unsigned)((b.n_reads + wpw - 1) / wpw)), dim3(64 * wpw), lds, s, b, em, qm, p, o, fb);
+    hipLaunchKernelGGL(k_err, dim3((count + wpw - 1) / wpw), dim3(64 * wpw), lds, s, b, em, qm, p, o, fb, order, begin, count, lds_lcap,
+                       lds_ncap);
+    return hipGetLastError();
+}
+hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s) {
+    if (!n_reads) return hipSuccess;
+    hipLaunchKernelGGL(k_collect_unfinished, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, fb, n_reads);
     return hipGetLastError();
 }
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, hipStream_t s) {
