@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtksmseq.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("TKSMSEQ_LIB", "libtksmseq.so"))   # TKSMSEQ_LIB: diagnostic builds
 
 OK, EINVAL, EIO, EDEVICE, ENOMEM, ESTATE, ELIMIT = range(7)
 MODE_PERFECT, MODE_BADREAD = 0, 1

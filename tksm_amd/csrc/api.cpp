@@ -86,13 +86,13 @@ struct tksmseq_ctx : ContigLookup {
     // models
     ErrorModelHost em; QScoreModelHost qm; IdentityHost idm;
     bool em_uniform = false;
-    DevBuf d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab;
+    DevBuf d_cdf32, d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow, f_jobcnt;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow, f_jobcnt, f_prof;
     bool force_slow = false;
     uint32_t tail_cut = 4096;
     std::vector<hipEvent_t> evpool;
@@ -263,6 +263,14 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
     for (uint8_t v : ctx->em.nalts) if ((int)v != ctx->em.max_alts) { ctx->em_uniform = false; break; }
     int rc;
     if ((rc = upload(ctx, ctx->d_cdf, ctx->em.cdf))) return rc;
+    {
+        if (ctx->em.max_alts > 32) { ctx->err = "error models with more than 32 alternatives per k-mer are not supported"; return TKSMSEQ_ELIMIT; }
+        const size_t nk = ctx->em.nalts.size(), A = (size_t)ctx->em.max_alts;
+        std::vector<uint32_t> c32(nk * 32, 0xFFFFFFFFu);
+        for (size_t i = 0; i < nk; i++) for (size_t a = 0; a < A; a++) c32[i * 32 + a] = ctx->em.cdf[i * A + a];
+        if (ctx->em.type == 0) std::fill(c32.begin(), c32.end(), 0u);
+        if ((rc = upload(ctx, ctx->d_cdf32, c32))) return rc;
+    }
     if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
     return upload(ctx, ctx->d_nalts, ctx->em.nalts);
 }
@@ -278,7 +286,31 @@ int tksmseq_load_qscore_model(tksmseq_ctx* ctx, const char* name_or_path) {
     if ((rc = upload(ctx, ctx->d_qoff, ctx->qm.row_off))) return rc;
     if ((rc = upload(ctx, ctx->d_qcnt, ctx->qm.row_cnt))) return rc;
     if ((rc = upload(ctx, ctx->d_qcdf, ctx->qm.cdf_pool))) return rc;
-    return upload(ctx, ctx->d_qq, ctx->qm.q_pool);
+    if ((rc = upload(ctx, ctx->d_qq, ctx->qm.q_pool))) return rc;
+    {
+        const QScoreModelHost& m2 = ctx->qm;
+        const size_t ns = (size_t)m2.n_slots;
+        std::vector<uint32_t> ent(ns * 4, 0), pairs(m2.q_pool.size() * 2, 0);
+        std::vector<uint8_t> guide(ns * 64, 0);
+        for (size_t i = 0; i < m2.q_pool.size(); i++) { pairs[2 * i] = m2.cdf_pool[i]; pairs[2 * i + 1] = m2.q_pool[i]; }
+        for (size_t s2 = 0; s2 < ns; s2++) {
+            ent[4 * s2] = (uint32_t)m2.keys[s2]; ent[4 * s2 + 1] = (uint32_t)(m2.keys[s2] >> 32);
+            ent[4 * s2 + 2] = m2.row_off[s2]; ent[4 * s2 + 3] = m2.row_cnt[s2];
+            if (!m2.keys[s2]) continue;
+            const uint32_t off = m2.row_off[s2], cnt = m2.row_cnt[s2];
+            if (cnt > 255) { ctx->err = "q-score rows with more than 255 entries are not supported"; return TKSMSEQ_ELIMIT; }
+            uint32_t a = 0;
+            for (uint32_t bkt = 0; bkt < 64; bkt++) {
+                // entries whose threshold is <= the smallest draw of the bucket can never be chosen in it
+                const uint32_t wmin = bkt << 26;
+                while (a + 1 < cnt && m2.cdf_pool[off + a] <= wmin) a++;
+                guide[s2 * 64 + bkt] = (uint8_t)a;
+            }
+        }
+        if ((rc = upload(ctx, ctx->d_qent, ent))) return rc;
+        if ((rc = upload(ctx, ctx->d_qpairs, pairs))) return rc;
+        return upload(ctx, ctx->d_qguide, guide);
+    }
 }
 
 int tksmseq_set_identity(tksmseq_ctx* ctx, double mean, double max, double stdev) {
@@ -492,9 +524,10 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), n, (uint32_t)b->n_literals};
     tk::RefView R{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
                   ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_cdf32.as<uint32_t>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
-                       ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>()};
+                       ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
+                       ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>()};
     tk::IdentView IM{ctx->idm.constant ? 1 : 0, ctx->idm.value, ctx->d_qtab.as<double>()};
     tk::SimParams P{};
     P.seed = p->seed; P.first_read = p->first_read_index; P.stride = p->read_index_stride ? p->read_index_stride : 1;
@@ -550,6 +583,11 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         FB.job_cnt = ctx->f_jobcnt.as<uint32_t>();
+        HIPCHK(ctx, ctx->f_prof.ensure(256));
+        FB.prof = ctx->f_prof.as<unsigned long long>();
+#ifdef TKSM_PROF
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_prof.p, 0, 256, s));
+#endif
         std::vector<uint32_t> hcnt((size_t)FB.n_ranges * 32);
         // length buckets over the sorted read order: each bucket gets its own LDS geometry
         struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; };
@@ -617,6 +655,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             kinds.push_back(2);
         }
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
+#ifdef TKSM_PROF
+        {
+            unsigned long long pr[16];
+            HIPCHK(ctx, hipMemcpy(pr, ctx->f_prof.p, 128, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[prof] rounds=%u slow=%u | per loop-invocation (n=%llu) cycles: load %.0f gen %.0f eval %.0f seq %.0f join %.0f job %.0f store %.0f total %.0f | final (n=%llu): join %.0f lookups %.0f total %.0f\n", rounds, cnt[2], pr[10], (double)pr[0] / (pr[10] + pr[12] + 1), (double)pr[1] / (pr[10] + 1), (double)pr[2] / (pr[10] + 1), (double)pr[3] / (pr[10] + 1), (double)pr[4] / (pr[10] + 1), (double)pr[5] / (pr[10] + 1), (double)pr[6] / (pr[10] + 1), (double)pr[9] / (pr[10] + 1), pr[12], (double)pr[7] / (pr[12] + 1), (double)pr[8] / (pr[12] + 1), (double)pr[11] / (pr[12] + 1));
+        }
+#endif
         if (cnt[2]) {
             // reads with non-ACGT bytes (or an alignment outside the band representation): byte-exact wave-wide path
             O.read_list = ctx->f_slow.as<uint32_t>(); O.n_work = cnt[2];

@@ -35,6 +35,7 @@ struct ErrModelView {
     const uint32_t* cdf;
     const uint64_t* alts;
     const uint8_t* nalts;
+    const uint32_t* cdf32;  // [4^k][32] the same thresholds padded to 128-byte rows (max_alts <= 32 only)
 };
 
 struct QsModelView {
@@ -44,6 +45,11 @@ struct QsModelView {
     const uint32_t* row_cnt;
     const uint32_t* cdf_pool;
     const uint8_t* q_pool;
+    // the same model in the layout k_err reads: one 16-byte hash entry {key, row offset, row count}, rows as
+    // {threshold, q} pairs, and a 64-bucket guide (first candidate index per quantile bucket of the draw)
+    const uint4* ent;
+    const uint2* pairs;
+    const uint8_t* guide;
 };
 
 struct IdentView {
@@ -104,6 +110,7 @@ struct FastBuffers {
     uint32_t* counters;               // [2] slow reads
     uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
     uint32_t rs, n_ranges;
+    unsigned long long* prof;         // diagnostic builds (-DTKSM_PROF) only: per-section cycle sums
     uint32_t* slow_list;              // [n_reads]
     int fw, nw, shw;
 };

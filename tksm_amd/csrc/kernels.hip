@@ -607,22 +607,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
 // are routed to the byte-exact wave-wide path (k_simulate over slow_list).  Same specification,
 // same results, bit for bit.
 // ================================================================================================
-// first alternative a with w < cdf[a] (cumulative, non-decreasing), or na if none: the row is fetched with
-// independent 16-byte loads instead of a dependent scalar scan
-DEV int cdf_pick(const uint32_t* cdf, int na, int stride, uint32_t w) {
+// first alternative a with w < cdf[a] (cumulative, non-decreasing), or na if none.  Device rows are padded to
+// 32 thresholds (128 B, filled with 0xffffffff): ~81 % of the draws are settled by the first threshold alone
+// (the k-mer itself), only the rest fetch the row, with independent 16-byte loads.
+DEV int cdf_pick(const uint32_t* cdf32, int na, uint32_t w) {
+    if (w < cdf32[0]) return 0;
+    const uint4* c4 = reinterpret_cast<const uint4*>(cdf32);
+    uint4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = c4[q];
     int a = 0;
-    if (((stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(cdf) & 7) == 0)) {
-        const int n2 = (na + 1) >> 1;
-        const uint2* c2 = reinterpret_cast<const uint2*>(cdf);
-        uint2 v[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = q < n2 ? c2[q] : make_uint2(0xffffffffu, 0xffffffffu);
-#pragma unroll
-        for (int q = 0; q < 16; q++) { a += (2 * q < na && !(w < v[q].x)) ? 1 : 0; a += (2 * q + 1 < na && !(w < v[q].y)) ? 1 : 0; }
-        if (na <= 32) return a;
-        a = 32;
+    for (int q = 0; q < 8; q++) {
+        a += (4 * q < na && !(w < v[q].x)) ? 1 : 0; a += (4 * q + 1 < na && !(w < v[q].y)) ? 1 : 0;
+        a += (4 * q + 2 < na && !(w < v[q].z)) ? 1 : 0; a += (4 * q + 3 < na && !(w < v[q].w)) ? 1 : 0;
     }
-    while (a < na && !(w < cdf[a])) a++;
     return a;
 }
 
@@ -834,6 +833,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     const uint64_t r = order[begin + widx];
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
+    PROF_T(t_begin);
     const int per_wave = lds_lcap * 3 + lds_ncap * 3;
     uint8_t* frag = lds_raw + (size_t)wave * per_wave;
     uint16_t* nb = reinterpret_cast<uint16_t*>(frag + lds_lcap);
@@ -853,6 +853,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag + t);
     for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
     wave_sync();
+    PROF_T(t_loaded); PROF_ADD(0, t_begin, t_loaded);
     uint32_t status = 0;
     const double frag_len = (double)L;
     double errors = S.errors;
@@ -882,6 +883,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
         if (!resume && !S.pending)
             if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
         while (!done && !need_aln) {
+            PROF_T(t_r0);
             const uint32_t n = n_base + (uint32_t)lane;
             const bool live = (long long)n + 1 <= loop_limit;
             const Ph4 d = philox(P.seed, g, ST_DRAW, n);
@@ -893,9 +895,8 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 for (int jj = 0; jj < k; jj++) { const int cc = code_of(frag[i + jj]); valid &= cc >= 0; kidx = (kidx << 2) | (cc & 3); }
                 if (EM.type == 0 || !valid) kind = 2;
                 else {
-                    const uint32_t* cdf = EM.cdf + (size_t)kidx * EM.max_alts;
                     const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
-                    const int a = cdf_pick(cdf, na, EM.max_alts, d.y);
+                    const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, na, d.y);
                     if (a == na) kind = 2;
                     else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
                 }
@@ -906,6 +907,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                     alt = type | (pos << 2) | (base4 << 8) | (side << 10) | (r3 << 12);
                 }
             }
+            PROF_T(t_r1); PROF_ADD(1, t_r0, t_r1);
             unsigned long long mask = __ballot(live && kind != 0);
             const unsigned long long dead = __ballot(!live);
             if (resume) mask &= ~((1ull << S.resume_src) - 1ull);
@@ -928,6 +930,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 depm = __ballot(acc && dep);
                 if (resume) depm |= 1ull << S.resume_src;
             }
+            PROF_T(t_r2); PROF_ADD(2, t_r1, t_r2);
             double est_cur = 1.0 - errors / frag_len;
             while (mask) {
                 const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
@@ -997,6 +1000,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 mask &= mask - 1;
             }
             wave_sync();
+            PROF_T(t_r3); PROF_ADD(3, t_r2, t_r3);
             if (!done && !need_aln) {
                 if (dead) { done = true; st_draws = (int)loop_limit; }
                 else n_base += 64;
@@ -1011,14 +1015,17 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
                 nrows = 1000;
             }
+            PROF_T(t_j0);
             const int m = join_window(frag, nb, p0, nrows, N, owner, lds_ncap, lane);
             wave_sync();
+            PROF_T(t_j1); PROF_ADD(4, t_j0, t_j1);
             if (m > lds_ncap) {                              // output slot overflow: the host reruns with larger slots
                 finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
                 if (lane == 0) FB.state[r].stage = 2;
                 return;
             }
             const uint32_t job = build_job(FB, r, begin + widx, 0, p0, nrows, m, N, owner, lane);
+            PROF_T(t_j2); PROF_ADD(5, t_j1, t_j2);
             if (job >> 31) { go_slow(FB, r, lane); return; }
             for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
             if (lane == 0) {
@@ -1027,6 +1034,8 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
                 FB.state[r] = S;
             }
+            PROF_T(t_j3); PROF_ADD(6, t_j2, t_j3); PROF_ADD(9, t_begin, t_j3);
+            if (lane == 0) atomicAdd(&FB.prof[10], 1ull);
             return;
         }
         // the loop has ended: write the final slots back once (the FINAL stage re-joins from them)
@@ -1036,6 +1045,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     }
 
     // ---- :434-437 trims and the joined sequence (both stages)
+    PROF_T(t_f0);
     int start_trim, end_trim;
     {
         int v1 = lane < k ? slot_len(nb[lane]) : 0, v2 = lane < k ? slot_len(nb[L - k + lane]) : 0;
@@ -1060,6 +1070,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
         }
         return;
     }
+    PROF_T(t_f1); PROF_ADD(7, t_f0, t_f1);
     if (want_q) {
         // ---- S5 q-scores from the alignment k_aln left in job_popd (py/tksm_badread.py:607-655)
         const uint32_t mt = FB.aln_res[4 * r], cols = FB.aln_res[4 * r + 1], fail = FB.aln_res[4 * r + 2];
@@ -1074,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
         for (int i2 = lo + lane; i2 < hi; i2 += 64) {
             int s0 = i2 - margins, e0 = i2 + margins;
             while (s0 < 0 || e0 >= m) { s0++; e0--; }
-            int row = -1;
+            int row = -1; uint32_t roff = 0, rcnt = 0;
             for (;;) {
                 uint64_t key = 0; int len = 0; bool ok = true;
                 for (int x2 = s0; x2 <= e0; x2++) {
@@ -1090,8 +1101,9 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                     key |= (uint64_t)len << 58;
                     uint32_t s = (uint32_t)qs_hash(key) & hmask;
                     for (;;) {
-                        const uint64_t kk = QM.keys[s];
-                        if (kk == key) { row = (int)s; break; }
+                        const uint4 e = QM.ent[s];               // {key lo, key hi, row offset, row count}
+                        const uint64_t kk = ((uint64_t)e.y << 32) | e.x;
+                        if (kk == key) { row = (int)s; roff = e.z; rcnt = e.w; break; }
                         if (kk == 0) break;
                         s = (s + 1) & hmask;
                     }
@@ -1102,11 +1114,12 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
             uint8_t q = 0;
             if (row >= 0) {
                 const uint32_t w = philox(P.seed, g, ST_QUAL, (uint32_t)i2).x;
-                const uint32_t off = QM.row_off[row], cnt = QM.row_cnt[row];
-                // first a with w < cdf[a], else the last entry (thresholds are non-decreasing)
-                uint32_t lo2 = 0, hi2 = cnt - 1;
-                while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (w < QM.cdf_pool[off + mid]) hi2 = mid; else lo2 = mid + 1; }
-                q = QM.q_pool[off + lo2];
+                // first a with w < cdf[a], else the last entry; the per-row guide table gives the first candidate
+                // for the 64-quantile bucket of w, the scan from there ends within a step or two
+                uint32_t a2 = QM.guide[(size_t)row * 64 + (w >> 26)];
+                uint2 pr = QM.pairs[roff + a2];
+                while (a2 + 1 < rcnt && !(w < pr.x)) { a2++; pr = QM.pairs[roff + a2]; }
+                q = (uint8_t)pr.y;
             }
             out_qual[i2 - lo] = (uint8_t)(q + 33);
         }
@@ -1118,6 +1131,8 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
                 start_trim, end_trim, errors, target, lane);
     if (lane == 0) FB.state[r].stage = 2;
+    PROF_T(t_f2); PROF_ADD(8, t_f1, t_f2); PROF_ADD(11, t_begin, t_f2);
+    if (lane == 0) atomicAdd(&FB.prof[12], 1ull);
 }
 
 // ---- tail cut: reads still in the error loop when few are left are finished by the wave-wide kernel in one launch
