@@ -86,7 +86,7 @@ struct tksmseq_ctx : ContigLookup {
     // models
     ErrorModelHost em; QScoreModelHost qm; IdentityHost idm;
     bool em_uniform = false;
-    DevBuf d_cdf32, d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
+    DevBuf d_pself, d_cdf32, d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
@@ -94,7 +94,8 @@ struct tksmseq_ctx : ContigLookup {
     // fast Badread pipeline state (see kernels.h FastBuffers)
     DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow, f_jobcnt, f_prof;
     bool force_slow = false;
-    uint32_t tail_cut = 4096;
+    uint32_t tail_cut = 1024;
+    uint32_t n_buckets = 16;
     std::vector<hipEvent_t> evpool;
     uint32_t last_rounds = 0, last_slow = 0;
     void* user_out = nullptr; uint64_t user_out_cap = 0;
@@ -134,6 +135,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     c->device = device;
     if (const char* fs = getenv("TKSMSEQ_FORCE_SLOW")) c->force_slow = fs[0] == '1';
     if (const char* tc = getenv("TKSMSEQ_TAIL_CUT")) c->tail_cut = (uint32_t)atoi(tc);
+    if (const char* nbk = getenv("TKSMSEQ_BUCKETS")) c->n_buckets = (uint32_t)std::max(1, atoi(nbk));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -270,6 +272,9 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
         for (size_t i = 0; i < nk; i++) for (size_t a = 0; a < A; a++) c32[i * 32 + a] = ctx->em.cdf[i * A + a];
         if (ctx->em.type == 0) std::fill(c32.begin(), c32.end(), 0u);
         if ((rc = upload(ctx, ctx->d_cdf32, c32))) return rc;
+        std::vector<uint32_t> ps(nk);
+        for (size_t i = 0; i < nk; i++) ps[i] = c32[i * 32];
+        if ((rc = upload(ctx, ctx->d_pself, ps))) return rc;
     }
     if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
     return upload(ctx, ctx->d_nalts, ctx->em.nalts);
@@ -486,7 +491,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         b->cache_scratch = t; b->cache_k = k; b->cache_num = cap_num; b->cache_den = cap_den; b->cache_add = cap_add;
     }
     // LDS geometry from the longest molecule of the batch
-    const int lcap = (int)((b->max_raw + 2 * k + 3) & ~3u);
+    const int lcap = (int)((b->max_raw + 2 * k + 7) & ~7u);   // multiple of 8: 64-bit LDS words follow 3 * lcap bytes
     const int ncap = badread ? (int)capf(b->max_raw) : 4;
     int wpw = tk::WAVES_PER_WG;
     while (wpw > 1 && tk::simulate_lds_bytes(lcap, ncap, wpw) > 160 * 1024) wpw >>= 1;
@@ -524,7 +529,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), n, (uint32_t)b->n_literals};
     tk::RefView R{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
                   ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_cdf32.as<uint32_t>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint32_t>(), ctx->d_cdf32.as<uint32_t>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
                        ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>()};
@@ -594,7 +599,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         std::vector<Bucket> buckets;
         {
             const uint32_t minr = b->raw_len[b->order.front()], maxr = b->raw_len[b->order.back()];
-            const uint32_t step = std::max<uint32_t>(128, ((maxr - minr) / 16 + 63) & ~63u);
+            const uint32_t step = std::max<uint32_t>(128, ((maxr - minr) / ctx->n_buckets + 63) & ~63u);
             uint64_t i0 = 0;
             while (i0 < n) {
                 const uint32_t lim = (b->raw_len[b->order[i0]] / step + 1) * step;
@@ -603,7 +608,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 const uint32_t mx = b->raw_len[b->order[i1 - 1]];
                 Bucket bk;
                 bk.begin = (uint32_t)i0; bk.count = (uint32_t)(i1 - i0);
-                bk.lcap = (int)((mx + 2 * k + 3) & ~3u); bk.ncap = (int)capf(mx);
+                bk.lcap = (int)((mx + 2 * k + 7) & ~7u); bk.ncap = (int)capf(mx);
                 bk.wpw = tk::WAVES_PER_WG;
                 while (bk.wpw > 1 && tk::err_lds_bytes(bk.lcap, bk.ncap, bk.wpw) > 64 * 1024) bk.wpw >>= 1;
                 buckets.push_back(bk);

@@ -610,8 +610,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
 // first alternative a with w < cdf[a] (cumulative, non-decreasing), or na if none.  Device rows are padded to
 // 32 thresholds (128 B, filled with 0xffffffff): ~81 % of the draws are settled by the first threshold alone
 // (the k-mer itself), only the rest fetch the row, with independent 16-byte loads.
-DEV int cdf_pick(const uint32_t* cdf32, int na, uint32_t w) {
-    if (w < cdf32[0]) return 0;
+DEV int cdf_pick(const uint32_t* cdf32, uint32_t pself, int na, uint32_t w) {
+    if (w < pself) return 0;
     const uint4* c4 = reinterpret_cast<const uint4*>(cdf32);
     uint4 v[8];
 #pragma unroll
@@ -814,6 +814,81 @@ DEV SlotEval eval_draw(const uint8_t* frag, const uint16_t* nb, int k, int i, in
     return r;
 }
 
+// joined length of slots [p0, p0+n)
+DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
+    int m = 0;
+    for (int q = 0; q < n; q += 64) {
+        const int p = q + lane;
+        const int len = p < n ? slot_len(nb[p0 + p]) : 0;
+        int total;
+        (void)prefix_small(len, total);
+        m += total;
+    }
+    return m;
+}
+
+// Walks the slots of window [p0, p0+n) once, slot per lane, and
+//  build != 0: packs the joined sequence straight into the alignment job (2-bit planes + 4-bit window shift per
+//              column) through a small LDS staging area filled with ds_or atomics -- the joined bytes and their
+//              owner array are never materialised;
+//  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
+// Returns the job id (bit 31: the job cannot be represented, shift > 15).
+DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
+                      int p0, int n, int m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
+    const int lnw = ncap_l / 64 + 2, lshw = ncap_l / 8 + 16;
+    unsigned long long* pl = reinterpret_cast<unsigned long long*>(stage);
+    uint32_t* shn = reinterpret_cast<uint32_t*>(stage + 16 * (size_t)lnw);
+    uint32_t idx = 0;
+    if (build) {
+        if (lane == 0) { const uint32_t c = pos / FB.rs; idx = c * FB.rs + atomicAdd(&FB.job_cnt[c * 32u], 1u); }
+        idx = __shfl(idx, 0, 64);
+        if (lane == 0) {
+            uint32_t* meta = FB.job_meta + 4ull * idx;
+            meta[0] = (uint32_t)r; meta[1] = (uint32_t)p0; meta[2] = (uint32_t)n | ((uint32_t)mode << 31); meta[3] = (uint32_t)m;
+        }
+        uint32_t* z = reinterpret_cast<uint32_t*>(stage);
+        for (int t = lane; t < 4 * lnw + lshw; t += 64) z[t] = 0u;
+        wave_sync();
+    }
+    bool fail = false;
+    int base = 0, last_nonempty = -1;
+    for (int q = 0; q < n; q += 64) {
+        const int p = q + lane;
+        uint32_t code = 0; int len = 0; uint8_t orig = 0;
+        if (p < n) { code = nb[p0 + p]; len = slot_len(code); orig = frag[p0 + p]; }
+        int total;
+        const int off = base + prefix_small(len, total);
+        const unsigned long long ne = __ballot(len > 0);
+        if (build && len > 0 && off + len <= ncap_l) {
+            const unsigned long long below = ne & ((1ull << lane) - 1ull);
+            const int prevp = below ? q + 63 - __builtin_clzll(below) : last_nonempty;
+            const int sh = max(1, p + 1 - 31) - max(1, prevp + 1 - 31);
+            if (sh > 15) fail = true;
+            atomicOr(&shn[off >> 3], (uint32_t)(sh & 15) << (4 * (off & 7)));
+            for (int x2 = 0; x2 < len; x2++) {
+                const int c = off + x2;
+                const int cd = code_of(slot_sym(code, x2, orig));
+                if (cd & 1) atomicOr(&pl[c >> 6], 1ull << (c & 63));
+                if (cd & 2) atomicOr(&pl[lnw + (c >> 6)], 1ull << (c & 63));
+            }
+        }
+        if (out_seq)
+            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = slot_sym(code, x2, orig); }
+        if (ne) last_nonempty = q + 63 - __builtin_clzll(ne);
+        base += total;
+    }
+    if (build) {
+        wave_sync();
+        unsigned long long* jn = FB.job_n + (size_t)idx * 2 * FB.nw;
+        uint32_t* jsh = FB.job_sh + (size_t)idx * FB.shw;
+        const int wn = m / 64 + 2;              // words k_aln may touch (incl. the zero word after the end)
+        for (int t = lane; t < wn; t += 64) { jn[t] = pl[t]; jn[FB.nw + t] = pl[lnw + t]; }
+        const int ws = m / 8 + 2;
+        for (int t = lane; t < ws; t += 64) jsh[t] = shn[t];
+    }
+    return idx | (__ballot(fail) ? 0x80000000u : 0u);
+}
+
 #ifdef TKSM_PROF
 #define PROF_T(x) unsigned long long x = __builtin_amdgcn_s_memtime()
 #define PROF_ADD(slot, t0, t1) do { if (lane == 0) atomicAdd(&FB.prof[slot], (t1) - (t0)); } while (0)
@@ -834,12 +909,12 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
     PROF_T(t_begin);
-    const int per_wave = lds_lcap * 3 + lds_ncap * 3;
+    // LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (job staging / per-position alignment ops)
+    const int per_wave = lds_lcap * 3 + lds_ncap + 128;
     uint8_t* frag = lds_raw + (size_t)wave * per_wave;
     uint16_t* nb = reinterpret_cast<uint16_t*>(frag + lds_lcap);
-    uint8_t* N = frag + 3 * (size_t)lds_lcap;
-    uint16_t* owner = reinterpret_cast<uint16_t*>(N + lds_ncap);
-    uint8_t* popd = reinterpret_cast<uint8_t*>(owner);
+    uint8_t* aux = frag + 3 * (size_t)lds_lcap;
+    uint8_t* popd = aux;
     const int k = EM.k;
     const uint64_t g = P.first_read + r * P.stride;
     const int raw_len = (int)O.raw_len[r];
@@ -896,7 +971,8 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 if (EM.type == 0 || !valid) kind = 2;
                 else {
                     const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
-                    const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, na, d.y);
+                    // the first threshold (the k-mer itself, ~81 % of all draws) comes from a compact 64 KB array
+                    const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, EM.pself[kidx], na, d.y);
                     if (a == na) kind = 2;
                     else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
                 }
@@ -1016,15 +1092,14 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
                 nrows = 1000;
             }
             PROF_T(t_j0);
-            const int m = join_window(frag, nb, p0, nrows, N, owner, lds_ncap, lane);
-            wave_sync();
+            const int m = joined_len(nb, p0, nrows, lane);
             PROF_T(t_j1); PROF_ADD(4, t_j0, t_j1);
             if (m > lds_ncap) {                              // output slot overflow: the host reruns with larger slots
                 finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
                 if (lane == 0) FB.state[r].stage = 2;
                 return;
             }
-            const uint32_t job = build_job(FB, r, begin + widx, 0, p0, nrows, m, N, owner, lane);
+            const uint32_t job = join_job(FB, 1, r, begin + widx, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
             PROF_T(t_j2); PROF_ADD(5, t_j1, t_j2);
             if (job >> 31) { go_slow(FB, r, lane); return; }
             for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
@@ -1053,15 +1128,14 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
         (void)prefix_small(v2, end_trim);
     }
     const int jcap = min(lds_ncap, cap);
-    const int m = join_window(frag, nb, 0, L, N, owner, jcap, lane);
-    wave_sync();
+    const int m = joined_len(nb, 0, L, lane);
     int lo = start_trim, hi = end_trim == 0 ? 0 : m - end_trim;
     lo = min(lo, m); hi = max(hi, lo);
     if (m > jcap) { status |= 1; lo = hi = 0; }
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
     if (S.stage == 0 && want_q) {
-        const uint32_t job = build_job(FB, r, begin + widx, 1, 0, L, m, N, owner, lane);
+        const uint32_t job = join_job(FB, 1, r, begin + widx, 1, frag, nb, 0, L, m, lds_ncap, aux, nullptr, 0, 0, lane);
         if (job >> 31) { go_slow(FB, r, lane); return; }
         if (lane == 0) {
             S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
@@ -1126,7 +1200,7 @@ __global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsMod
     } else {
         identity = 1.0 - errors / frag_len;
     }
-    for (int t = lo + lane; t < hi; t += 64) out_seq[t - lo] = N[t];
+    (void)join_job(FB, 0, r, 0, 0, frag, nb, 0, L, m, lds_ncap, aux, out_seq, lo, hi, lane);
     if (P.quirk_perfect) identity = 1.0;
     finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
                 start_trim, end_trim, errors, target, lane);
@@ -1268,38 +1342,31 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         unsigned long long pp = 0ull;
         bool touched = false;
         bool go = act && !fail && j > 0 && ((j - 1) >> 3) == blk;
+        const uint32_t modem = mode ? 0xffu : 0u;
         while (__ballot(go)) {
-            if (go) {
-                const int c = j - 1;
-                int mv, match = 0;                           // 0 up, 1 left, 2 diagonal
-                if (i == 0) mv = 1;
-                else {
-                    const int b = i - tt;
-                    if (b < 0) { fail = true; mv = 0; }
-                    else if (b > 63) mv = 0;                 // virtual cell below the window
-                    else {
-                        const ulonglong2 tw = tr_lds[(c & 7) * 64 + lane];
-                        const int code = (int)((tw.x >> b) & 1ull) | ((int)((tw.y >> b) & 1ull) << 1);
-                        mv = code == 0 ? 0 : (code == 1 ? 1 : 2);
-                        match = code == 3;
-                    }
-                }
-                cols++;
-                if (mv == 0) { i--; dpend++; }
-                else {
-                    if (mode) {
-                        pp |= (unsigned long long)((mv == 1 ? 2 : (match ? 0 : 1)) | (min(dpend, 63) << 2)) << (8 * (c & 7));
-                        touched = true;
-                    }
-                    dpend = 0;
-                    if (mv == 2) { i--; mt += (uint32_t)match; }
-                    tt -= (int)((cur_sh >> (4 * (c & 7))) & 15u);
-                    j--;
-                }
-                if (cols > (uint32_t)(n + m)) fail = true;   // cannot happen with a consistent trace
-                go = !fail && j > 0 && ((j - 1) >> 3) == blk;
-            }
+            // one step of every lane's walk, branch-free (lanes outside this block idle under `go`)
+            const int c = (j - 1) & 7;
+            const int b = i - tt;
+            const ulonglong2 tw = tr_lds[c * 64 + lane];
+            const int bs = b & 63;
+            int code = (int)((tw.x >> bs) & 1ull) | ((int)((tw.y >> bs) & 1ull) << 1);   // 0 up, 1 left, 2/3 diagonal
+            code = b > 63 ? 0 : code;                     // virtual cell below the window: up
+            code = i == 0 ? 1 : code;                     // row 0: only left
+            fail |= go && ((i > 0 && b < 0) || cols > (uint32_t)(n + m));
+            const bool up = code == 0, colmove = go && !up;
+            const uint32_t g1 = go ? 1u : 0u;
+            cols += g1;
+            i -= (go && code != 1) ? 1 : 0;
+            mt += (go && code == 3) ? 1u : 0u;
+            const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
+            pp |= colmove ? (unsigned long long)(opb & modem) << (8 * c) : 0ull;
+            touched |= colmove;
+            dpend = colmove ? 0 : dpend + (int)(g1 & (up ? 1u : 0u));
+            tt -= colmove ? (int)((cur_sh >> (4 * c)) & 15u) : 0;
+            j -= colmove ? 1 : 0;
+            go = go && !fail && j > 0 && ((j - 1) >> 3) == blk;
         }
+        touched = touched && mode;
         if (touched) popd8[blk] = pp;
         if (blk > 0) {
 #pragma unroll
@@ -1504,7 +1571,7 @@ hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView&
     hipLaunchKernelGGL(k_init, dim3((unsigned)((b.n_reads + wpw - 1) / wpw)), dim3(64 * wpw), lds, s, b, r, em, im, p, o, fb);
     return hipGetLastError();
 }
-int err_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap * 3); }
+int err_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap + 128); }
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
                       int wpw, hipStream_t s) {
