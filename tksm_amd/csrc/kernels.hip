@@ -897,7 +897,7 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
 #define PROF_ADD(slot, t0, t1)
 #endif
 // ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | N[ncap] | aux[2*ncap] (owner u16 / popd)
-__global__ __launch_bounds__(256) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
+__global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
                                               FastBuffers FB, const uint32_t* __restrict__ order, uint32_t begin, uint32_t count,
                                               int lds_lcap, int lds_ncap) {
     // one launch per length bucket: reads order[begin .. begin+count) share the LDS geometry (lds_lcap, lds_ncap),
@@ -1228,46 +1228,34 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
 // top row can only be reached from the left (vertical delta forced to -1).  Per column the resolved predecessor
 // of every cell is stored as 2 bits {w0, w1}: 0 up, 1 left, 2 diagonal mismatch, 3 diagonal match; the walk
 // back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
-__global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
-    // per-lane staging of 8 trace columns (16 B each), [column & 7][lane]: only the owning lane touches its slots
-    __shared__ ulonglong2 tr_lds[8 * 64];
-    const int lane = threadIdx.x;
-    const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;          // wave-aligned ranges of rs ids
-    const uint32_t rng = job / FB.rs;
-    const uint32_t in_rng = FB.job_cnt[rng * 32u];
-    if (in_rng <= (blockIdx.x * 64u) % FB.rs) return;                // whole wave beyond the range's job count
-    const bool act = job < n_jobs && (job % FB.rs) < in_rng;
-    uint32_t r = 0; int p0 = 0, n = 0, m = 0, mode = 0;
-    if (act) {
-        const uint32_t* meta = FB.job_meta + 4ull * job;
-        r = meta[0]; p0 = (int)meta[1]; n = (int)(meta[2] & 0x7fffffffu); mode = (int)(meta[2] >> 31); m = (int)meta[3];
-    }
-    const unsigned long long* fl = FB.st_fplanes + (size_t)r * 2 * FB.fw;
-    const unsigned long long* fh = fl + FB.fw;
-    const unsigned long long* nl = FB.job_n + (size_t)job * 2 * FB.nw;
-    const unsigned long long* nh = nl + FB.nw;
-    const uint32_t* jsh = FB.job_sh + (size_t)job * FB.shw;
-    // lane-major trace: every job owns ncap + 16 consecutive 16-byte columns (column c = j - 1), written and read
-    // back in whole 128-byte blocks of 8 columns
-    ulonglong2* trace = reinterpret_cast<ulonglong2*>(FB.trace) + (size_t)job * (size_t)(P.ncap + 16);
-    int mmax = m;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
+struct AlnJob {
+    bool act; int p0, n, m, mode;
+    const unsigned long long *fl, *fh, *nl, *nh;
+    const uint32_t* jsh;
+    unsigned long long* trace;   // per-job region of (ncap + 16) 16-byte columns
+    unsigned long long* popd8;
+};
+struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
 
+// One forward pass + walk back.  FULL = false keeps only the middle 32 rows of each column's predecessor codes
+// (8 bytes per column: rows 16..47 of the band, the path practically never leaves them); a lane whose walk needs a
+// row outside reports needfull and is redone with FULL = true (all 64 rows, 16 bytes per column).  Both variants
+// stage 4 KB per wave in LDS: 8 columns x 8 B or 4 columns x 16 B per lane.
+template <bool FULL>
+DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds) {
+    constexpr int CB = FULL ? 4 : 8, CSH = FULL ? 2 : 3, EW = FULL ? 2 : 1;   // columns per block, words per column
+    const int p0 = J.p0, n = J.n, m = J.m, mode = J.mode;
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1, fbase = -1;
-    // 4-word register window of each fragment plane, re-based only at block boundaries (uniform time for the
-    // whole wave): inside a block of 8 columns the band moves by at most 8 * 15 = 120 rows, so bits
-    // [o, o + 63] always lie inside words fbase .. fbase + 3
     unsigned long long fl0 = 0, fl1 = 0, fl2 = 0, fl3 = 0, fh0 = 0, fh1 = 0, fh2 = 0, fh3 = 0, nlo = 0, nhi = 0;
-    uint32_t shw = (act && m > 0) ? jsh[0] : 0u;
+    uint32_t shw = (act && m > 0) ? J.jsh[0] : 0u;
     for (int c = 0; c < mmax; c++) {
         if ((c & 7) == 0 && act && c < m) {
             const int nbase = (p0 + t - 1) >> 6;
             if (nbase != fbase) {
                 fbase = nbase;
-                fl0 = fl[nbase]; fl1 = fl[nbase + 1]; fl2 = fl[nbase + 2]; fl3 = fl[nbase + 3];
-                fh0 = fh[nbase]; fh1 = fh[nbase + 1]; fh2 = fh[nbase + 2]; fh3 = fh[nbase + 3];
+                fl0 = J.fl[nbase]; fl1 = J.fl[nbase + 1]; fl2 = J.fl[nbase + 2]; fl3 = J.fl[nbase + 3];
+                fh0 = J.fh[nbase]; fh1 = J.fh[nbase + 1]; fh2 = J.fh[nbase + 2]; fh3 = J.fh[nbase + 3];
             }
         }
         if (act && c < m) {
@@ -1280,11 +1268,10 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
             const unsigned long long fhi0 = kx == 0 ? fh0 : (kx == 1 ? fh1 : fh2), fhi1 = kx == 0 ? fh1 : (kx == 1 ? fh2 : fh3);
             const unsigned long long lo = s ? (flo0 >> s) | (flo1 << (64 - s)) : flo0;
             const unsigned long long hi = s ? (fhi0 >> s) | (fhi1 << (64 - s)) : fhi0;
-            const int nbv = n - t;
-            const unsigned long long vm = nbv >= 63 ? ~0ull : (nbv < 0 ? 0ull : ((2ull << nbv) - 1ull));
-            if ((c & 63) == 0) { nlo = nl[c >> 6]; nhi = nh[c >> 6]; }
+            if ((c & 63) == 0) { nlo = J.nl[c >> 6]; nhi = J.nh[c >> 6]; }
             const unsigned long long cl = 0ull - ((nlo >> (c & 63)) & 1ull), ch = 0ull - ((nhi >> (c & 63)) & 1ull);
-            const unsigned long long Eq = ~((lo ^ cl) | (hi ^ ch)) & vm;
+            // rows below the fragment window (i > n) are not masked: they never feed a row above them
+            const unsigned long long Eq = ~((lo ^ cl) | (hi ^ ch));
             const unsigned long long Xv = Eq | Mv;
             const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             const unsigned long long Ph = Mv | ~(Xh | Pv);
@@ -1298,86 +1285,138 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
             const unsigned long long is_up = mode ? (upv & ~Ph) : upv;
             const unsigned long long is_left = mode ? Ph : (Ph & ~upv);
             const unsigned long long is_diag = ~(is_up | is_left);
-            ulonglong2 tw;
-            tw.x = is_left | (is_diag & D0); tw.y = is_diag;
-            tr_lds[(c & 7) * 64 + lane] = tw;
+            const unsigned long long w0 = is_left | (is_diag & D0), w1 = is_diag;
+            if (FULL) { tr_lds[((c & 3) * 64 + lane) * 2] = w0; tr_lds[((c & 3) * 64 + lane) * 2 + 1] = w1; }
+            else {
+                // stored rows: 32 around the generative row, which sits at bit 31 once the window moves (t > 1) and
+                // climbs from bit 0 with the column index while the window is still clamped at row 1
+                const int st = t > 1 ? 16 : max(0, min(16, c - 15));
+                tr_lds[(c & 7) * 64 + lane] = ((w0 >> st) & 0xffffffffull) | ((w1 >> st) << 32);
+            }
         }
-        if ((c & 7) == 7 || c == mmax - 1) {
-            // the next block's shift word is requested BEFORE the stores: gfx9 counts stores in vmcnt, in issue
-            // order, so a load issued after them could only be waited for together with them
-            const uint32_t shn = (act && c + 1 < m) ? jsh[(c + 1) >> 3] : 0u;
-            const int c0 = c & ~7;
+        if ((c & (CB - 1)) == CB - 1 || c == mmax - 1) {
+            // the next shift word is requested BEFORE the stores: gfx9 counts stores in vmcnt, in issue order
+            uint32_t shn = shw;
+            if ((c & 7) == 7 || c == mmax - 1) shn = (act && c + 1 < m) ? J.jsh[(c + 1) >> 3] : 0u;
+            const int c0 = c & ~(CB - 1);
             if (act && c0 < m) {
 #pragma unroll
-                for (int x = 0; x < 8; x++) trace[c0 + x] = tr_lds[x * 64 + lane];
+                for (int x = 0; x < CB * EW; x++) J.trace[(size_t)c0 * EW + x] = tr_lds[FULL ? ((x >> 1) * 64 + lane) * 2 + (x & 1) : x * 64 + lane];
             }
             shw = shn;
         }
     }
     // ---- walk back from (n, m), block by block (uniform block index; every lane walks its own job)
+    AlnRes R;
     int i = n, j = m, tt = t;
     uint32_t mt = 0, cols = 0;
     int dpend = 0;
-    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0);
-    unsigned long long* popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + (size_t)job * P.ncap);
-    const int topblk = (mmax - 1) >> 3;
-    ulonglong2 pre[8];
+    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0), needfull = false;
+    const int topblk = (mmax - 1) >> CSH;
+    unsigned long long pre[CB * EW];
     uint32_t pre_sh = 0, cur_sh = 0;
+    unsigned long long pp = 0ull;          // op bytes of the current group of 8 columns
     if (mmax > 0) {
-        const bool have = act && topblk * 8 < m;
+        const bool have = act && topblk * CB < m;
 #pragma unroll
-        for (int x = 0; x < 8; x++) { pre[x].x = 0; pre[x].y = 0; if (have) pre[x] = trace[topblk * 8 + x]; }
-        pre_sh = have ? jsh[topblk] : 0u;
+        for (int x = 0; x < CB * EW; x++) pre[x] = have ? J.trace[(size_t)topblk * CB * EW + x] : 0ull;
+        pre_sh = have ? J.jsh[(topblk * CB) >> 3] : 0u;
 #pragma unroll
-        for (int x = 0; x < 8; x++) tr_lds[x * 64 + lane] = pre[x];
+        for (int x = 0; x < CB * EW; x++) tr_lds[FULL ? ((x >> 1) * 64 + lane) * 2 + (x & 1) : x * 64 + lane] = pre[x];
         cur_sh = pre_sh;
     }
+    const uint32_t modem = mode ? 0xffu : 0u;
+    bool touched = false;
     for (int blk = topblk; blk >= 0 && mmax > 0; blk--) {
-        if (blk > 0) {                                       // prefetch the next (lower) block into registers
-            const bool have = act && (blk - 1) * 8 < m;
+        if (blk > 0) {
+            const bool have = act && (blk - 1) * CB < m;
 #pragma unroll
-            for (int x = 0; x < 8; x++) if (have) pre[x] = trace[(blk - 1) * 8 + x];
-            pre_sh = have ? jsh[blk - 1] : 0u;
+            for (int x = 0; x < CB * EW; x++) if (have) pre[x] = J.trace[(size_t)(blk - 1) * CB * EW + x];
+            pre_sh = have ? J.jsh[((blk - 1) * CB) >> 3] : 0u;
         }
-        unsigned long long pp = 0ull;
-        bool touched = false;
-        bool go = act && !fail && j > 0 && ((j - 1) >> 3) == blk;
-        const uint32_t modem = mode ? 0xffu : 0u;
+        bool go = act && !fail && !needfull && j > 0 && ((j - 1) >> CSH) == blk;
         while (__ballot(go)) {
-            // one step of every lane's walk, branch-free (lanes outside this block idle under `go`)
-            const int c = (j - 1) & 7;
+            const int c8 = (j - 1) & 7, cb = (j - 1) & (CB - 1);
             const int b = i - tt;
-            const ulonglong2 tw = tr_lds[c * 64 + lane];
-            const int bs = b & 63;
-            int code = (int)((tw.x >> bs) & 1ull) | ((int)((tw.y >> bs) & 1ull) << 1);   // 0 up, 1 left, 2/3 diagonal
+            int code;
+            if (FULL) {
+                const unsigned long long w0 = tr_lds[(cb * 64 + lane) * 2], w1 = tr_lds[(cb * 64 + lane) * 2 + 1];
+                code = (int)((w0 >> (b & 63)) & 1ull) | ((int)((w1 >> (b & 63)) & 1ull) << 1);
+            } else {
+                const unsigned long long e = tr_lds[cb * 64 + lane];
+                const int st = tt > 1 ? 16 : max(0, min(16, (j - 1) - 15));
+                const int bs = (b - st) & 31;
+                code = (int)((e >> bs) & 1ull) | ((int)((e >> (32 + bs)) & 1ull) << 1);
+                needfull |= go && i > 0 && b >= 0 && b <= 63 && (b < st || b > st + 31);
+            }
             code = b > 63 ? 0 : code;                     // virtual cell below the window: up
             code = i == 0 ? 1 : code;                     // row 0: only left
             fail |= go && ((i > 0 && b < 0) || cols > (uint32_t)(n + m));
+            go = go && !needfull;
             const bool up = code == 0, colmove = go && !up;
             const uint32_t g1 = go ? 1u : 0u;
             cols += g1;
             i -= (go && code != 1) ? 1 : 0;
             mt += (go && code == 3) ? 1u : 0u;
             const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
-            pp |= colmove ? (unsigned long long)(opb & modem) << (8 * c) : 0ull;
+            pp |= colmove ? (unsigned long long)(opb & modem) << (8 * c8) : 0ull;
             touched |= colmove;
             dpend = colmove ? 0 : dpend + (int)(g1 & (up ? 1u : 0u));
-            tt -= colmove ? (int)((cur_sh >> (4 * c)) & 15u) : 0;
+            tt -= colmove ? (int)((cur_sh >> (4 * c8)) & 15u) : 0;
             j -= colmove ? 1 : 0;
-            go = go && !fail && j > 0 && ((j - 1) >> 3) == blk;
+            go = go && !fail && j > 0 && ((j - 1) >> CSH) == blk;
         }
-        touched = touched && mode;
-        if (touched) popd8[blk] = pp;
+        // the op bytes of a group of 8 columns are complete when the walk leaves its lowest block
+        if ((FULL ? (blk & 1) == 0 : true)) {
+            if (touched && mode) J.popd8[FULL ? (blk >> 1) : blk] = pp;
+            pp = 0ull; touched = false;
+        }
         if (blk > 0) {
 #pragma unroll
-            for (int x = 0; x < 8; x++) tr_lds[x * 64 + lane] = pre[x];
+            for (int x = 0; x < CB * EW; x++) tr_lds[FULL ? ((x >> 1) * 64 + lane) * 2 + (x & 1) : x * 64 + lane] = pre[x];
             cur_sh = pre_sh;
         }
     }
-    if (act && !fail && i > 0) { cols += (uint32_t)i; i = 0; }   // column 0: only fragment-only moves remain
-    if (act) {
+    if (act && !fail && !needfull && i > 0) { cols += (uint32_t)i; i = 0; }   // column 0: only fragment-only moves remain
+    R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = needfull;
+    return R;
+}
+
+__global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
+    __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
+    const int lane = threadIdx.x;
+    const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;          // wave-aligned ranges of rs ids
+    const uint32_t rng = job / FB.rs;
+    const uint32_t in_rng = FB.job_cnt[rng * 32u];
+    if (in_rng <= (blockIdx.x * 64u) % FB.rs) return;                // whole wave beyond the range's job count
+    AlnJob J;
+    J.act = job < n_jobs && (job % FB.rs) < in_rng;
+    uint32_t r = 0;
+    J.p0 = 0; J.n = 0; J.m = 0; J.mode = 0;
+    if (J.act) {
+        const uint32_t* meta = FB.job_meta + 4ull * job;
+        r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
+    }
+    J.fl = FB.st_fplanes + (size_t)r * 2 * FB.fw; J.fh = J.fl + FB.fw;
+    J.nl = FB.job_n + (size_t)job * 2 * FB.nw; J.nh = J.nl + FB.nw;
+    J.jsh = FB.job_sh + (size_t)job * FB.shw;
+    J.trace = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)job * (size_t)(P.ncap + 16) * 2;
+    J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + (size_t)job * P.ncap);
+    int mmax = J.m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
+    AlnRes R = aln_pass<false>(J, J.act, mmax, lane, tr_lds);
+    if (__ballot(R.needfull)) {
+        const bool redo = J.act && R.needfull;
+        int mm2 = redo ? J.m : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
+        const AlnRes R2 = aln_pass<true>(J, redo, mm2, lane, tr_lds);
+        if (redo) R = R2;
+    }
+    if (J.act) {
         uint32_t* res = FB.aln_res + 4ull * r;
-        res[0] = mt; res[1] = cols; res[2] = fail ? 1u : 0u;
+        res[0] = R.mt; res[1] = R.cols; res[2] = (R.fail || R.needfull) ? 1u : 0u;
     }
 }
 
