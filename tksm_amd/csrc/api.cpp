@@ -664,6 +664,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         {
             unsigned long long pr[16];
             HIPCHK(ctx, hipMemcpy(pr, ctx->f_prof.p, 128, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[prof] aln: waves %llu, waves with a full-width redo %llu, jobs redone %llu\n", pr[15], pr[14], pr[13]);
             fprintf(stderr, "[prof] rounds=%u slow=%u | per loop-invocation (n=%llu) cycles: load %.0f gen %.0f eval %.0f seq %.0f join %.0f job %.0f store %.0f total %.0f | final (n=%llu): join %.0f lookups %.0f total %.0f\n", rounds, cnt[2], pr[10], (double)pr[0] / (pr[10] + pr[12] + 1), (double)pr[1] / (pr[10] + 1), (double)pr[2] / (pr[10] + 1), (double)pr[3] / (pr[10] + 1), (double)pr[4] / (pr[10] + 1), (double)pr[5] / (pr[10] + 1), (double)pr[6] / (pr[10] + 1), (double)pr[9] / (pr[10] + 1), pr[12], (double)pr[7] / (pr[12] + 1), (double)pr[8] / (pr[12] + 1), (double)pr[11] / (pr[12] + 1));
         }
 #endif

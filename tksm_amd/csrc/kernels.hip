@@ -1233,6 +1233,8 @@ struct AlnJob {
     const unsigned long long *fl, *fh, *nl, *nh;
     const uint32_t* jsh;
     unsigned long long* trace;   // per-job region of (ncap + 16) 16-byte columns
+    unsigned long long* trace0;  // region of the wave's first job
+    size_t tstride;              // u64 words between consecutive jobs
     unsigned long long* popd8;
 };
 struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
@@ -1295,15 +1297,31 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             }
         }
         if ((c & (CB - 1)) == CB - 1 || c == mmax - 1) {
+            wave_sync();
             // the next shift word is requested BEFORE the stores: gfx9 counts stores in vmcnt, in issue order
             uint32_t shn = shw;
             if ((c & 7) == 7 || c == mmax - 1) shn = (act && c + 1 < m) ? J.jsh[(c + 1) >> 3] : 0u;
             const int c0 = c & ~(CB - 1);
-            if (act && c0 < m) {
+            if (FULL) {
+                if (act && c0 < m) {
 #pragma unroll
-                for (int x = 0; x < CB * EW; x++) J.trace[(size_t)c0 * EW + x] = tr_lds[FULL ? ((x >> 1) * 64 + lane) * 2 + (x & 1) : x * 64 + lane];
+                    for (int x = 0; x < CB * EW; x++) J.trace[(size_t)c0 * EW + x] = tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)];
+                }
+            } else {
+                // 64 bytes per job, written as whole lines: 4 threads cover one job's 8 columns (transpose through LDS)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int jl = q * 16 + (lane >> 2), part = lane & 3;
+                    const int mj = __shfl(act ? m : 0, jl, 64);
+                    if (c0 < mj) {
+                        ulonglong2 v;
+                        v.x = tr_lds[(2 * part) * 64 + jl]; v.y = tr_lds[(2 * part + 1) * 64 + jl];
+                        *reinterpret_cast<ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)c0 + 2 * part) = v;
+                    }
+                }
             }
             shw = shn;
+            wave_sync();
         }
     }
     // ---- walk back from (n, m), block by block (uniform block index; every lane walks its own job)
@@ -1316,24 +1334,42 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
     unsigned long long pre[CB * EW];
     uint32_t pre_sh = 0, cur_sh = 0;
     unsigned long long pp = 0ull;          // op bytes of the current group of 8 columns
-    if (mmax > 0) {
-        const bool have = act && topblk * CB < m;
+    // block loads / LDS fills: FULL per lane; otherwise whole 64-byte lines, 4 threads per job (transposed in LDS)
+    auto load_block = [&](int blk2) {
+        if (FULL) {
+            const bool have = act && blk2 * CB < m;
 #pragma unroll
-        for (int x = 0; x < CB * EW; x++) pre[x] = have ? J.trace[(size_t)topblk * CB * EW + x] : 0ull;
-        pre_sh = have ? J.jsh[(topblk * CB) >> 3] : 0u;
+            for (int x = 0; x < CB * EW; x++) pre[x] = have ? J.trace[(size_t)blk2 * CB * EW + x] : 0ull;
+        } else {
 #pragma unroll
-        for (int x = 0; x < CB * EW; x++) tr_lds[FULL ? ((x >> 1) * 64 + lane) * 2 + (x & 1) : x * 64 + lane] = pre[x];
+            for (int q = 0; q < 4; q++) {
+                const int jl = q * 16 + (lane >> 2), part = lane & 3;
+                const int mj = __shfl(act ? m : 0, jl, 64);
+                ulonglong2 v; v.x = 0ull; v.y = 0ull;
+                if (blk2 * CB < mj) v = *reinterpret_cast<const ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)blk2 * CB + 2 * part);
+                pre[2 * q] = v.x; pre[2 * q + 1] = v.y;
+            }
+        }
+        pre_sh = (act && blk2 * CB < m) ? J.jsh[(blk2 * CB) >> 3] : 0u;
+    };
+    auto fill_lds = [&]() {
+        if (FULL) {
+#pragma unroll
+            for (int x = 0; x < CB * EW; x++) tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)] = pre[x];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int jl = q * 16 + (lane >> 2), part = lane & 3;
+                tr_lds[(2 * part) * 64 + jl] = pre[2 * q]; tr_lds[(2 * part + 1) * 64 + jl] = pre[2 * q + 1];
+            }
+        }
         cur_sh = pre_sh;
-    }
+    };
+    if (mmax > 0) { load_block(topblk); fill_lds(); wave_sync(); }
     const uint32_t modem = mode ? 0xffu : 0u;
     bool touched = false;
     for (int blk = topblk; blk >= 0 && mmax > 0; blk--) {
-        if (blk > 0) {
-            const bool have = act && (blk - 1) * CB < m;
-#pragma unroll
-            for (int x = 0; x < CB * EW; x++) if (have) pre[x] = J.trace[(size_t)(blk - 1) * CB * EW + x];
-            pre_sh = have ? J.jsh[((blk - 1) * CB) >> 3] : 0u;
-        }
+        if (blk > 0) load_block(blk - 1);
         bool go = act && !fail && !needfull && j > 0 && ((j - 1) >> CSH) == blk;
         while (__ballot(go)) {
             const int c8 = (j - 1) & 7, cb = (j - 1) & (CB - 1);
@@ -1371,11 +1407,7 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             if (touched && mode) J.popd8[FULL ? (blk >> 1) : blk] = pp;
             pp = 0ull; touched = false;
         }
-        if (blk > 0) {
-#pragma unroll
-            for (int x = 0; x < CB * EW; x++) tr_lds[FULL ? ((x >> 1) * 64 + lane) * 2 + (x & 1) : x * 64 + lane] = pre[x];
-            cur_sh = pre_sh;
-        }
+        if (blk > 0) { wave_sync(); fill_lds(); wave_sync(); }
     }
     if (act && !fail && !needfull && i > 0) { cols += (uint32_t)i; i = 0; }   // column 0: only fragment-only moves remain
     R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = needfull;
@@ -1400,13 +1432,21 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     J.fl = FB.st_fplanes + (size_t)r * 2 * FB.fw; J.fh = J.fl + FB.fw;
     J.nl = FB.job_n + (size_t)job * 2 * FB.nw; J.nh = J.nl + FB.nw;
     J.jsh = FB.job_sh + (size_t)job * FB.shw;
-    J.trace = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)job * (size_t)(P.ncap + 16) * 2;
+    J.tstride = (size_t)(P.ncap + 16) * 2;
+    J.trace = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)job * J.tstride;
+    J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)(blockIdx.x * 64u) * J.tstride;
     J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + (size_t)job * P.ncap);
     int mmax = J.m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
+#ifdef TKSM_PROF
+    if (lane == 0) atomicAdd(&FB.prof[15], 1ull);
+#endif
     AlnRes R = aln_pass<false>(J, J.act, mmax, lane, tr_lds);
     if (__ballot(R.needfull)) {
+#ifdef TKSM_PROF
+        if (lane == 0) { atomicAdd(&FB.prof[13], (unsigned long long)__popcll(__ballot(R.needfull))); atomicAdd(&FB.prof[14], 1ull); }
+#endif
         const bool redo = J.act && R.needfull;
         int mm2 = redo ? J.m : 0;
 #pragma unroll
