@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# torch bundles its own ROCm runtime: it has to be loaded before libtksmseq.so (as in bench.py), otherwise torch finds
+# no device in a process that already loaded the system libamdhip64 through our library
+import torch  # noqa: E402,F401
+
+torch.cuda.is_available()
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -159,3 +159,95 @@ def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n
         assert dst[i, 1] == st.target_identity and dst[i, 0] == st.errors
         assert recs[i] == want, (i, mid)
     s.close()
+
+
+def test_cli_end_to_end_matches_goldens_and_oracle(tmp_path, po, oracle_models):
+    """`tksm sequence` (the module boundary) on files: --perfect vs the reference CLI golden; -o vs the oracle with
+    the CLI's seed; both outputs at once reproduce the reference's quirk (perfect file = badread sequence, quals K)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    d = os.path.join(GOLDEN, "splice_corpus")
+    out = tmp_path / "perfect.fastq"
+    r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "--perfect", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _normalize(out.read_text()) == open(os.path.join(d, "expected_perfect.fastq")).read()
+    # small batches (--batch-bytes) exercise the chunked MDF reader; read ids continue across chunks
+    bad, bad2, per2 = tmp_path / "bad.fq.gz", tmp_path / "bad2.fastq", tmp_path / "per2.fasta"
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", str(bad),
+                        "-s", "7", "--batch-bytes", "4096"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    import gzip
+    got = gzip.open(bad, "rb").read()
+    ref = po.get_reference_seqs([os.path.join(d, "ref.fa")])
+    from tksm_amd.sequence import Sequencer
+    s = Sequencer(0)
+    s.set_identity(84.0, 99.0, 5.5)
+    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    s.close()
+    want = []
+    with open(os.path.join(d, "mols.mdf")) as f:
+        for i, (mid, ivs) in enumerate(po.mdf_generator(f)):
+            want.append(po.badread_record(True, 7, i, po.splice(ref, ivs), ident, oracle_models["em"], oracle_models["qm"], True, mid)[0])
+    assert got == b"".join(want)
+    r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", str(bad2),
+                        "--perfect", str(per2), "-s", "7", "--skip-qual-compute"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    b2 = bad2.read_bytes().split(b"\n")
+    p2 = per2.read_bytes().split(b"\n")
+    assert b2[1::4][: len(p2[1::2])] == p2[1::2]                       # same (badread) sequences in the "perfect" file
+    assert all(b"read_identity=100.00%" in h for h in p2[0::2] if h)
+
+
+def test_full_size_properties_and_shard_invariance():
+    """size-independent properties at a bench-like size (131072 reads of ~1 kb): record structure, determinism, and
+    rank-count invariance -- two round-robin shards interleaved on the device equal the single-GPU stream."""
+    import torch
+    from tksm_amd import synthetic
+    from tksm_amd.sequence import Sequencer
+    s = Sequencer(0)
+    rs = np.random.RandomState(11)
+    lens = [4_000_000] * 4
+    for c, n in enumerate(lens):
+        s.add_contig(f"chr{c + 1}", rs.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes())
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    n = 131072
+    m = synthetic.make_molecules(rs, lens, n, 1000, 200)
+    b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+    rec1, off1 = s.run(b, seed=5).download()
+    rec2, _ = s.run(b, seed=5).download()
+    assert rec1 == rec2                                                   # deterministic
+    assert len(off1) == n + 1 and int(off1[-1]) == len(rec1)
+    lines = rec1.split(b"\n")
+    assert len(lines) == 4 * n + 1
+    hdr, seq, plus, qual = lines[0:-1:4], lines[1::4], lines[2::4], lines[3::4]
+    assert all(p == b"+" for p in plus[:: 97])
+    for k in range(0, n, 257):
+        f = dict(x.split(b"=") for x in hdr[k].split(b" ")[1:])
+        assert int(f[b"length"]) == len(seq[k]) == len(qual[k])
+        assert int(f[b"error_free_length"]) == int(m["raw_len"][k])
+        assert f[b"molecule_id"] == f"mol_{k}".encode() and 50.0 < float(f[b"read_identity"][:-1]) <= 100.0
+        assert set(seq[k]) <= set(b"ACGT") and min(qual[k]) >= 33
+    total_in = int(m["raw_len"].sum())
+    total_out = sum(len(x) for x in seq)
+    assert 0.93 < total_out / total_in < 0.97                             # nanopore2020: reads ~0.95 x the molecule
+    # two shards (global read g -> rank g mod 2), interleaved back on the device
+    parts = []
+    for rank in range(2):
+        sel = np.arange(rank, n, 2)
+        # mods of the selected reads must stay contiguous per interval: rebuild the shard from the text form
+        text = synthetic.mdf_text({**m, "reads": m["reads"][sel], "ids": m["ids"][sel]}, [f"chr{c + 1}" for c in range(4)])
+        sb = s.batch_from_mdf(text)
+        res = s.run(sb, seed=5, first_read_index=rank, stride=2)
+        rec, off = res.download()
+        parts.append((torch.tensor(list(rec), dtype=torch.uint8, device="cuda") if len(rec) < 1 else
+                      torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(sel)))
+    dst = torch.empty(len(rec1) + 64, dtype=torch.uint8, device="cuda")
+    nbytes = s.interleave_records([p[0].data_ptr() for p in parts], [p[1].data_ptr() for p in parts], [p[2] for p in parts],
+                                  dst.data_ptr(), dst.numel())
+    assert nbytes == len(rec1) and bytes(dst[:nbytes].cpu().numpy().tobytes()) == rec1
+    s.close()

@@ -1250,6 +1250,8 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1, fbase = -1;
     unsigned long long fl0 = 0, fl1 = 0, fl2 = 0, fl3 = 0, fh0 = 0, fh1 = 0, fh2 = 0, fh3 = 0, nlo = 0, nhi = 0;
+    unsigned long long flo0 = 0, flo1 = 0, fhi0 = 0, fhi1 = 0;
+    int kxc = -1;
     uint32_t shw = (act && m > 0) ? J.jsh[0] : 0u;
     for (int c = 0; c < mmax; c++) {
         if ((c & 7) == 0 && act && c < m) {
@@ -1258,6 +1260,7 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
                 fbase = nbase;
                 fl0 = J.fl[nbase]; fl1 = J.fl[nbase + 1]; fl2 = J.fl[nbase + 2]; fl3 = J.fl[nbase + 3];
                 fh0 = J.fh[nbase]; fh1 = J.fh[nbase + 1]; fh2 = J.fh[nbase + 2]; fh3 = J.fh[nbase + 3];
+                kxc = -1;
             }
         }
         if (act && c < m) {
@@ -1266,10 +1269,14 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             if (sh) { Pv = (Pv >> sh) | (~0ull << (64 - sh)); Mv >>= sh; }
             else if (t > 1) { Pv &= ~1ull; Mv |= 1ull; }
             const int o = p0 + t - 1, kx = (o >> 6) - fbase, s = o & 63;
-            const unsigned long long flo0 = kx == 0 ? fl0 : (kx == 1 ? fl1 : fl2), flo1 = kx == 0 ? fl1 : (kx == 1 ? fl2 : fl3);
-            const unsigned long long fhi0 = kx == 0 ? fh0 : (kx == 1 ? fh1 : fh2), fhi1 = kx == 0 ? fh1 : (kx == 1 ? fh2 : fh3);
-            const unsigned long long lo = s ? (flo0 >> s) | (flo1 << (64 - s)) : flo0;
-            const unsigned long long hi = s ? (fhi0 >> s) | (fhi1 << (64 - s)) : fhi0;
+            if (kx != kxc) {                                  // word pair changes only every ~64 columns
+                kxc = kx;
+                flo0 = kx == 0 ? fl0 : (kx == 1 ? fl1 : fl2); flo1 = kx == 0 ? fl1 : (kx == 1 ? fl2 : fl3);
+                fhi0 = kx == 0 ? fh0 : (kx == 1 ? fh1 : fh2); fhi1 = kx == 0 ? fh1 : (kx == 1 ? fh2 : fh3);
+            }
+            // 64-bit funnel shift; s == 0 needs no special case: (x << 1) << 63 drops out
+            const unsigned long long lo = (flo0 >> s) | ((flo1 << 1) << (63 - s));
+            const unsigned long long hi = (fhi0 >> s) | ((fhi1 << 1) << (63 - s));
             if ((c & 63) == 0) { nlo = J.nl[c >> 6]; nhi = J.nh[c >> 6]; }
             const unsigned long long cl = 0ull - ((nlo >> (c & 63)) & 1ull), ch = 0ull - ((nhi >> (c & 63)) & 1ull);
             // rows below the fragment window (i > n) are not masked: they never feed a row above them
