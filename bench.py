@@ -4,8 +4,8 @@
 A "step" = one pass of the hot path (splice -> Badread errors -> q-scores -> FASTQ records) over one batch of
 synthetic molecules with inputs resident in HBM.  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
 Badread error+qual model" -- synthetic 24 x 128 Mb genome (GRCh38 is not available offline), nanopore2020 error +
-q-score models, identity 84,99,5.5, FASTQ with computed qualities; the 10 M molecules are processed as steps of
---batch molecules each (default steps x batch is smaller so the default run finishes in minutes).
+q-score models, identity 84,99,5.5, FASTQ with computed qualities; the 10 M molecules are processed as 5 steps of
+--batch = 2,097,152 molecules each (the default run).
 
 N>1 (torchrun, one rank per GPU): molecules are sharded round-robin (global read g -> rank g mod P, counter-based
 RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RCCL gather of the per-rank record
@@ -84,9 +84,9 @@ def cpu_baseline(n_reads, mean_len, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1048576, help="molecules per GPU per step")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=2097152, help="molecules per GPU per step")
     ap.add_argument("--mean-len", type=int, default=1000)
     ap.add_argument("--genome-contigs", type=int, default=24)
     ap.add_argument("--contig-mb", type=int, default=128)

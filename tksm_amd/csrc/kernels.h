@@ -94,7 +94,9 @@ struct ReadState {
     uint8_t pending, slow, pad;
     int32_t st_draws, st_aligns;
     uint32_t job;
-    int32_t pad2;
+    int32_t raw_len;
+    // result of the read's last alignment, written by k_aln: one record load brings everything k_err needs
+    uint32_t res_mt, res_cols, res_fail, pad3;
 };
 
 struct FastBuffers {

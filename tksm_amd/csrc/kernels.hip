@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
         ReadState S;
         S.errors = 0.0; S.target = target; S.est = 0.0; S.change_count = 0; S.n_base = 0; S.aln_no = 0;
         S.resume_src = -1; S.resume_j = 0; S.stage = 0; S.pending = 0; S.slow = slow ? 1 : 0; S.pad = 0;
-        S.st_draws = 0; S.st_aligns = 0; S.job = 0; S.pad2 = 0;
+        S.st_draws = 0; S.st_aligns = 0; S.job = 0; S.raw_len = raw_len; S.res_mt = 0; S.res_cols = 0; S.res_fail = 0; S.pad3 = 0;
         FB.state[r] = S;
         O.status[r] |= status;
         if (slow) { const uint32_t idx = atomicAdd(&FB.counters[2], 1u); FB.slow_list[idx] = (uint32_t)r; }
@@ -917,16 +917,18 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     uint8_t* popd = aux;
     const int k = EM.k;
     const uint64_t g = P.first_read + r * P.stride;
-    const int raw_len = (int)O.raw_len[r];
+    const int raw_len = S.raw_len;
     const int L = raw_len + 2 * k;
     const uint64_t slot = O.slot_off[r];
     const int cap = (int)((O.slot_off[r + 1] - slot) >> 1);
     uint8_t* out_seq = O.scratch + slot;
     uint8_t* out_qual = out_seq + cap;
-    uint8_t* gfrag = FB.st_frag + r * (size_t)P.lcap;
     uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
-    for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag + t);
-    for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
+    {
+        const uint8_t* gfrag0 = FB.st_frag + r * (size_t)P.lcap;
+        for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag0 + t);
+        for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
+    }
     wave_sync();
     PROF_T(t_loaded); PROF_ADD(0, t_begin, t_loaded);
     uint32_t status = 0;
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (S.stage == 0) {
         bool resume = S.resume_src >= 0;
         if (S.pending) {                                   // apply the re-estimation result (py/tksm_badread.py:412-432)
-            const uint32_t mt = FB.aln_res[4 * r], cols = FB.aln_res[4 * r + 1], fail = FB.aln_res[4 * r + 2];
+            const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
             if (fail) { go_slow(FB, r, lane); return; }
             const double ident = cols ? (double)mt / (double)cols : 0.0;
             if (L <= 1000) errors = (1.0 - ident) * frag_len;
@@ -1147,7 +1149,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     PROF_T(t_f1); PROF_ADD(7, t_f0, t_f1);
     if (want_q) {
         // ---- S5 q-scores from the alignment k_aln left in job_popd (py/tksm_badread.py:607-655)
-        const uint32_t mt = FB.aln_res[4 * r], cols = FB.aln_res[4 * r + 1], fail = FB.aln_res[4 * r + 2];
+        const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
         if (fail) { go_slow(FB, r, lane); return; }
         identity = cols ? (double)mt / (double)cols : 0.0;
         const uint8_t* gp = FB.job_popd + (size_t)S.job * P.ncap;
@@ -1462,8 +1464,8 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         if (redo) R = R2;
     }
     if (J.act) {
-        uint32_t* res = FB.aln_res + 4ull * r;
-        res[0] = R.mt; res[1] = R.cols; res[2] = (R.fail || R.needfull) ? 1u : 0u;
+        ReadState* st = FB.state + r;
+        st->res_mt = R.mt; st->res_cols = R.cols; st->res_fail = (R.fail || R.needfull) ? 1u : 0u;
     }
 }
 
