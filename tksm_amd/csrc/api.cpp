@@ -272,8 +272,8 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
         for (size_t i = 0; i < nk; i++) for (size_t a = 0; a < A; a++) c32[i * 32 + a] = ctx->em.cdf[i * A + a];
         if (ctx->em.type == 0) std::fill(c32.begin(), c32.end(), 0u);
         if ((rc = upload(ctx, ctx->d_cdf32, c32))) return rc;
-        std::vector<uint32_t> ps(nk);
-        for (size_t i = 0; i < nk; i++) ps[i] = c32[i * 32];
+        std::vector<uint32_t> ps(nk * 2);
+        for (size_t i = 0; i < nk; i++) { ps[2 * i] = c32[i * 32]; ps[2 * i + 1] = ctx->em.nalts[i] ? c32[i * 32 + ctx->em.nalts[i] - 1] : 0u; }
         if ((rc = upload(ctx, ctx->d_pself, ps))) return rc;
     }
     if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
@@ -529,7 +529,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), n, (uint32_t)b->n_literals};
     tk::RefView R{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
                   ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint32_t>(), ctx->d_cdf32.as<uint32_t>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
                        ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>()};

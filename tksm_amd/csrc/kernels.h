@@ -35,7 +35,7 @@ struct ErrModelView {
     const uint32_t* cdf;
     const uint64_t* alts;
     const uint8_t* nalts;
-    const uint32_t* pself;  // [4^k] first threshold of every row (cache-resident)
+    const uint2* pself2;    // [4^k] {first, last} threshold of every row (cache-resident, 128 KB)
     const uint32_t* cdf32;  // [4^k][32] the same thresholds padded to 128-byte rows (max_alts <= 32 only)
 };
 

@@ -610,19 +610,30 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
 // first alternative a with w < cdf[a] (cumulative, non-decreasing), or na if none.  Device rows are padded to
 // 32 thresholds (128 B, filled with 0xffffffff): ~81 % of the draws are settled by the first threshold alone
 // (the k-mer itself), only the rest fetch the row, with independent 16-byte loads.
-DEV int cdf_pick(const uint32_t* cdf32, uint32_t pself, int na, uint32_t w) {
-    if (w < pself) return 0;
+DEV int cdf_pick(const uint32_t* cdf32, uint32_t pself, uint32_t ptot, int na, uint32_t w) {
+    if (w < pself) return 0;                 // the k-mer itself
+    if (!(w < ptot)) return na;              // residual mass: random change
     const uint4* c4 = reinterpret_cast<const uint4*>(cdf32);
-    uint4 v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = c4[q];
     int a = 0;
+    {
+        uint4 v[4];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        a += (4 * q < na && !(w < v[q].x)) ? 1 : 0; a += (4 * q + 1 < na && !(w < v[q].y)) ? 1 : 0;
-        a += (4 * q + 2 < na && !(w < v[q].z)) ? 1 : 0; a += (4 * q + 3 < na && !(w < v[q].w)) ? 1 : 0;
+        for (int q = 0; q < 4; q++) v[q] = c4[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a += !(w < v[q].x) ? 1 : 0; a += !(w < v[q].y) ? 1 : 0; a += !(w < v[q].z) ? 1 : 0; a += !(w < v[q].w) ? 1 : 0;
+        }
     }
-    return a;
+    if (a == 16) {                           // beyond the 16 most likely alternatives: second half of the row
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = c4[4 + q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a += !(w < v[q].x) ? 1 : 0; a += !(w < v[q].y) ? 1 : 0; a += !(w < v[q].z) ? 1 : 0; a += !(w < v[q].w) ? 1 : 0;
+        }
+    }
+    return min(a, na);
 }
 
 DEV void go_slow(const FastBuffers& FB, uint64_t r, int lane) {
@@ -974,7 +985,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 else {
                     const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
                     // the first threshold (the k-mer itself, ~81 % of all draws) comes from a compact 64 KB array
-                    const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, EM.pself[kidx], na, d.y);
+                    const uint2 pp2 = EM.pself2[kidx];   // {first threshold, last threshold}
+                    const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, pp2.x, pp2.y, na, d.y);
                     if (a == na) kind = 2;
                     else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
                 }
