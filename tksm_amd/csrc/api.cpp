@@ -92,9 +92,9 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow, f_jobcnt, f_prof;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow, f_jobcnt, f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
-    uint32_t tail_cut = 1024;
+    uint32_t tail_cut = 2048;
     uint32_t n_buckets = 16;
     std::vector<hipEvent_t> evpool;
     uint32_t last_rounds = 0, last_slow = 0;
@@ -588,6 +588,10 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         FB.job_cnt = ctx->f_jobcnt.as<uint32_t>();
+        HIPCHK(ctx, ctx->f_svi.ensure(n * 128 + 64));
+        HIPCHK(ctx, ctx->f_svk.ensure(n * 64 + 64));
+        HIPCHK(ctx, ctx->f_sva.ensure(n * 512 + 64));
+        FB.sv_i = ctx->f_svi.as<uint16_t>(); FB.sv_kind = ctx->f_svk.as<uint8_t>(); FB.sv_alt = ctx->f_sva.as<unsigned long long>();
         HIPCHK(ctx, ctx->f_prof.ensure(256));
         FB.prof = ctx->f_prof.as<unsigned long long>();
 #ifdef TKSM_PROF

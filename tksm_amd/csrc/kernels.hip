@@ -935,6 +935,11 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     uint8_t* out_seq = O.scratch + slot;
     uint8_t* out_qual = out_seq + cap;
     uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
+    // the draws of the round that was interrupted by the re-estimation come back with the state (no regeneration)
+    int sv_i = 0, sv_kind = 0; uint64_t sv_alt = 0;
+    if (S.stage == 0 && S.resume_src >= 0) {
+        sv_i = FB.sv_i[r * 64 + lane]; sv_kind = FB.sv_kind[r * 64 + lane]; sv_alt = FB.sv_alt[r * 64 + lane];
+    }
     {
         const uint8_t* gfrag0 = FB.st_frag + r * (size_t)P.lcap;
         for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag0 + t);
@@ -968,16 +973,19 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const long long loop_limit = 100ll * L;
         bool done = false, need_aln = false;
         int r_src = 0, r_j = 0; double r_est = 0.0;
+        int cur_i = 0, cur_kind = 0; uint64_t cur_alt = 0;
         if (!resume && !S.pending)
             if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
         while (!done && !need_aln) {
             PROF_T(t_r0);
             const uint32_t n = n_base + (uint32_t)lane;
             const bool live = (long long)n + 1 <= loop_limit;
-            const Ph4 d = philox(P.seed, g, ST_DRAW, n);
-            const int i = (int)__umulhi(d.x, (uint32_t)(max_kmer_index + 1));
-            int kind = 0;
+            int i, kind = 0;
             uint64_t alt = 0;
+            if (resume) { i = sv_i; kind = sv_kind; alt = sv_alt; }
+            else {
+            const Ph4 d = philox(P.seed, g, ST_DRAW, n);
+            i = (int)__umulhi(d.x, (uint32_t)(max_kmer_index + 1));
             if (live) {
                 int kidx = 0; bool valid = true;
                 for (int jj = 0; jj < k; jj++) { const int cc = code_of(frag[i + jj]); valid &= cc >= 0; kidx = (kidx << 2) | (cc & 3); }
@@ -997,7 +1005,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                     alt = type | (pos << 2) | (base4 << 8) | (side << 10) | (r3 << 12);
                 }
             }
+            }
             PROF_T(t_r1); PROF_ADD(1, t_r0, t_r1);
+            cur_i = i; cur_kind = kind; cur_alt = alt;
             unsigned long long mask = __ballot(live && kind != 0);
             const unsigned long long dead = __ballot(!live);
             if (resume) mask &= ~((1ull << S.resume_src) - 1ull);
@@ -1117,6 +1127,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             PROF_T(t_j2); PROF_ADD(5, t_j1, t_j2);
             if (job >> 31) { go_slow(FB, r, lane); return; }
             for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
+            FB.sv_i[r * 64 + lane] = (uint16_t)cur_i; FB.sv_kind[r * 64 + lane] = (uint8_t)cur_kind; FB.sv_alt[r * 64 + lane] = cur_alt;
             if (lane == 0) {
                 S.errors = errors; S.est = r_est; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
                 S.resume_src = (int16_t)r_src; S.resume_j = (int16_t)r_j; S.pending = 1; S.stage = 0;
