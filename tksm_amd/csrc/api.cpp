@@ -85,14 +85,14 @@ struct tksmseq_ctx : ContigLookup {
 
     // models
     ErrorModelHost em; QScoreModelHost qm; IdentityHost idm;
-    bool em_uniform = false;
+    bool em_uniform = false, em_alt0 = false;
     DevBuf d_pself, d_cdf32, d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta, f_jn, f_jsh, f_jpopd, f_res, f_trace, f_counters, f_slow, f_jobcnt, f_prof, f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jn[2], f_jsh[2], f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 2048;
     uint32_t n_buckets = 16;
@@ -261,6 +261,9 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
     ErrorModelHost m;
     if (!load_error_model(name_or_path, m, ctx->err)) return TKSMSEQ_EIO;
     ctx->em = std::move(m);
+    ctx->em_alt0 = ctx->em.type == 1;
+    for (size_t i = 0; i < ctx->em.nalts.size() && ctx->em_alt0; i++)
+        if (ctx->em.nalts[i] && !(ctx->em.alts[i * (size_t)ctx->em.max_alts] >> 63)) ctx->em_alt0 = false;
     ctx->em_uniform = ctx->em.type == 1;
     for (uint8_t v : ctx->em.nalts) if ((int)v != ctx->em.max_alts) { ctx->em_uniform = false; break; }
     int rc;
@@ -529,7 +532,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), n, (uint32_t)b->n_literals};
     tk::RefView R{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
                   ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
                        ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>()};
@@ -539,6 +542,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     P.mode = badread ? 1 : 0; P.fastq = p->fastq ? 1 : 0;
     P.quirk_perfect = (badread && p->perfect_of_badread) ? 1 : 0;
     P.compute_q = (badread && p->compute_qual && p->fastq && !P.quirk_perfect) ? 1 : 0;
+    P.ablate = getenv("TKSMSEQ_ABLATE") ? atoi(getenv("TKSMSEQ_ABLATE")) : 0;
     P.lcap = lcap; P.ncap = ncap; P.trace_words = trace_words; P.cap_num = cap_num; P.cap_den = cap_den; P.cap_add = cap_add;
     tk::SimBuffers O{};
     O.raw_len = ctx->w_rawlen.as<uint32_t>(); O.slot_off = ctx->w_slotoff.as<uint64_t>(); O.scratch = ctx->w_scratch.as<uint8_t>();
@@ -573,21 +577,31 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_frag.ensure(n * (size_t)lcap + 64));
         HIPCHK(ctx, ctx->f_nb.ensure(n * (size_t)lcap * 2 + 64));
         HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
-        HIPCHK(ctx, ctx->f_jmeta.ensure(jcap * 16 + 64));
-        HIPCHK(ctx, ctx->f_jn.ensure(jcap * (size_t)FB.nw * 16 + 64));
-        HIPCHK(ctx, ctx->f_jsh.ensure(jcap * (size_t)FB.shw * 4 + 64));
-        HIPCHK(ctx, ctx->f_jpopd.ensure(jcap * (size_t)ncap + 64));
+        for (int z = 0; z < 2; z++) {
+            HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
+            HIPCHK(ctx, ctx->f_jn[z].ensure(jcap * (size_t)FB.nw * 16 + 64));
+            HIPCHK(ctx, ctx->f_jsh[z].ensure(jcap * (size_t)FB.shw * 4 + 64));
+            HIPCHK(ctx, ctx->f_jpopd[z].ensure(jcap * (size_t)ncap + 64));
+            HIPCHK(ctx, ctx->f_jobcnt[z].ensure((size_t)FB.n_ranges * 128 + 64));
+        }
+        HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 4 + 64));
         HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
         HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(64));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
-        HIPCHK(ctx, ctx->f_jobcnt.ensure((size_t)FB.n_ranges * 128 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
-        FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.job_meta = ctx->f_jmeta.as<uint32_t>();
-        FB.job_n = ctx->f_jn.as<unsigned long long>(); FB.job_sh = ctx->f_jsh.as<uint32_t>(); FB.job_popd = ctx->f_jpopd.as<uint8_t>();
+        FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
         FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
-        FB.job_cnt = ctx->f_jobcnt.as<uint32_t>();
+        FB.prefix = ctx->f_prefix.as<uint32_t>();
+        auto select_set = [&](uint32_t round) {
+            const int z = round & 1, y = z ^ 1;
+            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_n = ctx->f_jn[z].as<unsigned long long>();
+            FB.job_sh = ctx->f_jsh[z].as<uint32_t>(); FB.job_popd = ctx->f_jpopd[z].as<uint8_t>(); FB.job_cnt = ctx->f_jobcnt[z].as<uint32_t>();
+            FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[y].as<uint8_t>();
+        };
+        select_set(0);
+        std::vector<uint32_t> hprefix(FB.n_ranges + 1, 0);
         HIPCHK(ctx, ctx->f_svi.ensure(n * 128 + 64));
         HIPCHK(ctx, ctx->f_svk.ensure(n * 64 + 64));
         HIPCHK(ctx, ctx->f_sva.ensure(n * 512 + 64));
@@ -635,18 +649,41 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         uint32_t cnt[4] = {0, 0, 0, 0};
         uint32_t rounds = 0;
         for (;; rounds++) {
-            HIPCHK(ctx, hipMemsetAsync(ctx->f_jobcnt.p, 0, (size_t)FB.n_ranges * 128, s));
+            select_set(rounds);
+            HIPCHK(ctx, hipMemsetAsync((void*)FB.job_cnt, 0, (size_t)FB.n_ranges * 128, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            for (const Bucket& bk : buckets)
-                HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, bk.wpw, s));
+            if (rounds == 0) {
+                for (const Bucket& bk : buckets)
+                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, 0, 0, 0, bk.wpw, s));
+            } else {
+                // one wave per job of the previous round; ranges are chunks of the sorted order, so a bucket is a run of ranges
+                size_t bi = 0;
+                uint32_t c = 0;
+                while (c < FB.n_ranges) {
+                    const uint32_t last_pos = (uint32_t)std::min<uint64_t>((uint64_t)(c + 1) * FB.rs, n) - 1;
+                    while (bi + 1 < buckets.size() && last_pos >= buckets[bi].begin + buckets[bi].count) bi++;
+                    uint32_t c1 = c + 1;
+                    while (c1 < FB.n_ranges) {
+                        const uint32_t lp = (uint32_t)std::min<uint64_t>((uint64_t)(c1 + 1) * FB.rs, n) - 1;
+                        if (lp >= buckets[bi].begin + buckets[bi].count) break;
+                        c1++;
+                    }
+                    const uint32_t cntw = hprefix[c1] - hprefix[c];
+                    if (cntw)
+                        HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, buckets[bi].ncap, 1, c, c1, buckets[bi].wpw, s));
+                    c = c1;
+                }
+            }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(1);
             HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
-            HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), ctx->f_jobcnt.p, (size_t)FB.n_ranges * 128, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), (const void*)FB.job_cnt, (size_t)FB.n_ranges * 128, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
             cnt[0] = 0;
-            for (uint32_t c = 0; c < FB.n_ranges; c++) cnt[0] += hcnt[(size_t)c * 32];
+            for (uint32_t c = 0; c < FB.n_ranges; c++) { hprefix[c] = cnt[0]; cnt[0] += hcnt[(size_t)c * 32]; }
+            hprefix[FB.n_ranges] = cnt[0];
+            HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hprefix.data(), hprefix.size() * 4, hipMemcpyHostToDevice, s));
             if (cnt[0] == 0) break;
             if (cnt[0] < ctx->tail_cut && cnt[0] * 64ull < n) {
                 // tail: every further round costs a full alignment latency for a handful of reads; finish the

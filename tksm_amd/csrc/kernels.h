@@ -31,6 +31,7 @@ struct BatchView {
 
 struct ErrModelView {
     int type, k, max_alts;
+    int alt0_noop;         // alternative 0 of every row is the k-mer itself (true for Badread model files)
     int uniform_nalts;     // every k-mer row has exactly max_alts alternatives: nalts need not be read
     const uint32_t* cdf;
     const uint64_t* alts;
@@ -65,6 +66,7 @@ struct SimParams {
     int lcap;          // LDS capacity for the padded fragment (bytes, multiple of 4)
     int ncap;          // LDS capacity for the joined new sequence (bytes, multiple of 4)
     int trace_words;   // u32 words per wave in the traceback scratch
+    int ablate;        // diagnostic builds only
     int cap_num, cap_den, cap_add;   // per-read scratch capacity = (raw+2k)*num/den + add, 16-aligned
 };
 
@@ -113,6 +115,9 @@ struct FastBuffers {
     uint32_t* counters;               // [2] slow reads
     uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
     uint32_t rs, n_ranges;
+    // previous round's job set (double buffered): its jobs are the list of reads that are still running
+    const uint32_t* prev_meta; const uint8_t* prev_popd;
+    const uint32_t* prefix;           // [n_ranges + 1] exclusive prefix sum of the previous round's per-range job counts
     uint16_t* sv_i; uint8_t* sv_kind; unsigned long long* sv_alt;   // [n_reads][64] draws of an interrupted round
     unsigned long long* prof;         // diagnostic builds (-DTKSM_PROF) only: per-section cycle sums
     uint32_t* slow_list;              // [n_reads]
@@ -133,7 +138,7 @@ hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView&
 int err_lds_bytes(int lcap, int ncap, int waves_per_wg);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
-                      int waves_per_wg, hipStream_t s);
+                      int from_jobs, uint32_t c0, uint32_t c1, int waves_per_wg, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, hipStream_t s);
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off,

@@ -910,13 +910,24 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
 // ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | N[ncap] | aux[2*ncap] (owner u16 / popd)
 __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
                                               FastBuffers FB, const uint32_t* __restrict__ order, uint32_t begin, uint32_t count,
-                                              int lds_lcap, int lds_ncap) {
+                                              int lds_lcap, int lds_ncap, int from_jobs, uint32_t c0, uint32_t c1) {
     // one launch per length bucket: reads order[begin .. begin+count) share the LDS geometry (lds_lcap, lds_ncap),
     // so a batch with a few long molecules does not cost everyone its occupancy
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6;
     const uint32_t widx = blockIdx.x * (uint32_t)wpw + (uint32_t)wave;
     if (widx >= count) return;
-    const uint64_t r = order[begin + widx];
+    uint64_t r; uint32_t pos;
+    if (!from_jobs) { pos = begin + widx; r = order[pos]; }      // round 0: every read, in sorted order
+    else {
+        // later rounds: one wave per job of the previous round (= per read still running); a dispatched wave costs
+        // ~1-2 ns even if it returns at once, and most reads are finished long before the last round
+        const uint32_t target = FB.prefix[c0] + widx;
+        uint32_t lo2 = c0, hi2 = c1 - 1;
+        while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2 + 1) >> 1; if (FB.prefix[mid] <= target) lo2 = mid; else hi2 = mid - 1; }
+        const uint32_t pjob = lo2 * FB.rs + (target - FB.prefix[lo2]);
+        r = FB.prev_meta[4ull * pjob];
+        pos = lo2 * FB.rs;                                        // any position inside the read's range
+    }
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
     PROF_T(t_begin);
@@ -947,6 +958,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     }
     wave_sync();
     PROF_T(t_loaded); PROF_ADD(0, t_begin, t_loaded);
+#ifdef TKSM_ABLATE
+    if (P.ablate == 1) return;
+#endif
     uint32_t status = 0;
     const double frag_len = (double)L;
     double errors = S.errors;
@@ -986,9 +1000,16 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             else {
             const Ph4 d = philox(P.seed, g, ST_DRAW, n);
             i = (int)__umulhi(d.x, (uint32_t)(max_kmer_index + 1));
+#ifdef TKSM_ABLATE
+            if (P.ablate == 6) { if (i == -12345 || d.y == 77u) FB.prof[0] = d.z + d.w; return; }
+#endif
             if (live) {
                 int kidx = 0; bool valid = true;
                 for (int jj = 0; jj < k; jj++) { const int cc = code_of(frag[i + jj]); valid &= cc >= 0; kidx = (kidx << 2) | (cc & 3); }
+#ifdef TKSM_ABLATE
+                if (P.ablate == 7) { if (kidx == -12345) FB.prof[0] = d.z + d.w + d.y; return; }
+                if (P.ablate == 8) { const uint2 q2 = EM.pself2[kidx]; if (q2.x == 12345u && q2.y == d.y) FB.prof[0] = d.z + d.w; return; }
+#endif
                 if (EM.type == 0 || !valid) kind = 2;
                 else {
                     const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
@@ -996,6 +1017,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                     const uint2 pp2 = EM.pself2[kidx];   // {first threshold, last threshold}
                     const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, pp2.x, pp2.y, na, d.y);
                     if (a == na) kind = 2;
+                    else if (a == 0 && EM.alt0_noop) kind = 0;      // the k-mer itself: no need to fetch its packed form
                     else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
                 }
                 if (kind == 2) {
@@ -1007,6 +1029,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             }
             }
             PROF_T(t_r1); PROF_ADD(1, t_r0, t_r1);
+#ifdef TKSM_ABLATE
+            if (P.ablate == 2) return;
+#endif
             cur_i = i; cur_kind = kind; cur_alt = alt;
             unsigned long long mask = __ballot(live && kind != 0);
             const unsigned long long dead = __ballot(!live);
@@ -1031,6 +1056,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 if (resume) depm |= 1ull << S.resume_src;
             }
             PROF_T(t_r2); PROF_ADD(2, t_r1, t_r2);
+#ifdef TKSM_ABLATE
+            if (P.ablate == 3) return;
+#endif
             double est_cur = 1.0 - errors / frag_len;
             while (mask) {
                 const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
@@ -1107,6 +1135,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             }
         }
         wave_sync();
+#ifdef TKSM_ABLATE
+        if (P.ablate == 4) return;
+#endif
         if (need_aln) {
             st_aligns++;
             int p0 = 0, nrows = L;
@@ -1123,8 +1154,11 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 if (lane == 0) FB.state[r].stage = 2;
                 return;
             }
-            const uint32_t job = join_job(FB, 1, r, begin + widx, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
+            const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
             PROF_T(t_j2); PROF_ADD(5, t_j1, t_j2);
+#ifdef TKSM_ABLATE
+            if (P.ablate == 5) return;
+#endif
             if (job >> 31) { go_slow(FB, r, lane); return; }
             for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
             FB.sv_i[r * 64 + lane] = (uint16_t)cur_i; FB.sv_kind[r * 64 + lane] = (uint8_t)cur_kind; FB.sv_alt[r * 64 + lane] = cur_alt;
@@ -1160,7 +1194,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
     if (S.stage == 0 && want_q) {
-        const uint32_t job = join_job(FB, 1, r, begin + widx, 1, frag, nb, 0, L, m, lds_ncap, aux, nullptr, 0, 0, lane);
+        const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m, lds_ncap, aux, nullptr, 0, 0, lane);
         if (job >> 31) { go_slow(FB, r, lane); return; }
         if (lane == 0) {
             S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
@@ -1175,7 +1209,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
         if (fail) { go_slow(FB, r, lane); return; }
         identity = cols ? (double)mt / (double)cols : 0.0;
-        const uint8_t* gp = FB.job_popd + (size_t)S.job * P.ncap;
+        const uint8_t* gp = FB.prev_popd + (size_t)S.job * P.ncap;
         wave_sync();
         for (int t = lane; t < m; t += 64) popd[t] = gp[t];
         wave_sync();
@@ -1685,13 +1719,13 @@ hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView&
 int err_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap + 128); }
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
-                      int wpw, hipStream_t s) {
+                      int from_jobs, uint32_t c0, uint32_t c1, int wpw, hipStream_t s) {
     if (!count) return hipSuccess;
     const int lds = err_lds_bytes(lds_lcap, lds_ncap, wpw);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_err), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_err, dim3((count + wpw - 1) / wpw), dim3(64 * wpw), lds, s, b, em, qm, p, o, fb, order, begin, count, lds_lcap,
-                       lds_ncap);
+                       lds_ncap, from_jobs, c0, c1);
     return hipGetLastError();
 }
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s) {
