@@ -913,11 +913,12 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                                               int lds_lcap, int lds_ncap, int from_jobs, uint32_t c0, uint32_t c1) {
     // one launch per length bucket: reads order[begin .. begin+count) share the LDS geometry (lds_lcap, lds_ncap),
     // so a batch with a few long molecules does not cost everyone its occupancy
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6;
+    // wave-uniform values are pinned to scalar registers (readfirstlane): the vector file is the occupancy limit
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpw = blockDim.x >> 6;
     const uint32_t widx = blockIdx.x * (uint32_t)wpw + (uint32_t)wave;
     if (widx >= count) return;
     uint64_t r; uint32_t pos;
-    if (!from_jobs) { pos = begin + widx; r = order[pos]; }      // round 0: every read, in sorted order
+    if (!from_jobs) { pos = begin + widx; r = (uint64_t)__builtin_amdgcn_readfirstlane((int)order[pos]) & 0xffffffffull; }   // round 0: every read, in sorted order
     else {
         // later rounds: one wave per job of the previous round (= per read still running); a dispatched wave costs
         // ~1-2 ns even if it returns at once, and most reads are finished long before the last round
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         uint32_t lo2 = c0, hi2 = c1 - 1;
         while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2 + 1) >> 1; if (FB.prefix[mid] <= target) lo2 = mid; else hi2 = mid - 1; }
         const uint32_t pjob = lo2 * FB.rs + (target - FB.prefix[lo2]);
-        r = FB.prev_meta[4ull * pjob];
+        r = (uint64_t)__builtin_amdgcn_readfirstlane((int)FB.prev_meta[4ull * pjob]) & 0xffffffffull;
         pos = lo2 * FB.rs;                                        // any position inside the read's range
     }
     ReadState S = FB.state[r];
@@ -939,10 +940,10 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     uint8_t* popd = aux;
     const int k = EM.k;
     const uint64_t g = P.first_read + r * P.stride;
-    const int raw_len = S.raw_len;
+    const int raw_len = __builtin_amdgcn_readfirstlane(S.raw_len);
     const int L = raw_len + 2 * k;
     const uint64_t slot = O.slot_off[r];
-    const int cap = (int)((O.slot_off[r + 1] - slot) >> 1);
+    const int cap = __builtin_amdgcn_readfirstlane((int)((O.slot_off[r + 1] - slot) >> 1));
     uint8_t* out_seq = O.scratch + slot;
     uint8_t* out_qual = out_seq + cap;
     uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
@@ -965,8 +966,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const double frag_len = (double)L;
     double errors = S.errors;
     const double target = S.target;
-    int change_count = S.change_count, st_draws = S.st_draws, st_aligns = S.st_aligns;
-    uint32_t n_base = S.n_base, aln_no = S.aln_no;
+    int change_count = __builtin_amdgcn_readfirstlane(S.change_count), st_draws = __builtin_amdgcn_readfirstlane(S.st_draws),
+        st_aligns = __builtin_amdgcn_readfirstlane(S.st_aligns);
+    uint32_t n_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.n_base), aln_no = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.aln_no);
     double identity = 1.0;
 
     if (S.stage == 0) {
@@ -987,7 +989,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const long long loop_limit = 100ll * L;
         bool done = false, need_aln = false;
         int r_src = 0, r_j = 0; double r_est = 0.0;
-        int cur_i = 0, cur_kind = 0; uint64_t cur_alt = 0;
         if (!resume && !S.pending)
             if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
         while (!done && !need_aln) {
@@ -1032,7 +1033,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
 #ifdef TKSM_ABLATE
             if (P.ablate == 2) return;
 #endif
-            cur_i = i; cur_kind = kind; cur_alt = alt;
             unsigned long long mask = __ballot(live && kind != 0);
             const unsigned long long dead = __ballot(!live);
             if (resume) mask &= ~((1ull << S.resume_src) - 1ull);
@@ -1117,7 +1117,10 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                         for (int jj = 0; jj < 8; jj++)
                             if ((wm >> jj) & 1u) nb[i + jj] = (uint16_t)((ev.e[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
                     }
-                    if (need_aln) break;
+                    if (need_aln) {                            // the round's draws travel with the state
+                        FB.sv_i[r * 64 + lane] = (uint16_t)i; FB.sv_kind[r * 64 + lane] = (uint8_t)kind; FB.sv_alt[r * 64 + lane] = alt;
+                        break;
+                    }
                     est_cur = 1.0 - errors / frag_len;
                 }
                 // stop rules at the top of the next iteration (also after a resumed draw that applied nothing more:
@@ -1161,7 +1164,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
 #endif
             if (job >> 31) { go_slow(FB, r, lane); return; }
             for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
-            FB.sv_i[r * 64 + lane] = (uint16_t)cur_i; FB.sv_kind[r * 64 + lane] = (uint8_t)cur_kind; FB.sv_alt[r * 64 + lane] = cur_alt;
             if (lane == 0) {
                 S.errors = errors; S.est = r_est; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
                 S.resume_src = (int16_t)r_src; S.resume_j = (int16_t)r_j; S.pending = 1; S.stage = 0;
