@@ -1305,7 +1305,7 @@ struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
 // row outside reports needfull and is redone with FULL = true (all 64 rows, 16 bytes per column).  Both variants
 // stage 4 KB per wave in LDS: 8 columns x 8 B or 4 columns x 16 B per lane.
 template <bool FULL>
-DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds) {
+DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds, int P_ablate) {
     constexpr int CB = FULL ? 4 : 8, CSH = FULL ? 2 : 3, EW = FULL ? 2 : 1;   // columns per block, words per column
     const int p0 = J.p0, n = J.n, m = J.m, mode = J.mode;
     unsigned long long Pv = ~0ull, Mv = 0ull;
@@ -1392,6 +1392,9 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             wave_sync();
         }
     }
+#ifdef TKSM_ABLATE
+    if (P_ablate == 11) { AlnRes R0; R0.mt = (uint32_t)(Pv ^ Mv); R0.cols = (uint32_t)t; R0.fail = false; R0.needfull = false; return R0; }
+#endif
     // ---- walk back from (n, m), block by block (uniform block index; every lane walks its own job)
     AlnRes R;
     int i = n, j = m, tt = t;
@@ -1510,7 +1513,10 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
 #ifdef TKSM_PROF
     if (lane == 0) atomicAdd(&FB.prof[15], 1ull);
 #endif
-    AlnRes R = aln_pass<false>(J, J.act, mmax, lane, tr_lds);
+#ifdef TKSM_ABLATE
+    if (P.ablate == 10) return;
+#endif
+    AlnRes R = aln_pass<false>(J, J.act, mmax, lane, tr_lds, P.ablate);
     if (__ballot(R.needfull)) {
 #ifdef TKSM_PROF
         if (lane == 0) { atomicAdd(&FB.prof[13], (unsigned long long)__popcll(__ballot(R.needfull))); atomicAdd(&FB.prof[14], 1ull); }
@@ -1519,7 +1525,7 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         int mm2 = redo ? J.m : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
-        const AlnRes R2 = aln_pass<true>(J, redo, mm2, lane, tr_lds);
+        const AlnRes R2 = aln_pass<true>(J, redo, mm2, lane, tr_lds, P.ablate);
         if (redo) R = R2;
     }
     if (J.act) {
