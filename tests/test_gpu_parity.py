@@ -251,3 +251,91 @@ def test_full_size_properties_and_shard_invariance():
                                   dst.data_ptr(), dst.numel())
     assert nbytes == len(rec1) and bytes(dst[:nbytes].cpu().numpy().tobytes()) == rec1
     s.close()
+
+
+@pytest.mark.parametrize("err,qs", [("random", "random"), ("random", "ideal"), ("nanopore2020", "ideal"), ("nanopore2020", "random")])
+def test_builtin_models_bit_exact_vs_oracle(po, oracle_models, err, qs):
+    """the special model names of the CLI (py/tksm_badread.py:80-83 'random' error model with k = 1; :487-544 'random' and
+    'ideal' q-score models) through the same kernels"""
+    s, ref, rs = _random_genome_seqr(n_contigs=2, size=60_000, seed=9)
+    s.set_identity(88.0, 97.0, 4.0)
+    s.load_error_model(ERR_MODEL if err == "nanopore2020" else err)
+    s.load_qscore_model(qs)
+    em = oracle_models["em"] if err == "nanopore2020" else po.ErrorModel(err)
+    qm = po.QScoreModel(qs)
+    mols = _make_molecules(rs, ref, 40, 500)
+    text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
+    recs = s.run(s.batch_from_mdf(text), target="badread", fastq=True, compute_qual=True, seed=77).records()
+    ident = po.Identities(88.0, 4.0, 97.0, qtab=s.identity_tables()["qtab"])
+    for i, (mid, ivs) in enumerate(mols):
+        want, st = po.badread_record(True, 77, i, po.splice(ref, ivs), ident, em, qm, True, mid)
+        assert recs[i] == want, (err, qs, i)
+    s.close()
+
+
+def test_edge_cases_empty_short_constant_identity_and_limits(po, oracle_models):
+    """empty batch, empty / one-base / shorter-than-k molecules, depth 0 and depth 3, a constant identity
+    (mean == max, py/tksm_badread.py:711-715), FASTA output (no q-scores), and the documented size limit"""
+    from tksm_amd.sequence import Sequencer, TksmSeqError
+    s, ref, rs = _random_genome_seqr(n_contigs=1, size=30_000, seed=2)
+    s.set_identity(90.0, 90.0, 3.0)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    b0 = s.batch_from_mdf("")
+    r0 = s.run(b0, target="badread")
+    assert r0.n_reads == 0 and r0.records_bytes == 0
+    mdf = ("+empty\t1\t\nchr1\t5\t5\t+\t\n" "+one\t1\t\nchr1\t7\t8\t-\t\n" "+short\t1\t\nchr1\t100\t104\t+\t2A\n"
+           "+gone\t0\t\nchr1\t0\t50\t+\t\n" "+thrice\t3\tx=1;\nchr1\t200\t420\t-\t\n" "+lit\t1\t\nACGTN\t0\t5\t+\t\n")
+    ident = po.Identities(90.0, 3.0, 90.0)
+    mols = list(po.mdf_generator(mdf.splitlines(keepends=True)))
+    assert [m[0] for m in mols] == ["empty", "one", "short", "thrice", "thrice", "thrice", "lit"]
+    for fastq in (True, False):
+        recs = s.run(s.batch_from_mdf(mdf), target="badread", fastq=fastq, compute_qual=True, seed=3).records()
+        assert len(recs) == len(mols)
+        for i, (mid, ivs) in enumerate(mols):
+            want, _ = po.badread_record(fastq, 3, i, po.splice(ref, ivs), ident, oracle_models["em"], oracle_models["qm"], fastq, mid)
+            assert recs[i] == want, (fastq, i, mid)
+        per = s.run(s.batch_from_mdf(mdf), target="perfect", fastq=fastq, seed=3).records()
+        for i, (mid, ivs) in enumerate(mols):
+            assert per[i] == po.perfect_record(fastq, 3, i, po.splice(ref, ivs), mid)
+    # malformed input is refused the way the reference crashes on it (ValueError / IndexError -> exit 1)
+    for bad in ("chr1\t0\t5\t+\t\n", "+m\t1\t\nchr1\t0\t5\t+\n", "+m\t1\t\nchr1\t0\t5\t+\t9A\n", "+m\tx\t\n"):
+        with pytest.raises(TksmSeqError):
+            s.run(s.batch_from_mdf(bad), target="perfect")
+    # documented limit: a molecule beyond the LDS-resident working set
+    s.add_contig("big", rs.choice(np.frombuffer(b"ACGT", np.uint8), 80_000).tobytes())
+    with pytest.raises(TksmSeqError) as e:
+        s.run(s.batch_from_mdf("+huge\t1\t\nbig\t0\t70000\t+\t\n"), target="badread")
+    assert e.value.code == 6
+    s.close()
+
+
+def test_output_slot_overflow_triggers_rerun(tmp_path, po):
+    """an insertion-heavy error model outgrows the default 1.5x output slot: the library reruns with the worst-case
+    slot and still matches the oracle"""
+    import gzip
+    path = tmp_path / "ins.error.gz"
+    rs = np.random.RandomState(0)
+    with gzip.open(path, "wt") as f:
+        for idx in range(4 ** 3):
+            kmer = "".join("ACGT"[(idx >> (2 * (2 - j))) & 3] for j in range(3))
+            alt = kmer[0] + kmer[1] + "ACGT"[rs.randint(4)] * 4 + kmer[2]      # 4-base insertion in the middle
+            f.write(f"{kmer},0.300000;{alt},0.650000;\n")
+    from tksm_amd.sequence import Sequencer
+    s, ref, rs2 = _random_genome_seqr(n_contigs=1, size=20_000, seed=4)
+    s.set_identity(55.0, 60.0, 1.0)
+    s.load_error_model(str(path))
+    s.load_qscore_model("random")
+    em, qm = po.ErrorModel(str(path)), po.QScoreModel("random")
+    assert em.k == 3
+    mols = [(f"m{i}", [("chr1", 100 * i, 100 * i + 300, "+", "")]) for i in range(12)]
+    text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
+    recs = s.run(s.batch_from_mdf(text), target="badread", fastq=True, compute_qual=True, seed=8).records()
+    ident = po.Identities(55.0, 1.0, 60.0, qtab=s.identity_tables()["qtab"])
+    grew = 0
+    for i, (mid, ivs) in enumerate(mols):
+        want, st = po.badread_record(True, 8, i, po.splice(ref, ivs), ident, em, qm, True, mid)
+        grew += st.new_len > 1.5 * st.frag_len + 64
+        assert recs[i] == want, i
+    assert grew > 0, "the model did not outgrow the default slot: the test does not exercise the rerun"
+    s.close()
