@@ -92,7 +92,7 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jn[2], f_jsh[2], f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 2048;
     uint32_t n_buckets = 16;
@@ -567,7 +567,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     } else {
         // ---- fast pipeline: k_init, then rounds of k_err (wave per read) + k_aln (lane per alignment)
         tk::FastBuffers FB{};
-        FB.fw = lcap / 64 + 5; FB.nw = ncap / 64 + 2; FB.shw = ncap / 8 + 16;
+        FB.fw = lcap / 64 + 8; FB.cw = ncap / 8 + 4;
         // job-id ranges: ~256 ranges of rs (multiple of 64) consecutive reads of the sorted order
         FB.rs = (uint32_t)((((n + 255) / 256) + 63) & ~63ull);
         FB.n_ranges = (uint32_t)((n + FB.rs - 1) / FB.rs);
@@ -579,8 +579,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
         for (int z = 0; z < 2; z++) {
             HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
-            HIPCHK(ctx, ctx->f_jn[z].ensure(jcap * (size_t)FB.nw * 16 + 64));
-            HIPCHK(ctx, ctx->f_jsh[z].ensure(jcap * (size_t)FB.shw * 4 + 64));
+            HIPCHK(ctx, ctx->f_jcols[z].ensure(jcap * (size_t)FB.cw * 8 + 64));
             HIPCHK(ctx, ctx->f_jpopd[z].ensure(jcap * (size_t)ncap + 64));
             HIPCHK(ctx, ctx->f_jobcnt[z].ensure((size_t)FB.n_ranges * 128 + 64));
         }
@@ -596,8 +595,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.prefix = ctx->f_prefix.as<uint32_t>();
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
-            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_n = ctx->f_jn[z].as<unsigned long long>();
-            FB.job_sh = ctx->f_jsh[z].as<uint32_t>(); FB.job_popd = ctx->f_jpopd[z].as<uint8_t>(); FB.job_cnt = ctx->f_jobcnt[z].as<uint32_t>();
+            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[z].as<unsigned long long>();
+            FB.job_popd = ctx->f_jpopd[z].as<uint8_t>(); FB.job_cnt = ctx->f_jobcnt[z].as<uint32_t>();
             FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[y].as<uint8_t>();
         };
         select_set(0);
@@ -641,7 +640,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         };
         std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other, 1 err, 2 aln, -1 host gap
         HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, n * (size_t)lcap * 2, s));
-        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 16, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 64, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, tk::WAVES_PER_WG, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
@@ -701,6 +700,15 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             kinds.push_back(2);
         }
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
+        if (getenv("TKSMSEQ_VERBOSE")) {
+            uint32_t cc[16];
+            HIPCHK(ctx, hipMemcpy(cc, ctx->f_counters.p, 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
+                    (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);
+#ifdef TKSM_ABLATE
+            fprintf(stderr, "[tksmseq] walk deviation from the generative row: <=3 %u, <=5 %u, <=7 %u, <=9 %u, <=11 %u, more %u\n", cc[10], cc[11], cc[12], cc[13], cc[14], cc[15]);
+#endif
+        }
 #ifdef TKSM_PROF
         {
             unsigned long long pr[16];

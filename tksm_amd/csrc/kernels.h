@@ -105,10 +105,11 @@ struct FastBuffers {
     ReadState* state;                 // [n_reads]
     uint8_t* st_frag;                 // [n_reads][lcap]
     uint16_t* st_nb;                  // [n_reads][lcap]
-    unsigned long long* st_fplanes;   // [n_reads][2][fw] 2-bit planes of the padded fragment
+    unsigned long long* st_fplanes;   // [n_reads][fw][2] 2-bit planes of the padded fragment, {lo, hi} word pairs
     uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, m}
-    unsigned long long* job_n;        // [n_reads][2][nw] 2-bit planes of the joined window
-    uint32_t* job_sh;                 // [n_reads][shw] 4-bit window shift per column
+    // [n_reads][cw] one record per 8 columns of the joined window: bits 0-31 the 4-bit window shifts of the columns,
+    // bits 32-39 / 40-47 the low / high bit of the columns' 2-bit base codes
+    unsigned long long* job_cols;
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
     uint32_t* aln_res;                // [n_reads][4] {matches, columns, fail, -}
     void* trace;                      // [n_groups][ncap + 1][64] x 16 B
@@ -121,7 +122,7 @@ struct FastBuffers {
     uint16_t* sv_i; uint8_t* sv_kind; unsigned long long* sv_alt;   // [n_reads][64] draws of an interrupted round
     unsigned long long* prof;         // diagnostic builds (-DTKSM_PROF) only: per-section cycle sums
     uint32_t* slow_list;              // [n_reads]
-    int fw, nw, shw;
+    int fw, cw;
 };
 
 hipError_t launch_pack(const uint8_t* ascii, uint64_t n, uint64_t gstart, uint32_t* packed, uint32_t* blockflag,

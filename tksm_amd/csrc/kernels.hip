@@ -636,9 +636,10 @@ DEV int cdf_pick(const uint32_t* cdf32, uint32_t pself, uint32_t ptot, int na, u
     return min(a, na);
 }
 
-DEV void go_slow(const FastBuffers& FB, uint64_t r, int lane) {
+DEV void go_slow(const FastBuffers& FB, uint64_t r, int lane, int cause) {
     if (lane == 0) {
         FB.state[r].slow = 1;
+        atomicAdd(&FB.counters[4 + cause], 1u);            // diagnostics: 0/3 alignment left the band, 1/2 window shift > 15
         const uint32_t idx = atomicAdd(&FB.counters[2], 1u);
         FB.slow_list[idx] = (uint32_t)r;
     }
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
         const int code = code_of(c);
         dirty |= code < 0;
         const unsigned long long lo = __ballot(valid && (code & 1)), hi = __ballot(valid && (code & 2));
-        if (lane == 0) { fpl[q] = lo; fpl[FB.fw + q] = hi; }
+        if (lane == 0) { fpl[2 * q] = lo; fpl[2 * q + 1] = hi; }
     }
     const bool slow = __ballot(dirty) != 0ull;
     if (lane == 0) {
@@ -716,41 +717,6 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
         O.status[r] |= status;
         if (slow) { const uint32_t idx = atomicAdd(&FB.counters[2], 1u); FB.slow_list[idx] = (uint32_t)r; }
     }
-}
-
-// packs the joined window into an alignment job: 2-bit planes of N, 4-bit window-shift per column
-DEV uint32_t build_job(const FastBuffers& FB, uint64_t r, uint32_t pos, int mode, int p0, int n, int m, const uint8_t* N,
-                       const uint16_t* owner, int lane) {
-    // job ids are handed out by one counter per contiguous range of `rs` reads of the sorted order (one hot word
-    // for the whole chip would cap the kernel at ~88 allocations per microsecond); range c owns ids [c*rs, (c+1)*rs)
-    uint32_t idx = 0;
-    if (lane == 0) { const uint32_t c = pos / FB.rs; idx = c * FB.rs + atomicAdd(&FB.job_cnt[c * 32u], 1u); }
-    idx = __shfl(idx, 0, 64);
-    if (lane == 0) {
-        uint32_t* meta = FB.job_meta + 4ull * idx;
-        meta[0] = (uint32_t)r; meta[1] = (uint32_t)p0; meta[2] = (uint32_t)n | ((uint32_t)mode << 31); meta[3] = (uint32_t)m;
-    }
-    unsigned long long* jn = FB.job_n + (size_t)idx * 2 * FB.nw;
-    uint32_t* jsh = FB.job_sh + (size_t)idx * FB.shw;
-    bool fail = false;
-    for (int q = 0; q * 64 < m + 64; q++) {
-        const int c = q * 64 + lane;
-        const bool valid = c < m;
-        const int code = valid ? code_of(N[c]) : 0;
-        const unsigned long long lo = __ballot(valid && (code & 1)), hi = __ballot(valid && (code & 2));
-        if (lane == 0) { jn[q] = lo; jn[FB.nw + q] = hi; }
-        int sh = 0;
-        if (valid) {
-            const int tj = max(1, (int)owner[c] + 1 - 31);
-            const int tprev = c == 0 ? 1 : max(1, (int)owner[c - 1] + 1 - 31);
-            sh = tj - tprev;
-            if (sh > 15) fail = true;
-        }
-        uint32_t v = (uint32_t)(sh & 15) << (4 * (lane & 7));
-        v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); v |= __shfl_xor(v, 4, 64);
-        if ((lane & 7) == 0) jsh[q * 8 + (lane >> 3)] = v;
-    }
-    return idx | (__ballot(fail) ? 0x80000000u : 0u);
 }
 
 // per-read results shared by both stages of k_err (py/sequence.py:252-288 record length)
@@ -890,12 +856,12 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
     }
     if (build) {
         wave_sync();
-        unsigned long long* jn = FB.job_n + (size_t)idx * 2 * FB.nw;
-        uint32_t* jsh = FB.job_sh + (size_t)idx * FB.shw;
-        const int wn = m / 64 + 2;              // words k_aln may touch (incl. the zero word after the end)
-        for (int t = lane; t < wn; t += 64) { jn[t] = pl[t]; jn[FB.nw + t] = pl[lnw + t]; }
-        const int ws = m / 8 + 2;
-        for (int t = lane; t < ws; t += 64) jsh[t] = shn[t];
+        // one record per 8 columns: {shifts, low code bits, high code bits}; one zero record after the end
+        unsigned long long* jc = FB.job_cols + (size_t)idx * FB.cw;
+        const uint8_t* plb = stage;
+        const int nrec = m / 8 + 2;
+        for (int t = lane; t < nrec; t += 64)
+            jc[t] = (unsigned long long)shn[t] | ((unsigned long long)plb[t] << 32) | ((unsigned long long)plb[8 * lnw + t] << 40);
     }
     return idx | (__ballot(fail) ? 0x80000000u : 0u);
 }
@@ -975,7 +941,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         bool resume = S.resume_src >= 0;
         if (S.pending) {                                   // apply the re-estimation result (py/tksm_badread.py:412-432)
             const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
-            if (fail) { go_slow(FB, r, lane); return; }
+            if (fail) { go_slow(FB, r, lane, 0); return; }
             const double ident = cols ? (double)mt / (double)cols : 0.0;
             if (L <= 1000) errors = (1.0 - ident) * frag_len;
             else {
@@ -1162,7 +1128,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
 #ifdef TKSM_ABLATE
             if (P.ablate == 5) return;
 #endif
-            if (job >> 31) { go_slow(FB, r, lane); return; }
+            if (job >> 31) { go_slow(FB, r, lane, 1); return; }
             for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
             if (lane == 0) {
                 S.errors = errors; S.est = r_est; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
@@ -1197,7 +1163,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
     if (S.stage == 0 && want_q) {
         const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m, lds_ncap, aux, nullptr, 0, 0, lane);
-        if (job >> 31) { go_slow(FB, r, lane); return; }
+        if (job >> 31) { go_slow(FB, r, lane, 2); return; }
         if (lane == 0) {
             S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
             S.resume_src = -1; S.pending = 1; S.stage = 1; S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
@@ -1209,7 +1175,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (want_q) {
         // ---- S5 q-scores from the alignment k_aln left in job_popd (py/tksm_badread.py:607-655)
         const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
-        if (fail) { go_slow(FB, r, lane); return; }
+        if (fail) { go_slow(FB, r, lane, 3); return; }
         identity = cols ? (double)mt / (double)cols : 0.0;
         const uint8_t* gp = FB.prev_popd + (size_t)S.job * P.ncap;
         wave_sync();
@@ -1291,56 +1257,245 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
 // back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
 struct AlnJob {
     bool act; int p0, n, m, mode;
-    const unsigned long long *fl, *fh, *nl, *nh;
-    const uint32_t* jsh;
-    unsigned long long* trace;   // per-job region of (ncap + 16) 16-byte columns
-    unsigned long long* trace0;  // region of the wave's first job
-    size_t tstride;              // u64 words between consecutive jobs
+    const unsigned long long* fp;    // fragment planes of the read, {lo, hi} word pairs
+    const unsigned long long* jc;    // the job's column records
+    unsigned long long* trace;       // per-job region of (ncap + 16) 16-byte columns
+    unsigned long long* trace0;      // region of the wave's first job
+    size_t tstride;                  // u64 words between consecutive jobs
     unsigned long long* popd8;
 };
 struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
 
-// One forward pass + walk back.  FULL = false keeps only the middle 32 rows of each column's predecessor codes
-// (8 bytes per column: rows 16..47 of the band, the path practically never leaves them); a lane whose walk needs a
-// row outside reports needfull and is redone with FULL = true (all 64 rows, 16 bytes per column).  Both variants
-// stage 4 KB per wave in LDS: 8 columns x 8 B or 4 columns x 16 B per lane.
-template <bool FULL>
-DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds, int P_ablate) {
-    constexpr int CB = FULL ? 4 : 8, CSH = FULL ? 2 : 3, EW = FULL ? 2 : 1;   // columns per block, words per column
+DEV uint32_t lo32(unsigned long long v) { return (uint32_t)v; }
+DEV uint32_t hi32(unsigned long long v) { return (uint32_t)(v >> 32); }
+DEV unsigned long long mk64(uint32_t hi, uint32_t lo) { return ((unsigned long long)hi << 32) | lo; }
+// ({hi, lo} >> s) & 0xffffffff for s in 0..31: one v_alignbit_b32
+DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+// bits [s, s + 64) of the 128-bit value {x1, x0}, s in 0..63
+DEV unsigned long long funnel128(unsigned long long x0, unsigned long long x1, int s) {
+    const bool a = (s & 32) != 0;
+    const uint32_t b = (uint32_t)s & 31u;
+    const uint32_t y0 = a ? hi32(x0) : lo32(x0), y1 = a ? lo32(x1) : hi32(x0), y2 = a ? hi32(x1) : lo32(x1);
+    return mk64(alignbit(y2, y1, b), alignbit(y1, y0, b));
+}
+
+// ---- the common case: 8 bytes of predecessor codes per column (rows 16..47 of the band; the path practically
+// never leaves them).  Written for the vector ALU: every per-column shift is by 0..15, so the 64-bit words are
+// moved with v_alignbit on their halves; the fragment window slides (window + 64 bits of lookahead, refilled once
+// per 8 columns) instead of being re-extracted from the planes; the loop body is branch-free and every memory
+// operation is unconditional, so that the waits on the per-block prefetches do not have to drain the trace stores
+// (gfx9 counts loads and stores in one counter, in issue order).
+// A lane whose walk needs a row outside the stored 32 reports needfull (redone by aln_full); a lane whose window
+// moves by more than 64 rows within 8 columns reports fail (the read goes to the exact wave-wide path).
+DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned long long* tr_lds, int ablate, uint32_t* devhist) {
+    const bool act = J.act;
+    const int p0 = J.p0, n = J.n, m = J.m;
+    const unsigned long long M64 = J.mode ? ~0ull : 0ull;
+    unsigned long long Pv = ~0ull, Mv = 0ull;
+    int t = 1;
+    bool bandfail = false;
+    unsigned long long A, LA, B, LB;             // low / high code plane: window rows and the 64 rows after them
+    auto nibsum = [](uint32_t w) -> int {
+        const uint32_t x4 = (w & 0x0f0f0f0fu) + ((w >> 4) & 0x0f0f0f0fu);
+        return (int)((x4 * 0x01010101u) >> 24);
+    };
+    // records of the current and the next block of 8 columns (zero after the end of the job)
+    unsigned long long recC = (act && m > 0) ? J.jc[0] : 0ull, recN = (act && m > 8) ? J.jc[1] : 0ull;
+    ulonglong2 pfA0, pfA1, pfB0, pfB1;           // lookahead words in flight: two sets, two blocks deep
+    {
+        const int w = p0 >> 6, s = p0 & 63;
+        const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w);
+        const ulonglong2 q1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 2);
+        const ulonglong2 q2 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 4);
+        A = funnel128(q0.x, q1.x, s); LA = funnel128(q1.x, q2.x, s);
+        B = funnel128(q0.y, q1.y, s); LB = funnel128(q1.y, q2.y, s);
+        const int w1 = (p0 + nibsum(lo32(recC)) + 64) >> 6;
+        pfA0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w1);
+        pfA1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w1 + 2);
+    }
+    int mjq[4];                                  // lengths of the jobs this lane stores trace lines for
+#pragma unroll
+    for (int q = 0; q < 4; q++) mjq[q] = __shfl(act ? m : 0, q * 16 + (lane >> 2), 64);
+    // one block of 8 columns; pfc = lookahead words for the refill at its end (requested one block earlier),
+    // pfn = the set to request now for the refill at the end of the next block
+    auto block = [&](int c0, const ulonglong2& pfc0, const ulonglong2& pfc1, ulonglong2& pfn0, ulonglong2& pfn1) {
+        const uint32_t shw = lo32(recC), nbits = hi32(recC);
+        const int adv = nibsum(shw);             // rows the window moves in this block
+        bandfail |= adv > 64;
+        const int o1 = p0 + t - 1 + adv, o2 = o1 + nibsum(lo32(recN));
+        const int wn = (o2 + 64) >> 6;
+#ifdef TKSM_ABLATE
+        if (ablate == 13 || ablate == 14) { pfn0.x = recC; pfn0.y = ~recC; pfn1.x = recC * 3; pfn1.y = recC * 5; } else
+#endif
+        {
+            pfn0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * wn);
+            pfn1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * wn + 2);
+        }
+        const unsigned long long recF = J.jc[(c0 >> 3) + 2];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const uint32_t sh = (shw >> (4 * x)) & 15u;
+            t += (int)sh;
+            const bool g = t > 1;
+            // window moves down by sh rows: entering rows take vertical delta +1
+            Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh));
+            Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh));
+            const unsigned long long f = (sh == 0u && g) ? 1ull : 0ull;   // window did not move: top row only from the left
+            Pv &= ~f; Mv |= f;
+            A = mk64(alignbit(lo32(LA), hi32(A), sh), alignbit(hi32(A), lo32(A), sh));
+            LA = mk64(hi32(LA) >> sh, alignbit(hi32(LA), lo32(LA), sh));
+            B = mk64(alignbit(lo32(LB), hi32(B), sh), alignbit(hi32(B), lo32(B), sh));
+            LB = mk64(hi32(LB) >> sh, alignbit(hi32(LB), lo32(LB), sh));
+            const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
+            const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
+            // rows below the fragment (i > n) are not masked: they never feed a row above them
+            const unsigned long long Eq = ~((A ^ mk64(cl, cl)) | (B ^ mk64(ch, ch)));
+            const unsigned long long Xv = Eq | Mv;
+            const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            const unsigned long long Ph = Mv | ~(Xh | Pv);
+            const unsigned long long Mh = Pv & Xh;
+            const unsigned long long D0 = Xh | Mv;
+            const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
+            const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
+            Pv = Mhs | ~(Xv | Phs);
+            Mv = Phs & Xv;
+            const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
+            // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal
+            const unsigned long long w1 = ~(upv | Ph);
+            const unsigned long long w0 = (Ph & (~upv | M64)) | (w1 & D0);
+            // stored rows: 32 around the generative row, which sits at bit 31 once the window moves (t > 1) and
+            // climbs from bit 0 with the column index while the window is still clamped at row 1
+            const uint32_t st = g ? 16u : (uint32_t)max(0, min(16, c0 + x - 15));
+            tr_lds[x * 64 + lane] = mk64(alignbit(hi32(w1), lo32(w1), st), alignbit(hi32(w0), lo32(w0), st));
+        }
+        wave_sync();
+        // 64 bytes per job, written as whole lines: 4 threads cover one job's 8 columns (transpose through LDS);
+        // lines of jobs that have already ended go to the spare columns at the end of the job's own region
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int jl = q * 16 + (lane >> 2), part = lane & 3;
+            ulonglong2 v;
+            v.x = tr_lds[(2 * part) * 64 + jl]; v.y = tr_lds[(2 * part + 1) * 64 + jl];
+            const int col = c0 < mjq[q] ? c0 : spare_col;
+#ifdef TKSM_ABLATE
+            if (ablate == 12 || ablate == 14) { if (v.x == 0x1234567ull) J.trace0[0] = v.y; } else
+#endif
+            *reinterpret_cast<ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)col + 2 * part) = v;
+        }
+        wave_sync();
+        LA = funnel128(pfc0.x, pfc1.x, o1 & 63);
+        LB = funnel128(pfc0.y, pfc1.y, o1 & 63);
+        recC = recN;
+        recN = (act && c0 + 16 < m) ? recF : 0ull;
+    };
+    for (int c0 = 0; c0 < mmax; c0 += 16) {
+        block(c0, pfA0, pfA1, pfB0, pfB1);
+        block(c0 + 8, pfB0, pfB1, pfA0, pfA1);   // may lie past the last column: all shifts zero, lines to the spare columns
+    }
+#ifdef TKSM_ABLATE
+    if (ablate >= 11 && ablate <= 19) { AlnRes R0; R0.mt = (uint32_t)(Pv ^ Mv); R0.cols = (uint32_t)t; R0.fail = false; R0.needfull = false; return R0; }
+#endif
+    // ---- walk back from (n, m), block by block (uniform block index; every lane walks its own job)
+    int i = n, j = m, tt = t;
+    uint32_t mt = 0, cols = 0;
+    int dpend = 0;
+    bool fail = act && (bandfail || (m > 0 && (n - tt > 63 || n - tt < 0))), needfull = false;
+    const int topblk = (mmax - 1) >> 3;
+    const uint32_t lim = (uint32_t)(n + m);
+    const uint32_t modem = J.mode ? 0xffu : 0u;
+    unsigned long long preA[8], preB[8];        // trace blocks in flight: two sets, two blocks deep
+    uint32_t shA = 0, shB = 0, cur_sh = 0;
+    // block loads / LDS fills: whole 64-byte lines, 4 threads per job (transposed in LDS)
+    auto load_block = [&](int blk2, unsigned long long* pre, uint32_t& psh) {
+        blk2 = max(blk2, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int jl = q * 16 + (lane >> 2), part = lane & 3;
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)blk2 * 8 + 2 * part);
+            pre[2 * q] = v.x; pre[2 * q + 1] = v.y;
+        }
+        psh = lo32(J.jc[blk2]);
+    };
+    auto fill_lds = [&](const unsigned long long* pre, uint32_t psh) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int jl = q * 16 + (lane >> 2), part = lane & 3;
+            tr_lds[(2 * part) * 64 + jl] = pre[2 * q]; tr_lds[(2 * part + 1) * 64 + jl] = pre[2 * q + 1];
+        }
+        cur_sh = psh;
+    };
+#ifdef TKSM_ABLATE
+    int maxdev = 0;
+#endif
+    // one block: the set `nxt` (block blk - 1) was requested while the previous block was walked; `far` is requested now
+    auto walk_block = [&](int blk, unsigned long long* nxt, uint32_t& nsh, unsigned long long* far, uint32_t& fsh) {
+        load_block(blk - 2, far, fsh);
+        unsigned long long pp = 0ull;          // op bytes of this group of 8 columns
+        bool touched = false;
+        bool go = act && !fail && !needfull && j > 0 && ((j - 1) >> 3) == blk;
+        while (go) {
+            const int c8 = (j - 1) & 7;
+            const unsigned long long e = tr_lds[c8 * 64 + lane];
+            const int st = tt > 1 ? 16 : max(0, min(16, j - 16));
+            const int b = i - tt, bs = b - st;
+            int code = (int)((lo32(e) >> (bs & 31)) & 1u) | (int)(((hi32(e) >> (bs & 31)) & 1u) << 1);
+            code = b > 63 ? 0 : code;                     // virtual cell below the window: up
+            code = i == 0 ? 1 : code;                     // row 0: only left
+            const bool bad = (i > 0 && b < 0) || cols > lim;
+            const bool out = i > 0 && b >= 0 && b <= 63 && (uint32_t)bs > 31u;
+            if (bad || out) { fail |= bad; needfull |= out && !bad; break; }
+#ifdef TKSM_ABLATE
+            if (tt > 1) maxdev = max(maxdev, abs(bs - 15));
+#endif
+            cols++;
+            const bool up = code == 0;
+            i -= code != 1 ? 1 : 0;
+            mt += code == 3 ? 1u : 0u;
+            const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
+            pp |= up ? 0ull : (unsigned long long)(opb & modem) << (8 * c8);
+            touched |= !up;
+            dpend = up ? dpend + 1 : 0;
+            tt -= up ? 0 : (int)((cur_sh >> (4 * c8)) & 15u);
+            j -= up ? 0 : 1;
+            go = up || c8 != 0;                           // leaving column c8 == 0 leaves the block
+        }
+        if (touched && J.mode) J.popd8[blk] = pp;
+        wave_sync(); fill_lds(nxt, nsh); wave_sync();
+    };
+    if (mmax > 0) {
+        load_block(topblk, preA, shA);
+        load_block(topblk - 1, preB, shB);
+        fill_lds(preA, shA); wave_sync();
+        for (int blk = topblk; blk >= 0; blk -= 2) {
+            walk_block(blk, preB, shB, preA, shA);
+            if (blk > 0) walk_block(blk - 1, preA, shA, preB, shB);
+        }
+    }
+    if (act && !fail && !needfull && i > 0) { cols += (uint32_t)i; i = 0; }   // column 0: only fragment-only moves remain
+#ifdef TKSM_ABLATE
+    if (ablate == 20 && act) atomicAdd(&devhist[maxdev <= 3 ? 0 : maxdev <= 5 ? 1 : maxdev <= 7 ? 2 : maxdev <= 9 ? 3 : maxdev <= 11 ? 4 : 5], 1u);
+#endif
+    AlnRes R;
+    R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = needfull;
+    return R;
+}
+
+// ---- full-width redo (rare): all 64 rows of every column, 16 bytes per column, 4 columns per LDS block
+DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds) {
     const int p0 = J.p0, n = J.n, m = J.m, mode = J.mode;
     unsigned long long Pv = ~0ull, Mv = 0ull;
-    int t = 1, fbase = -1;
-    unsigned long long fl0 = 0, fl1 = 0, fl2 = 0, fl3 = 0, fh0 = 0, fh1 = 0, fh2 = 0, fh3 = 0, nlo = 0, nhi = 0;
-    unsigned long long flo0 = 0, flo1 = 0, fhi0 = 0, fhi1 = 0;
-    int kxc = -1;
-    uint32_t shw = (act && m > 0) ? J.jsh[0] : 0u;
+    int t = 1;
+    unsigned long long rec = 0ull;
     for (int c = 0; c < mmax; c++) {
-        if ((c & 7) == 0 && act && c < m) {
-            const int nbase = (p0 + t - 1) >> 6;
-            if (nbase != fbase) {
-                fbase = nbase;
-                fl0 = J.fl[nbase]; fl1 = J.fl[nbase + 1]; fl2 = J.fl[nbase + 2]; fl3 = J.fl[nbase + 3];
-                fh0 = J.fh[nbase]; fh1 = J.fh[nbase + 1]; fh2 = J.fh[nbase + 2]; fh3 = J.fh[nbase + 3];
-                kxc = -1;
-            }
-        }
         if (act && c < m) {
-            const int sh = (int)((shw >> (4 * (c & 7))) & 15u);
+            if ((c & 7) == 0) rec = J.jc[c >> 3];
+            const int sh = (int)((lo32(rec) >> (4 * (c & 7))) & 15u);
             t += sh;
             if (sh) { Pv = (Pv >> sh) | (~0ull << (64 - sh)); Mv >>= sh; }
             else if (t > 1) { Pv &= ~1ull; Mv |= 1ull; }
-            const int o = p0 + t - 1, kx = (o >> 6) - fbase, s = o & 63;
-            if (kx != kxc) {                                  // word pair changes only every ~64 columns
-                kxc = kx;
-                flo0 = kx == 0 ? fl0 : (kx == 1 ? fl1 : fl2); flo1 = kx == 0 ? fl1 : (kx == 1 ? fl2 : fl3);
-                fhi0 = kx == 0 ? fh0 : (kx == 1 ? fh1 : fh2); fhi1 = kx == 0 ? fh1 : (kx == 1 ? fh2 : fh3);
-            }
-            // 64-bit funnel shift; s == 0 needs no special case: (x << 1) << 63 drops out
-            const unsigned long long lo = (flo0 >> s) | ((flo1 << 1) << (63 - s));
-            const unsigned long long hi = (fhi0 >> s) | ((fhi1 << 1) << (63 - s));
-            if ((c & 63) == 0) { nlo = J.nl[c >> 6]; nhi = J.nh[c >> 6]; }
-            const unsigned long long cl = 0ull - ((nlo >> (c & 63)) & 1ull), ch = 0ull - ((nhi >> (c & 63)) & 1ull);
-            // rows below the fragment window (i > n) are not masked: they never feed a row above them
+            const int o = p0 + t - 1, w = o >> 6, s = o & 63;
+            const unsigned long long lo = funnel128(J.fp[2 * w], J.fp[2 * w + 2], s), hi = funnel128(J.fp[2 * w + 1], J.fp[2 * w + 3], s);
+            const unsigned long long cl = 0ull - ((rec >> (32 + (c & 7))) & 1ull), ch = 0ull - ((rec >> (40 + (c & 7))) & 1ull);
             const unsigned long long Eq = ~((lo ^ cl) | (hi ^ ch));
             const unsigned long long Xv = Eq | Mv;
             const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
@@ -1355,133 +1510,66 @@ DEV AlnRes aln_pass(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             const unsigned long long is_up = mode ? (upv & ~Ph) : upv;
             const unsigned long long is_left = mode ? Ph : (Ph & ~upv);
             const unsigned long long is_diag = ~(is_up | is_left);
-            const unsigned long long w0 = is_left | (is_diag & D0), w1 = is_diag;
-            if (FULL) { tr_lds[((c & 3) * 64 + lane) * 2] = w0; tr_lds[((c & 3) * 64 + lane) * 2 + 1] = w1; }
-            else {
-                // stored rows: 32 around the generative row, which sits at bit 31 once the window moves (t > 1) and
-                // climbs from bit 0 with the column index while the window is still clamped at row 1
-                const int st = t > 1 ? 16 : max(0, min(16, c - 15));
-                tr_lds[(c & 7) * 64 + lane] = ((w0 >> st) & 0xffffffffull) | ((w1 >> st) << 32);
-            }
+            tr_lds[((c & 3) * 64 + lane) * 2] = is_left | (is_diag & D0);
+            tr_lds[((c & 3) * 64 + lane) * 2 + 1] = is_diag;
         }
-        if ((c & (CB - 1)) == CB - 1 || c == mmax - 1) {
+        if ((c & 3) == 3 || c == mmax - 1) {
             wave_sync();
-            // the next shift word is requested BEFORE the stores: gfx9 counts stores in vmcnt, in issue order
-            uint32_t shn = shw;
-            if ((c & 7) == 7 || c == mmax - 1) shn = (act && c + 1 < m) ? J.jsh[(c + 1) >> 3] : 0u;
-            const int c0 = c & ~(CB - 1);
-            if (FULL) {
-                if (act && c0 < m) {
+            const int c0 = c & ~3;
+            if (act && c0 < m) {
 #pragma unroll
-                    for (int x = 0; x < CB * EW; x++) J.trace[(size_t)c0 * EW + x] = tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)];
-                }
-            } else {
-                // 64 bytes per job, written as whole lines: 4 threads cover one job's 8 columns (transpose through LDS)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int jl = q * 16 + (lane >> 2), part = lane & 3;
-                    const int mj = __shfl(act ? m : 0, jl, 64);
-                    if (c0 < mj) {
-                        ulonglong2 v;
-                        v.x = tr_lds[(2 * part) * 64 + jl]; v.y = tr_lds[(2 * part + 1) * 64 + jl];
-                        *reinterpret_cast<ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)c0 + 2 * part) = v;
-                    }
-                }
+                for (int x = 0; x < 8; x++) J.trace[(size_t)c0 * 2 + x] = tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)];
             }
-            shw = shn;
             wave_sync();
         }
     }
-#ifdef TKSM_ABLATE
-    if (P_ablate == 11) { AlnRes R0; R0.mt = (uint32_t)(Pv ^ Mv); R0.cols = (uint32_t)t; R0.fail = false; R0.needfull = false; return R0; }
-#endif
-    // ---- walk back from (n, m), block by block (uniform block index; every lane walks its own job)
-    AlnRes R;
     int i = n, j = m, tt = t;
     uint32_t mt = 0, cols = 0;
     int dpend = 0;
-    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0), needfull = false;
-    const int topblk = (mmax - 1) >> CSH;
-    unsigned long long pre[CB * EW];
-    uint32_t pre_sh = 0, cur_sh = 0;
-    unsigned long long pp = 0ull;          // op bytes of the current group of 8 columns
-    // block loads / LDS fills: FULL per lane; otherwise whole 64-byte lines, 4 threads per job (transposed in LDS)
-    auto load_block = [&](int blk2) {
-        if (FULL) {
-            const bool have = act && blk2 * CB < m;
-#pragma unroll
-            for (int x = 0; x < CB * EW; x++) pre[x] = have ? J.trace[(size_t)blk2 * CB * EW + x] : 0ull;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int jl = q * 16 + (lane >> 2), part = lane & 3;
-                const int mj = __shfl(act ? m : 0, jl, 64);
-                ulonglong2 v; v.x = 0ull; v.y = 0ull;
-                if (blk2 * CB < mj) v = *reinterpret_cast<const ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)blk2 * CB + 2 * part);
-                pre[2 * q] = v.x; pre[2 * q + 1] = v.y;
-            }
-        }
-        pre_sh = (act && blk2 * CB < m) ? J.jsh[(blk2 * CB) >> 3] : 0u;
-    };
-    auto fill_lds = [&]() {
-        if (FULL) {
-#pragma unroll
-            for (int x = 0; x < CB * EW; x++) tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)] = pre[x];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int jl = q * 16 + (lane >> 2), part = lane & 3;
-                tr_lds[(2 * part) * 64 + jl] = pre[2 * q]; tr_lds[(2 * part + 1) * 64 + jl] = pre[2 * q + 1];
-            }
-        }
-        cur_sh = pre_sh;
-    };
-    if (mmax > 0) { load_block(topblk); fill_lds(); wave_sync(); }
+    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0);
+    const int topblk = (mmax - 1) >> 2;
     const uint32_t modem = mode ? 0xffu : 0u;
+    unsigned long long pp = 0ull;
     bool touched = false;
+    uint32_t cur_sh = 0;
     for (int blk = topblk; blk >= 0 && mmax > 0; blk--) {
-        if (blk > 0) load_block(blk - 1);
-        bool go = act && !fail && !needfull && j > 0 && ((j - 1) >> CSH) == blk;
-        while (__ballot(go)) {
-            const int c8 = (j - 1) & 7, cb = (j - 1) & (CB - 1);
-            const int b = i - tt;
-            int code;
-            if (FULL) {
-                const unsigned long long w0 = tr_lds[(cb * 64 + lane) * 2], w1 = tr_lds[(cb * 64 + lane) * 2 + 1];
-                code = (int)((w0 >> (b & 63)) & 1ull) | ((int)((w1 >> (b & 63)) & 1ull) << 1);
-            } else {
-                const unsigned long long e = tr_lds[cb * 64 + lane];
-                const int st = tt > 1 ? 16 : max(0, min(16, (j - 1) - 15));
-                const int bs = (b - st) & 31;
-                code = (int)((e >> bs) & 1ull) | ((int)((e >> (32 + bs)) & 1ull) << 1);
-                needfull |= go && i > 0 && b >= 0 && b <= 63 && (b < st || b > st + 31);
-            }
-            code = b > 63 ? 0 : code;                     // virtual cell below the window: up
-            code = i == 0 ? 1 : code;                     // row 0: only left
-            fail |= go && ((i > 0 && b < 0) || cols > (uint32_t)(n + m));
-            go = go && !needfull;
-            const bool up = code == 0, colmove = go && !up;
-            const uint32_t g1 = go ? 1u : 0u;
-            cols += g1;
-            i -= (go && code != 1) ? 1 : 0;
-            mt += (go && code == 3) ? 1u : 0u;
-            const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
-            pp |= colmove ? (unsigned long long)(opb & modem) << (8 * c8) : 0ull;
-            touched |= colmove;
-            dpend = colmove ? 0 : dpend + (int)(g1 & (up ? 1u : 0u));
-            tt -= colmove ? (int)((cur_sh >> (4 * c8)) & 15u) : 0;
-            j -= colmove ? 1 : 0;
-            go = go && !fail && j > 0 && ((j - 1) >> CSH) == blk;
+        wave_sync();
+        if (act && blk * 4 < m) {
+#pragma unroll
+            for (int x = 0; x < 8; x++) tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)] = J.trace[(size_t)blk * 8 + x];
+            cur_sh = lo32(J.jc[blk >> 1]);
         }
-        // the op bytes of a group of 8 columns are complete when the walk leaves its lowest block
-        if ((FULL ? (blk & 1) == 0 : true)) {
-            if (touched && mode) J.popd8[FULL ? (blk >> 1) : blk] = pp;
+        wave_sync();
+        bool go = act && !fail && j > 0 && ((j - 1) >> 2) == blk;
+        while (go) {
+            const int c8 = (j - 1) & 7, cb = (j - 1) & 3;
+            const int b = i - tt;
+            const unsigned long long w0 = tr_lds[(cb * 64 + lane) * 2], w1 = tr_lds[(cb * 64 + lane) * 2 + 1];
+            int code = (int)((w0 >> (b & 63)) & 1ull) | ((int)((w1 >> (b & 63)) & 1ull) << 1);
+            code = b > 63 ? 0 : code;
+            code = i == 0 ? 1 : code;
+            if ((i > 0 && b < 0) || cols > (uint32_t)(n + m)) { fail = true; break; }
+            cols++;
+            const bool up = code == 0;
+            i -= code != 1 ? 1 : 0;
+            mt += code == 3 ? 1u : 0u;
+            const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
+            pp |= up ? 0ull : (unsigned long long)(opb & modem) << (8 * c8);
+            touched |= !up;
+            dpend = up ? dpend + 1 : 0;
+            tt -= up ? 0 : (int)((cur_sh >> (4 * c8)) & 15u);
+            j -= up ? 0 : 1;
+            go = up || cb != 0;
+        }
+        // the op bytes of a group of 8 columns are complete when the walk leaves its lower block
+        if ((blk & 1) == 0) {
+            if (touched && mode) J.popd8[blk >> 1] = pp;
             pp = 0ull; touched = false;
         }
-        if (blk > 0) { wave_sync(); fill_lds(); wave_sync(); }
     }
-    if (act && !fail && !needfull && i > 0) { cols += (uint32_t)i; i = 0; }   // column 0: only fragment-only moves remain
-    R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = needfull;
+    if (act && !fail && i > 0) { cols += (uint32_t)i; i = 0; }
+    AlnRes R;
+    R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = false;
     return R;
 }
 
@@ -1500,9 +1588,8 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         const uint32_t* meta = FB.job_meta + 4ull * job;
         r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
     }
-    J.fl = FB.st_fplanes + (size_t)r * 2 * FB.fw; J.fh = J.fl + FB.fw;
-    J.nl = FB.job_n + (size_t)job * 2 * FB.nw; J.nh = J.nl + FB.nw;
-    J.jsh = FB.job_sh + (size_t)job * FB.shw;
+    J.fp = FB.st_fplanes + (size_t)r * 2 * FB.fw;
+    J.jc = FB.job_cols + (size_t)job * FB.cw;
     J.tstride = (size_t)(P.ncap + 16) * 2;
     J.trace = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)job * J.tstride;
     J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)(blockIdx.x * 64u) * J.tstride;
@@ -1510,22 +1597,18 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     int mmax = J.m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
-#ifdef TKSM_PROF
-    if (lane == 0) atomicAdd(&FB.prof[15], 1ull);
-#endif
 #ifdef TKSM_ABLATE
     if (P.ablate == 10) return;
 #endif
-    AlnRes R = aln_pass<false>(J, J.act, mmax, lane, tr_lds, P.ablate);
-    if (__ballot(R.needfull)) {
-#ifdef TKSM_PROF
-        if (lane == 0) { atomicAdd(&FB.prof[13], (unsigned long long)__popcll(__ballot(R.needfull))); atomicAdd(&FB.prof[14], 1ull); }
-#endif
+    AlnRes R = aln_fast(J, mmax, (P.ncap + 7) & ~7, lane, tr_lds, P.ablate, FB.counters + 10);
+    const unsigned long long nf = __ballot(R.needfull);
+    if (nf) {
+        if (lane == 0) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
         const bool redo = J.act && R.needfull;
         int mm2 = redo ? J.m : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
-        const AlnRes R2 = aln_pass<true>(J, redo, mm2, lane, tr_lds, P.ablate);
+        const AlnRes R2 = aln_full(J, redo, mm2, lane, tr_lds);
         if (redo) R = R2;
     }
     if (J.act) {

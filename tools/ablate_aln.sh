@@ -1,7 +1,7 @@
 #!/bin/bash
 # diagnostic: duration of the first k_aln launch when the kernel returns early (10: after meta, 11: after the forward pass)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for a in 10 11 0; do
+for a in ${ABL:-10 11 0}; do
   rm -rf gpurun_out/abl
   TKSMSEQ_ABLATE=$a TKSMSEQ_TAIL_CUT=100000000 TKSMSEQ_LIB=libtksmseq_prof.so rocprofv3 --kernel-trace --output-format csv -d gpurun_out/abl -- python tools/quick_stage_times.py 1048576 > gpurun_out/abl.log 2>&1
   echo run $a done >> gpurun_out/abl_progress.log

@@ -1,4 +1,6 @@
-import sys, os, time, numpy as np
+import sys, os, time, faulthandler, numpy as np
+faulthandler.dump_traceback_later(90, exit=True)
+_t0 = time.time()
 sys.path.insert(0, os.getcwd())
 import torch
 from tksm_amd import synthetic
@@ -16,6 +18,8 @@ rs=np.random.RandomState(2)
 m=synthetic.make_molecules(rs,[16_000_000]*4,B,1000,200)
 b=s.batch_from_arrays(m["reads"],m["intervals"],m["mods"],m["literals"],m["literal_pool"],m["ids"],m["id_pool"])
 s.set_timing(True)
+print('setup %.1f s' % (time.time() - _t0), flush=True)
 for it in range(3):
     t=time.time(); r=s.run(b,target='badread',fastq=True,compute_qual=True,seed=42,first_read_index=it*B); dt=time.time()-t
+    faulthandler.cancel_dump_traceback_later(); faulthandler.dump_traceback_later(90, exit=True)
     print('wall %.1f ms'%(dt*1e3), 'reads/s %.0f'%(B/dt), 'ms: lens %.2f sim %.2f scan %.2f emit %.2f total %.2f | err %.2f aln %.2f other %.2f'%tuple(r.kernel_ms))
