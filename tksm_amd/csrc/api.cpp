@@ -92,7 +92,7 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 2048;
     uint32_t n_buckets = 16;
@@ -567,7 +567,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     } else {
         // ---- fast pipeline: k_init, then rounds of k_err (wave per read) + k_aln (lane per alignment)
         tk::FastBuffers FB{};
-        FB.fw = lcap / 64 + 8; FB.cw = ncap / 8 + 4;
+        FB.fw = lcap / 64 + 8; FB.cw = (ncap / 8 + 8 + 3) & ~3;
         // job-id ranges: ~256 ranges of rs (multiple of 64) consecutive reads of the sorted order
         FB.rs = (uint32_t)((((n + 255) / 256) + 63) & ~63ull);
         FB.n_ranges = (uint32_t)((n + FB.rs - 1) / FB.rs);
@@ -579,11 +579,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
         for (int z = 0; z < 2; z++) {
             HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
-            HIPCHK(ctx, ctx->f_jcols[z].ensure(jcap * (size_t)FB.cw * 8 + 64));
+            HIPCHK(ctx, ctx->f_jcols[z].ensure(jcap * (size_t)FB.cw * 16 + 64));
+            HIPCHK(ctx, ctx->f_jwin[z].ensure(jcap * 16 + 64));
             HIPCHK(ctx, ctx->f_jpopd[z].ensure(jcap * (size_t)ncap + 64));
             HIPCHK(ctx, ctx->f_jobcnt[z].ensure((size_t)FB.n_ranges * 128 + 64));
         }
         HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 4 + 64));
+        HIPCHK(ctx, ctx->f_wsh.ensure(jcap * (size_t)FB.cw * 4 + 64));
         HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
         HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(64));
@@ -592,10 +594,10 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
         FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
-        FB.prefix = ctx->f_prefix.as<uint32_t>();
+        FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.walk_sh = ctx->f_wsh.as<uint32_t>();
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
-            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[z].as<unsigned long long>();
+            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[z].as<uint4>(); FB.job_win = ctx->f_jwin[z].as<unsigned long long>();
             FB.job_popd = ctx->f_jpopd[z].as<uint8_t>(); FB.job_cnt = ctx->f_jobcnt[z].as<uint32_t>();
             FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[y].as<uint8_t>();
         };

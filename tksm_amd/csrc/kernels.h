@@ -107,9 +107,12 @@ struct FastBuffers {
     uint16_t* st_nb;                  // [n_reads][lcap]
     unsigned long long* st_fplanes;   // [n_reads][fw][2] 2-bit planes of the padded fragment, {lo, hi} word pairs
     uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, m}
-    // [n_reads][cw] one record per 8 columns of the joined window: bits 0-31 the 4-bit window shifts of the columns,
-    // bits 32-39 / 40-47 the low / high bit of the columns' 2-bit base codes
-    unsigned long long* job_cols;
+    // [n_reads][cw] one 16-byte record per 8 columns of the joined window: {4-bit window shifts of the columns,
+    // low | high << 8 bits of the columns' 2-bit base codes, low / high code bit of the 32 fragment rows that follow
+    // the window at the start of the block}: k_aln never touches the per-read fragment planes again
+    uint4* job_cols;
+    unsigned long long* job_win;      // [n_reads][2] code planes of the first 64 window rows
+    uint32_t* walk_sh;                // [n_groups][cw][64] shift words per block and lane, written by the forward pass
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
     uint32_t* aln_res;                // [n_reads][4] {matches, columns, fail, -}
     void* trace;                      // [n_groups][ncap + 1][64] x 16 B

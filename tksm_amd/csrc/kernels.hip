@@ -79,6 +79,19 @@ DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+DEV uint32_t lo32(unsigned long long v) { return (uint32_t)v; }
+DEV uint32_t hi32(unsigned long long v) { return (uint32_t)(v >> 32); }
+DEV unsigned long long mk64(uint32_t hi, uint32_t lo) { return ((unsigned long long)hi << 32) | lo; }
+// ({hi, lo} >> s) & 0xffffffff for s in 0..31: one v_alignbit_b32
+DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+// bits [s, s + 64) of the 128-bit value {x1, x0}, s in 0..63
+DEV unsigned long long funnel128(unsigned long long x0, unsigned long long x1, int s) {
+    const bool a = (s & 32) != 0;
+    const uint32_t b = (uint32_t)s & 31u;
+    const uint32_t y0 = a ? hi32(x0) : lo32(x0), y1 = a ? lo32(x1) : hi32(x0), y2 = a ? hi32(x1) : lo32(x1);
+    return mk64(alignbit(y2, y1, b), alignbit(y1, y0, b));
+}
+
 DEV uint8_t ref_base(const RefView& R, uint64_t g) {
     uint32_t ex = R.blocktab[g >> BLOCK_SHIFT];
     if (ex != NO_BLOCK) return R.pool[((uint64_t)ex << BLOCK_SHIFT) + (g & ((1u << BLOCK_SHIFT) - 1))];
@@ -809,7 +822,7 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 //              column) through a small LDS staging area filled with ds_or atomics -- the joined bytes and their
 //              owner array are never materialised;
 //  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
-// Returns the job id (bit 31: the job cannot be represented, shift > 15).
+// Returns the job id (bit 31: the job cannot be represented: a shift > 15 or more than 32 rows within 8 columns).
 DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
                       int p0, int n, int m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
     const int lnw = ncap_l / 64 + 2, lshw = ncap_l / 8 + 16;
@@ -856,12 +869,35 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
     }
     if (build) {
         wave_sync();
-        // one record per 8 columns: {shifts, low code bits, high code bits}; one zero record after the end
-        unsigned long long* jc = FB.job_cols + (size_t)idx * FB.cw;
+        // one record per 8 columns: {shifts, code bits, entering fragment rows}; one zero record after the end
+        uint4* jc = FB.job_cols + (size_t)idx * FB.cw;
         const uint8_t* plb = stage;
+        const unsigned long long* fp = FB.st_fplanes + r * 2ull * FB.fw;
         const int nrec = m / 8 + 2;
-        for (int t = lane; t < nrec; t += 64)
-            jc[t] = (unsigned long long)shn[t] | ((unsigned long long)plb[t] << 32) | ((unsigned long long)plb[8 * lnw + t] << 40);
+        int tcar = 1;                                             // window top at the start of the chunk's first block
+        for (int q = 0; q < nrec; q += 64) {
+            const int t = q + lane;
+            const uint32_t shw = t < nrec ? shn[t] : 0u;
+            const uint32_t x4 = (shw & 0x0f0f0f0fu) + ((shw >> 4) & 0x0f0f0f0fu);
+            const int adv = (int)((x4 * 0x01010101u) >> 24);
+            if (adv > 32) fail = true;                            // more rows than one record carries
+            const int incl = scan_add_incl(adv, lane);
+            const int tk = tcar + incl - adv;                     // window top at the start of block t
+            tcar += __shfl(incl, 63, 64);
+            if (t < nrec) {
+                // fragment rows p0 + tk - 1 + 64 .. + 95 (zero past the padded fragment)
+                const int o = p0 + tk - 1 + 64, w = o >> 6, s2 = o & 63;
+                const uint32_t elo = lo32(funnel128(fp[2 * w], fp[2 * w + 2], s2)), ehi = lo32(funnel128(fp[2 * w + 1], fp[2 * w + 3], s2));
+                uint4 rec;
+                rec.x = shw; rec.y = (uint32_t)plb[t] | ((uint32_t)plb[8 * lnw + t] << 8); rec.z = elo; rec.w = ehi;
+                jc[t] = rec;
+            }
+        }
+        if (lane == 0) {
+            const int w = p0 >> 6, s2 = p0 & 63;
+            FB.job_win[2ull * idx] = funnel128(fp[2 * w], fp[2 * w + 2], s2);
+            FB.job_win[2ull * idx + 1] = funnel128(fp[2 * w + 1], fp[2 * w + 3], s2);
+        }
     }
     return idx | (__ballot(fail) ? 0x80000000u : 0u);
 }
@@ -1257,8 +1293,12 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
 // back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
 struct AlnJob {
     bool act; int p0, n, m, mode;
-    const unsigned long long* fp;    // fragment planes of the read, {lo, hi} word pairs
-    const unsigned long long* jc;    // the job's column records
+    const unsigned long long* fp;    // fragment planes of the read, {lo, hi} word pairs (full-width redo only)
+    const uint4* jc;                 // the job's block records
+    const uint4* jc0;                // records of the wave's first job
+    int cw;                          // records per job
+    ulonglong2 win;                  // code planes of the first 64 window rows
+    uint32_t* wsh0;                  // the wave's [block][lane] shift words for the walk
     unsigned long long* trace;       // per-job region of (ncap + 16) 16-byte columns
     unsigned long long* trace0;      // region of the wave's first job
     size_t tstride;                  // u64 words between consecutive jobs
@@ -1266,131 +1306,100 @@ struct AlnJob {
 };
 struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
 
-DEV uint32_t lo32(unsigned long long v) { return (uint32_t)v; }
-DEV uint32_t hi32(unsigned long long v) { return (uint32_t)(v >> 32); }
-DEV unsigned long long mk64(uint32_t hi, uint32_t lo) { return ((unsigned long long)hi << 32) | lo; }
-// ({hi, lo} >> s) & 0xffffffff for s in 0..31: one v_alignbit_b32
-DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
-// bits [s, s + 64) of the 128-bit value {x1, x0}, s in 0..63
-DEV unsigned long long funnel128(unsigned long long x0, unsigned long long x1, int s) {
-    const bool a = (s & 32) != 0;
-    const uint32_t b = (uint32_t)s & 31u;
-    const uint32_t y0 = a ? hi32(x0) : lo32(x0), y1 = a ? lo32(x1) : hi32(x0), y2 = a ? hi32(x1) : lo32(x1);
-    return mk64(alignbit(y2, y1, b), alignbit(y1, y0, b));
-}
-
 // ---- the common case: 8 bytes of predecessor codes per column (rows 16..47 of the band; the path practically
-// never leaves them).  Written for the vector ALU: every per-column shift is by 0..15, so the 64-bit words are
-// moved with v_alignbit on their halves; the fragment window slides (window + 64 bits of lookahead, refilled once
-// per 8 columns) instead of being re-extracted from the planes; the loop body is branch-free and every memory
-// operation is unconditional, so that the waits on the per-block prefetches do not have to drain the trace stores
-// (gfx9 counts loads and stores in one counter, in issue order).
-// A lane whose walk needs a row outside the stored 32 reports needfull (redone by aln_full); a lane whose window
-// moves by more than 64 rows within 8 columns reports fail (the read goes to the exact wave-wide path).
-DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned long long* tr_lds, int ablate, uint32_t* devhist) {
+// never leaves them).  Written for the vector ALU and for the memory system:
+//  * every per-column shift is by 0..15, so the 64-bit words are moved with v_alignbit on their halves; the fragment
+//    window slides, fed by the 32 entering rows each block record carries, instead of being re-extracted from the
+//    per-read planes (330 k concurrent jobs each touching its own plane and record lines thrash the L2);
+//  * everything a lane reads or writes in HBM moves as whole 64-byte lines, 4 threads per job, transposed through
+//    LDS: block records one group of 32 columns ahead, predecessor codes per 8 columns;
+//  * the loop body is branch-free and every memory operation is unconditional, so the waits on the prefetches do
+//    not have to drain the trace stores (gfx9 counts loads and stores in one counter, in issue order).
+// A lane whose walk needs a row outside the stored 32 reports needfull (redone by aln_full).
+DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned long long* tr_lds, uint4* rec_lds, int ablate,
+                    uint32_t* devhist) {
     const bool act = J.act;
-    const int p0 = J.p0, n = J.n, m = J.m;
+    const int n = J.n, m = J.m;
     const unsigned long long M64 = J.mode ? ~0ull : 0ull;
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1;
-    bool bandfail = false;
-    unsigned long long A, LA, B, LB;             // low / high code plane: window rows and the 64 rows after them
-    auto nibsum = [](uint32_t w) -> int {
-        const uint32_t x4 = (w & 0x0f0f0f0fu) + ((w >> 4) & 0x0f0f0f0fu);
-        return (int)((x4 * 0x01010101u) >> 24);
-    };
-    // records of the current and the next block of 8 columns (zero after the end of the job)
-    unsigned long long recC = (act && m > 0) ? J.jc[0] : 0ull, recN = (act && m > 8) ? J.jc[1] : 0ull;
-    ulonglong2 pfA0, pfA1, pfB0, pfB1;           // lookahead words in flight: two sets, two blocks deep
-    {
-        const int w = p0 >> 6, s = p0 & 63;
-        const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w);
-        const ulonglong2 q1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 2);
-        const ulonglong2 q2 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 4);
-        A = funnel128(q0.x, q1.x, s); LA = funnel128(q1.x, q2.x, s);
-        B = funnel128(q0.y, q1.y, s); LB = funnel128(q1.y, q2.y, s);
-        const int w1 = (p0 + nibsum(lo32(recC)) + 64) >> 6;
-        pfA0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w1);
-        pfA1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w1 + 2);
-    }
-    int mjq[4];                                  // lengths of the jobs this lane stores trace lines for
+    unsigned long long A = J.win.x, B = J.win.y;                  // low / high code plane of the window rows
+    int mjq[4];                                                   // lengths of the jobs this lane moves lines for
 #pragma unroll
     for (int q = 0; q < 4; q++) mjq[q] = __shfl(act ? m : 0, q * 16 + (lane >> 2), 64);
-    // one block of 8 columns; pfc = lookahead words for the refill at its end (requested one block earlier),
-    // pfn = the set to request now for the refill at the end of the next block
-    auto block = [&](int c0, const ulonglong2& pfc0, const ulonglong2& pfc1, ulonglong2& pfn0, ulonglong2& pfn1) {
-        const uint32_t shw = lo32(recC), nbits = hi32(recC);
-        const int adv = nibsum(shw);             // rows the window moves in this block
-        bandfail |= adv > 64;
-        const int o1 = p0 + t - 1 + adv, o2 = o1 + nibsum(lo32(recN));
-        const int wn = (o2 + 64) >> 6;
-#ifdef TKSM_ABLATE
-        if (ablate == 13 || ablate == 14) { pfn0.x = recC; pfn0.y = ~recC; pfn1.x = recC * 3; pfn1.y = recC * 5; } else
-#endif
-        {
-            pfn0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * wn);
-            pfn1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * wn + 2);
-        }
-        const unsigned long long recF = J.jc[(c0 >> 3) + 2];
+    // Job records travel in groups of 4 (32 columns, one 64-byte line per job): whole lines are loaded by 4 threads
+    // per job one group ahead and handed to the owning lanes through LDS
+    uint4 rg[4];
+    auto load_group = [&](int g) {
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const uint32_t sh = (shw >> (4 * x)) & 15u;
-            t += (int)sh;
-            const bool g = t > 1;
-            // window moves down by sh rows: entering rows take vertical delta +1
-            Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh));
-            Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh));
-            const unsigned long long f = (sh == 0u && g) ? 1ull : 0ull;   // window did not move: top row only from the left
-            Pv &= ~f; Mv |= f;
-            A = mk64(alignbit(lo32(LA), hi32(A), sh), alignbit(hi32(A), lo32(A), sh));
-            LA = mk64(hi32(LA) >> sh, alignbit(hi32(LA), lo32(LA), sh));
-            B = mk64(alignbit(lo32(LB), hi32(B), sh), alignbit(hi32(B), lo32(B), sh));
-            LB = mk64(hi32(LB) >> sh, alignbit(hi32(LB), lo32(LB), sh));
-            const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
-            const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
-            // rows below the fragment (i > n) are not masked: they never feed a row above them
-            const unsigned long long Eq = ~((A ^ mk64(cl, cl)) | (B ^ mk64(ch, ch)));
-            const unsigned long long Xv = Eq | Mv;
-            const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-            const unsigned long long Ph = Mv | ~(Xh | Pv);
-            const unsigned long long Mh = Pv & Xh;
-            const unsigned long long D0 = Xh | Mv;
-            const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
-            const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
-            Pv = Mhs | ~(Xv | Phs);
-            Mv = Phs & Xv;
-            const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
-            // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal
-            const unsigned long long w1 = ~(upv | Ph);
-            const unsigned long long w0 = (Ph & (~upv | M64)) | (w1 & D0);
-            // stored rows: 32 around the generative row, which sits at bit 31 once the window moves (t > 1) and
-            // climbs from bit 0 with the column index while the window is still clamped at row 1
-            const uint32_t st = g ? 16u : (uint32_t)max(0, min(16, c0 + x - 15));
-            tr_lds[x * 64 + lane] = mk64(alignbit(hi32(w1), lo32(w1), st), alignbit(hi32(w0), lo32(w0), st));
-        }
-        wave_sync();
-        // 64 bytes per job, written as whole lines: 4 threads cover one job's 8 columns (transpose through LDS);
-        // lines of jobs that have already ended go to the spare columns at the end of the job's own region
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int jl = q * 16 + (lane >> 2), part = lane & 3;
-            ulonglong2 v;
-            v.x = tr_lds[(2 * part) * 64 + jl]; v.y = tr_lds[(2 * part + 1) * 64 + jl];
-            const int col = c0 < mjq[q] ? c0 : spare_col;
-#ifdef TKSM_ABLATE
-            if (ablate == 12 || ablate == 14) { if (v.x == 0x1234567ull) J.trace0[0] = v.y; } else
-#endif
-            *reinterpret_cast<ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)col + 2 * part) = v;
-        }
-        wave_sync();
-        LA = funnel128(pfc0.x, pfc1.x, o1 & 63);
-        LB = funnel128(pfc0.y, pfc1.y, o1 & 63);
-        recC = recN;
-        recN = (act && c0 + 16 < m) ? recF : 0ull;
+        for (int q = 0; q < 4; q++) rg[q] = J.jc0[(size_t)(q * 16 + (lane >> 2)) * J.cw + 4 * g + (lane & 3)];
     };
-    for (int c0 = 0; c0 < mmax; c0 += 16) {
-        block(c0, pfA0, pfA1, pfB0, pfB1);
-        block(c0 + 8, pfB0, pfB1, pfA0, pfA1);   // may lie past the last column: all shifts zero, lines to the spare columns
+    auto stage_group = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) rec_lds[(lane & 3) * 64 + q * 16 + (lane >> 2)] = rg[q];
+    };
+    load_group(0); stage_group(); wave_sync();
+    for (int c0 = 0; c0 < mmax; c0 += 32) {
+        load_group((c0 >> 5) + 1);
+#pragma unroll
+        for (int bq = 0; bq < 4; bq++) {
+            const int cb = c0 + 8 * bq;
+            uint4 rec = rec_lds[bq * 64 + lane];
+            if (!(act && cb < m)) { rec.x = 0u; rec.y = 0u; rec.z = 0u; rec.w = 0u; }
+            const uint32_t shw = rec.x, nbits = rec.y;
+            uint32_t EA = rec.z, EB = rec.w;                      // the 32 rows after the window
+            J.wsh0[(size_t)(cb >> 3) * 64 + lane] = shw;          // shift words for the walk, one coalesced line per block
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                const uint32_t sh = (shw >> (4 * x)) & 15u;
+                t += (int)sh;
+                const bool g = t > 1;
+                // window moves down by sh rows: entering rows take vertical delta +1
+                Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh));
+                Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh));
+                const unsigned long long f = (sh == 0u && g) ? 1ull : 0ull;   // window did not move: top row only from the left
+                Pv &= ~f; Mv |= f;
+                A = mk64(alignbit(EA, hi32(A), sh), alignbit(hi32(A), lo32(A), sh)); EA >>= sh;
+                B = mk64(alignbit(EB, hi32(B), sh), alignbit(hi32(B), lo32(B), sh)); EB >>= sh;
+                const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
+                const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
+                // rows below the fragment (i > n) are not masked: they never feed a row above them
+                const unsigned long long Eq = ~((A ^ mk64(cl, cl)) | (B ^ mk64(ch, ch)));
+                const unsigned long long Xv = Eq | Mv;
+                const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                const unsigned long long Ph = Mv | ~(Xh | Pv);
+                const unsigned long long Mh = Pv & Xh;
+                const unsigned long long D0 = Xh | Mv;
+                const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
+                const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
+                Pv = Mhs | ~(Xv | Phs);
+                Mv = Phs & Xv;
+                const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
+                // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal
+                const unsigned long long w1 = ~(upv | Ph);
+                const unsigned long long w0 = (Ph & (~upv | M64)) | (w1 & D0);
+                // stored rows: 32 around the generative row, which sits at bit 31 once the window moves (t > 1) and
+                // climbs from bit 0 with the column index while the window is still clamped at row 1
+                const uint32_t st = g ? 16u : (uint32_t)max(0, min(16, cb + x - 15));
+                tr_lds[x * 64 + lane] = mk64(alignbit(hi32(w1), lo32(w1), st), alignbit(hi32(w0), lo32(w0), st));
+            }
+            wave_sync();
+            // 64 bytes per job, written as whole lines: 4 threads cover one job's 8 columns (transpose through LDS);
+            // lines of jobs that have already ended go to the spare columns at the end of the job's own region
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int jl = q * 16 + (lane >> 2), part = lane & 3;
+                ulonglong2 v;
+                v.x = tr_lds[(2 * part) * 64 + jl]; v.y = tr_lds[(2 * part + 1) * 64 + jl];
+                const int col = cb < mjq[q] ? cb : spare_col;
+#ifdef TKSM_ABLATE
+                if (ablate == 12 || ablate == 14) { if (v.x == 0x1234567ull) J.trace0[0] = v.y; } else
+#endif
+                *reinterpret_cast<ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)col + 2 * part) = v;
+            }
+            wave_sync();
+        }
+        stage_group(); wave_sync();
     }
 #ifdef TKSM_ABLATE
     if (ablate >= 11 && ablate <= 19) { AlnRes R0; R0.mt = (uint32_t)(Pv ^ Mv); R0.cols = (uint32_t)t; R0.fail = false; R0.needfull = false; return R0; }
@@ -1399,7 +1408,7 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
     int i = n, j = m, tt = t;
     uint32_t mt = 0, cols = 0;
     int dpend = 0;
-    bool fail = act && (bandfail || (m > 0 && (n - tt > 63 || n - tt < 0))), needfull = false;
+    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0), needfull = false;
     const int topblk = (mmax - 1) >> 3;
     const uint32_t lim = (uint32_t)(n + m);
     const uint32_t modem = J.mode ? 0xffu : 0u;
@@ -1414,7 +1423,7 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
             const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)blk2 * 8 + 2 * part);
             pre[2 * q] = v.x; pre[2 * q + 1] = v.y;
         }
-        psh = lo32(J.jc[blk2]);
+        psh = J.wsh0[(size_t)blk2 * 64 + lane];
     };
     auto fill_lds = [&](const unsigned long long* pre, uint32_t psh) {
 #pragma unroll
@@ -1488,7 +1497,7 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
     unsigned long long rec = 0ull;
     for (int c = 0; c < mmax; c++) {
         if (act && c < m) {
-            if ((c & 7) == 0) rec = J.jc[c >> 3];
+            if ((c & 7) == 0) { const uint4 q4 = J.jc[c >> 3]; rec = mk64(q4.y, q4.x); }
             const int sh = (int)((lo32(rec) >> (4 * (c & 7))) & 15u);
             t += sh;
             if (sh) { Pv = (Pv >> sh) | (~0ull << (64 - sh)); Mv >>= sh; }
@@ -1537,7 +1546,7 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
         if (act && blk * 4 < m) {
 #pragma unroll
             for (int x = 0; x < 8; x++) tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)] = J.trace[(size_t)blk * 8 + x];
-            cur_sh = lo32(J.jc[blk >> 1]);
+            cur_sh = J.jc[blk >> 1].x;
         }
         wave_sync();
         bool go = act && !fail && j > 0 && ((j - 1) >> 2) == blk;
@@ -1575,6 +1584,7 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
 
 __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
     __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
+    __shared__ uint4 rec_lds[4 * 64];               // 4 KB: the current group of 4 block records per lane
     const int lane = threadIdx.x;
     const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;          // wave-aligned ranges of rs ids
     const uint32_t rng = job / FB.rs;
@@ -1590,6 +1600,10 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     }
     J.fp = FB.st_fplanes + (size_t)r * 2 * FB.fw;
     J.jc = FB.job_cols + (size_t)job * FB.cw;
+    J.jc0 = FB.job_cols + (size_t)(blockIdx.x * 64u) * FB.cw; J.cw = FB.cw;
+    J.win.x = 0ull; J.win.y = 0ull;
+    if (J.act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
+    J.wsh0 = FB.walk_sh + (size_t)blockIdx.x * FB.cw * 64;
     J.tstride = (size_t)(P.ncap + 16) * 2;
     J.trace = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)job * J.tstride;
     J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)(blockIdx.x * 64u) * J.tstride;
@@ -1600,7 +1614,7 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
 #ifdef TKSM_ABLATE
     if (P.ablate == 10) return;
 #endif
-    AlnRes R = aln_fast(J, mmax, (P.ncap + 7) & ~7, lane, tr_lds, P.ablate, FB.counters + 10);
+    AlnRes R = aln_fast(J, mmax, (P.ncap + 7) & ~7, lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
     const unsigned long long nf = __ballot(R.needfull);
     if (nf) {
         if (lane == 0) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
