@@ -128,13 +128,17 @@ def _make_molecules(rs, ref, n, mean_len, literal=True):
     return mols
 
 
-@pytest.mark.parametrize("path", ["fast", "slow"])
+@pytest.mark.parametrize("path", ["fast", "fast-small", "slow"])
 @pytest.mark.parametrize("mean_len,n,compute_q", [(300, 96, True), (1000, 64, True), (1000, 32, False), (2600, 24, True)])
 def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n, compute_q, path):
     """whole records of the stochastic path, GPU vs oracle, same (seed, read index).  mean_len 2600 exercises
-    the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = k_err + bit-parallel
-    k_aln (reads touching N / IUPAC bytes still take the wave-wide kernel), "slow" = wave-wide kernel for all."""
+    the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = k_err per length bucket +
+    k_aln with 8-byte predecessor columns and full-width redo (what large batches run; reads touching N / IUPAC bytes
+    still take the wave-wide kernel), "fast-small" = the latency-bound variant small rounds switch to (one k_err launch,
+    full-width k_aln), "slow" = wave-wide kernel for all."""
     monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
+    if path == "fast":
+        monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_TAIL_CUT", "0")
     s, ref, rs = _random_genome_seqr()
     s.set_identity(84.0, 99.0, 5.5)
     s.load_error_model(ERR_MODEL)
@@ -210,17 +214,31 @@ def test_full_size_properties_and_shard_invariance():
     s = Sequencer(0)
     rs = np.random.RandomState(11)
     lens = [4_000_000] * 4
-    for c, n in enumerate(lens):
-        s.add_contig(f"chr{c + 1}", rs.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes())
-    s.set_identity(84.0, 99.0, 5.5)
-    s.load_error_model(ERR_MODEL)
-    s.load_qscore_model(QS_MODEL)
+    contigs = [rs.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes() for n in lens]
+
+    def setup(sq):
+        for c, seq in enumerate(contigs):
+            sq.add_contig(f"chr{c + 1}", seq)
+        sq.set_identity(84.0, 99.0, 5.5)
+        sq.load_error_model(ERR_MODEL)
+        sq.load_qscore_model(QS_MODEL)
+    setup(s)
     n = 131072
     m = synthetic.make_molecules(rs, lens, n, 1000, 200)
     b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
     rec1, off1 = s.run(b, seed=5).download()
     rec2, _ = s.run(b, seed=5).download()
     assert rec1 == rec2                                                   # deterministic
+    # the same batch with every alignment at full width and no tail cut: the 8-byte predecessor columns + redo,
+    # the launch grouping and the tail hand-over to the wave-wide kernel do not change a byte
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("TKSMSEQ_SMALL_ALN", str(1 << 30)); mp.setenv("TKSMSEQ_SMALL_ROUND", str(1 << 30)); mp.setenv("TKSMSEQ_TAIL_CUT", "0")
+        s3 = Sequencer(0)
+    setup(s3)
+    b3 = s3.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+    rec3, _ = s3.run(b3, seed=5).download()
+    assert rec3 == rec1
+    s3.close()
     assert len(off1) == n + 1 and int(off1[-1]) == len(rec1)
     lines = rec1.split(b"\n")
     assert len(lines) == 4 * n + 1

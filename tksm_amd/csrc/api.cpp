@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <string>
 
 #include "host.h"
@@ -95,6 +96,7 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 2048;
+    uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
     uint32_t n_buckets = 16;
     std::vector<hipEvent_t> evpool;
     uint32_t last_rounds = 0, last_slow = 0;
@@ -135,6 +137,8 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     c->device = device;
     if (const char* fs = getenv("TKSMSEQ_FORCE_SLOW")) c->force_slow = fs[0] == '1';
     if (const char* tc = getenv("TKSMSEQ_TAIL_CUT")) c->tail_cut = (uint32_t)atoi(tc);
+    if (const char* tc = getenv("TKSMSEQ_SMALL_ROUND")) c->small_round = (uint32_t)atoi(tc);
+    if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
     if (const char* nbk = getenv("TKSMSEQ_BUCKETS")) c->n_buckets = (uint32_t)std::max(1, atoi(nbk));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -479,6 +483,12 @@ int tksmseq_set_output_buffer(tksmseq_ctx* ctx, void* p, uint64_t cap) {
     return TKSMSEQ_OK;
 }
 
+// Contexts on the same device may be driven from different threads.  A run is bandwidth/occupancy-bound while most
+// reads are still in the error loop and latency-bound afterwards (few reads, one short round after the other): the
+// runs of different contexts take turns in the first phase and leave it as soon as they enter the second, so that the
+// tail of one batch executes underneath the bulk of the next.
+static std::mutex g_bulk_phase[64];
+
 static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params* p, int cap_num, int cap_den, int cap_add,
                     tksmseq_result* res, bool* overflow) {
     *overflow = false;
@@ -486,6 +496,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     hipStream_t s = ctx->stream;
     const bool badread = p->mode == TKSMSEQ_MODE_BADREAD;
     const int k = badread ? ctx->em.k : 0;
+    std::unique_lock<std::mutex> bulk(g_bulk_phase[ctx->device & 63]);
     auto align16 = [](uint64_t v) { return (v + 15) & ~15ull; };
     auto capf = [&](uint64_t raw) { return align16((raw + 2 * (uint64_t)k) * cap_num / cap_den + cap_add); };
     if (b->cache_k != k || b->cache_num != cap_num || b->cache_den != cap_den || b->cache_add != cap_add) {
@@ -659,6 +670,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, 0, 0, 0, bk.wpw, s));
             } else {
                 // one wave per job of the previous round; ranges are chunks of the sorted order, so a bucket is a run of ranges
+                const uint32_t total = hprefix[FB.n_ranges];
+                if (total <= ctx->small_round) {
+                    // few reads left: the round is bound by launch and single-wave latency, not by occupancy -- one
+                    // launch with the geometry of the longest bucket instead of one per bucket
+                    const Bucket& bk = buckets.back();
+                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, total, bk.lcap, bk.ncap, 1, 0, FB.n_ranges, bk.wpw, s));
+                } else {
                 size_t bi = 0;
                 uint32_t c = 0;
                 while (c < FB.n_ranges) {
@@ -675,6 +693,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                         HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, buckets[bi].ncap, 1, c, c1, buckets[bi].wpw, s));
                     c = c1;
                 }
+                }
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(1);
@@ -686,6 +705,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             hprefix[FB.n_ranges] = cnt[0];
             HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hprefix.data(), hprefix.size() * 4, hipMemcpyHostToDevice, s));
             if (cnt[0] == 0) break;
+            if (bulk.owns_lock() && cnt[0] * 16ull < n) bulk.unlock();      // latency-bound from here on
             if (cnt[0] < ctx->tail_cut && cnt[0] * 64ull < n) {
                 // tail: every further round costs a full alignment latency for a handful of reads; finish the
                 // stragglers in one launch of the wave-wide kernel instead (same results: it recomputes them)
@@ -697,7 +717,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            HIPCHK(ctx, tk::launch_aln(P, FB, (uint32_t)jcap, s));
+            HIPCHK(ctx, tk::launch_aln(P, FB, (uint32_t)jcap, cnt[0] <= ctx->small_aln, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
         }

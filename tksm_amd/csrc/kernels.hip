@@ -1491,21 +1491,28 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
 
 // ---- full-width redo (rare): all 64 rows of every column, 16 bytes per column, 4 columns per LDS block
 DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds) {
-    const int p0 = J.p0, n = J.n, m = J.m, mode = J.mode;
+    const int n = J.n, m = J.m, mode = J.mode;
+    const unsigned long long M64 = mode ? ~0ull : 0ull;
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1;
-    unsigned long long rec = 0ull;
+    unsigned long long A = J.win.x, B = J.win.y;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rec = zero4, recn = (act && m > 0) ? J.jc[0] : zero4;
+    uint32_t EA = 0u, EB = 0u;
     for (int c = 0; c < mmax; c++) {
         if (act && c < m) {
-            if ((c & 7) == 0) { const uint4 q4 = J.jc[c >> 3]; rec = mk64(q4.y, q4.x); }
-            const int sh = (int)((lo32(rec) >> (4 * (c & 7))) & 15u);
-            t += sh;
-            if (sh) { Pv = (Pv >> sh) | (~0ull << (64 - sh)); Mv >>= sh; }
-            else if (t > 1) { Pv &= ~1ull; Mv |= 1ull; }
-            const int o = p0 + t - 1, w = o >> 6, s = o & 63;
-            const unsigned long long lo = funnel128(J.fp[2 * w], J.fp[2 * w + 2], s), hi = funnel128(J.fp[2 * w + 1], J.fp[2 * w + 3], s);
-            const unsigned long long cl = 0ull - ((rec >> (32 + (c & 7))) & 1ull), ch = 0ull - ((rec >> (40 + (c & 7))) & 1ull);
-            const unsigned long long Eq = ~((lo ^ cl) | (hi ^ ch));
+            if ((c & 7) == 0) { rec = recn; EA = rec.z; EB = rec.w; recn = c + 8 < m ? J.jc[(c >> 3) + 1] : zero4; }
+            const uint32_t sh = (rec.x >> (4 * (c & 7))) & 15u;
+            t += (int)sh;
+            const bool g = t > 1;
+            Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh));
+            Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh));
+            const unsigned long long f = (sh == 0u && g) ? 1ull : 0ull;
+            Pv &= ~f; Mv |= f;
+            A = mk64(alignbit(EA, hi32(A), sh), alignbit(hi32(A), lo32(A), sh)); EA >>= sh;
+            B = mk64(alignbit(EB, hi32(B), sh), alignbit(hi32(B), lo32(B), sh)); EB >>= sh;
+            const uint32_t cl = 0u - ((rec.y >> (c & 7)) & 1u), ch = 0u - ((rec.y >> (8 + (c & 7))) & 1u);
+            const unsigned long long Eq = ~((A ^ mk64(cl, cl)) | (B ^ mk64(ch, ch)));
             const unsigned long long Xv = Eq | Mv;
             const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             const unsigned long long Ph = Mv | ~(Xh | Pv);
@@ -1514,24 +1521,14 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             const unsigned long long Phs = (Ph << 1) | 1ull, Mhs = Mh << 1;
             Pv = Mhs | ~(Xv | Phs);
             Mv = Phs & Xv;
-            unsigned long long upv = Pv;
-            if (t > 1) upv &= ~1ull;
-            const unsigned long long is_up = mode ? (upv & ~Ph) : upv;
-            const unsigned long long is_left = mode ? Ph : (Ph & ~upv);
-            const unsigned long long is_diag = ~(is_up | is_left);
-            tr_lds[((c & 3) * 64 + lane) * 2] = is_left | (is_diag & D0);
-            tr_lds[((c & 3) * 64 + lane) * 2 + 1] = is_diag;
-        }
-        if ((c & 3) == 3 || c == mmax - 1) {
-            wave_sync();
-            const int c0 = c & ~3;
-            if (act && c0 < m) {
-#pragma unroll
-                for (int x = 0; x < 8; x++) J.trace[(size_t)c0 * 2 + x] = tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)];
-            }
-            wave_sync();
+            const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
+            ulonglong2 w;
+            w.y = ~(upv | Ph);                                    // diagonal
+            w.x = (Ph & (~upv | M64)) | (w.y & D0);               // left | diagonal match
+            *reinterpret_cast<ulonglong2*>(J.trace + 2 * (size_t)c) = w;
         }
     }
+    // walk back: every lane on its own job, 4 columns (64 bytes) per block, next block requested one block ahead
     int i = n, j = m, tt = t;
     uint32_t mt = 0, cols = 0;
     int dpend = 0;
@@ -1540,15 +1537,23 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
     const uint32_t modem = mode ? 0xffu : 0u;
     unsigned long long pp = 0ull;
     bool touched = false;
-    uint32_t cur_sh = 0;
+    uint32_t cur_sh = 0, pre_sh = 0;
+    unsigned long long pre[8];
+    auto loadb = [&](int blk2) {
+        const bool have = act && blk2 >= 0 && blk2 * 4 < m;
+#pragma unroll
+        for (int x = 0; x < 8; x++) pre[x] = have ? J.trace[(size_t)blk2 * 8 + x] : 0ull;
+        pre_sh = have ? J.jc[blk2 >> 1].x : 0u;
+    };
+    wave_sync();
+    loadb(topblk);
     for (int blk = topblk; blk >= 0 && mmax > 0; blk--) {
         wave_sync();
-        if (act && blk * 4 < m) {
 #pragma unroll
-            for (int x = 0; x < 8; x++) tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)] = J.trace[(size_t)blk * 8 + x];
-            cur_sh = J.jc[blk >> 1].x;
-        }
+        for (int x = 0; x < 8; x++) tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)] = pre[x];
+        cur_sh = pre_sh;
         wave_sync();
+        loadb(blk - 1);
         bool go = act && !fail && j > 0 && ((j - 1) >> 2) == blk;
         while (go) {
             const int c8 = (j - 1) & 7, cb = (j - 1) & 3;
@@ -1582,6 +1587,9 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
     return R;
 }
 
+// FULL_ONLY: rounds with few jobs are bound by the latency of one lane's pass; they go straight to the full-width
+// pass (no redo to wait for, traffic is irrelevant)
+template <bool FULL_ONLY>
 __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
     __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
     __shared__ uint4 rec_lds[4 * 64];               // 4 KB: the current group of 4 block records per lane
@@ -1614,16 +1622,20 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
 #ifdef TKSM_ABLATE
     if (P.ablate == 10) return;
 #endif
-    AlnRes R = aln_fast(J, mmax, (P.ncap + 7) & ~7, lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
-    const unsigned long long nf = __ballot(R.needfull);
-    if (nf) {
-        if (lane == 0) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
-        const bool redo = J.act && R.needfull;
-        int mm2 = redo ? J.m : 0;
+    AlnRes R;
+    if (FULL_ONLY) R = aln_full(J, J.act, mmax, lane, tr_lds);
+    else {
+        R = aln_fast(J, mmax, (P.ncap + 7) & ~7, lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
+        const unsigned long long nf = __ballot(R.needfull);
+        if (nf) {
+            if (lane == 0) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
+            const bool redo = J.act && R.needfull;
+            int mm2 = redo ? J.m : 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
-        const AlnRes R2 = aln_full(J, redo, mm2, lane, tr_lds);
-        if (redo) R = R2;
+            for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
+            const AlnRes R2 = aln_full(J, redo, mm2, lane, tr_lds);
+            if (redo) R = R2;
+        }
     }
     if (J.act) {
         ReadState* st = FB.state + r;
@@ -1838,9 +1850,10 @@ hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hi
     hipLaunchKernelGGL(k_collect_unfinished, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, fb, n_reads);
     return hipGetLastError();
 }
-hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, hipStream_t s) {
+hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, hipStream_t s) {
     if (!n_jobs) return hipSuccess;
-    hipLaunchKernelGGL(k_aln, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
+    if (full_only) hipLaunchKernelGGL(k_aln<true>, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
+    else hipLaunchKernelGGL(k_aln<false>, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
     return hipGetLastError();
 }
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records, hipStream_t s) {
