@@ -72,6 +72,8 @@ struct tksmseq_ctx : ContigLookup {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;            // wave-wide kernel for reads classified at k_init, underneath the rounds
+    hipEvent_t side_ev[2] = {};
     bool own_stream = false;
     std::string err;
 
@@ -95,7 +97,7 @@ struct tksmseq_ctx : ContigLookup {
     // fast Badread pipeline state (see kernels.h FastBuffers)
     DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
-    uint32_t tail_cut = 2048;
+    uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
     uint32_t n_buckets = 16;
     std::vector<hipEvent_t> evpool;
@@ -156,6 +158,8 @@ void tksmseq_destroy(tksmseq_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->evpool) (void)hipEventDestroy(ev);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    for (auto& ev : ctx->side_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -595,8 +599,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, ctx->f_jpopd[z].ensure(jcap * (size_t)ncap + 64));
             HIPCHK(ctx, ctx->f_jobcnt[z].ensure((size_t)FB.n_ranges * 128 + 64));
         }
-        HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 4 + 64));
-        HIPCHK(ctx, ctx->f_wsh.ensure(jcap * (size_t)FB.cw * 4 + 64));
+        HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
+        HIPCHK(ctx, ctx->f_wsh.ensure(jcap * (size_t)FB.cw * 8 + 64));
         HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
         HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(64));
@@ -605,7 +609,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
         FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
-        FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.walk_sh = ctx->f_wsh.as<uint32_t>();
+        FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
+        FB.walk_sh = ctx->f_wsh.as<uint32_t>();
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
             FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[z].as<uint4>(); FB.job_win = ctx->f_jwin[z].as<unsigned long long>();
@@ -613,7 +618,14 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[y].as<uint8_t>();
         };
         select_set(0);
-        std::vector<uint32_t> hprefix(FB.n_ranges + 1, 0);
+        // host copy of {prefix, base_prev, base_cur}, uploaded before every round
+        const size_t nr1 = FB.n_ranges + 1;
+        std::vector<uint32_t> hgeo(3 * nr1, 0);
+        uint32_t* hprefix = hgeo.data();
+        uint32_t* hbase_prev = hgeo.data() + nr1;
+        uint32_t* hbase_cur = hgeo.data() + 2 * nr1;
+        for (uint32_t c = 0; c <= FB.n_ranges; c++) hbase_cur[c] = hbase_prev[c] = c * FB.rs;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
         HIPCHK(ctx, ctx->f_svi.ensure(n * 128 + 64));
         HIPCHK(ctx, ctx->f_svk.ensure(n * 64 + 64));
         HIPCHK(ctx, ctx->f_sva.ensure(n * 512 + 64));
@@ -659,6 +671,28 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         kinds.push_back(0);
         uint32_t cnt[4] = {0, 0, 0, 0};
+        // reads with non-ACGT bytes are known after k_init: their wave-wide kernel (latency-bound, a few waves) starts
+        // now on a second stream and runs underneath the rounds
+        uint32_t n_side = 0;
+        HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        if (cnt[2]) {
+            n_side = cnt[2];
+            if (!ctx->side) {
+                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
+            }
+            tk::SimBuffers O2 = O;
+            O2.read_list = ctx->f_slow.as<uint32_t>(); O2.n_work = n_side;
+            O2.work_counter = ctx->w_counter.as<unsigned long long>() + 1;
+            HIPCHK(ctx, hipEventRecord(ctx->side_ev[0], s));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[0], 0));
+            HIPCHK(ctx, hipMemsetAsync((void*)O2.work_counter, 0, 8, ctx->side));
+            const uint64_t want2 = (n_side + wpw - 1) / wpw;
+            HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O2, (int)std::max<uint64_t>(1, std::min<uint64_t>(want2, (uint64_t)n_wgs)), wpw, ctx->side));
+            HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], ctx->side));
+        }
         uint32_t rounds = 0;
         for (;; rounds++) {
             select_set(rounds);
@@ -671,7 +705,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             } else {
                 // one wave per job of the previous round; ranges are chunks of the sorted order, so a bucket is a run of ranges
                 const uint32_t total = hprefix[FB.n_ranges];
-                if (total <= ctx->small_round) {
+                if (total <= ctx->small_round || total * 16ull < n) {
                     // few reads left: the round is bound by launch and single-wave latency, not by occupancy -- one
                     // launch with the geometry of the longest bucket instead of one per bucket
                     const Bucket& bk = buckets.back();
@@ -703,7 +737,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             cnt[0] = 0;
             for (uint32_t c = 0; c < FB.n_ranges; c++) { hprefix[c] = cnt[0]; cnt[0] += hcnt[(size_t)c * 32]; }
             hprefix[FB.n_ranges] = cnt[0];
-            HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hprefix.data(), hprefix.size() * 4, hipMemcpyHostToDevice, s));
             if (cnt[0] == 0) break;
             if (bulk.owns_lock() && cnt[0] * 16ull < n) bulk.unlock();      // latency-bound from here on
             if (cnt[0] < ctx->tail_cut && cnt[0] * 64ull < n) {
@@ -717,9 +750,16 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            HIPCHK(ctx, tk::launch_aln(P, FB, (uint32_t)jcap, cnt[0] <= ctx->small_aln, s));
+            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= ctx->small_aln, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
+            // next round: its jobs are packed by this round's counts (a read has at most one job per round)
+            {
+                uint32_t acc = 0;
+                for (uint32_t c = 0; c < FB.n_ranges; c++) { hbase_prev[c] = hbase_cur[c]; hbase_cur[c] = acc; acc += (hcnt[(size_t)c * 32] + 63) & ~63u; }
+                hbase_prev[FB.n_ranges] = hbase_cur[FB.n_ranges]; hbase_cur[FB.n_ranges] = acc;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
+            }
         }
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
         if (getenv("TKSMSEQ_VERBOSE")) {
@@ -739,10 +779,12 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             fprintf(stderr, "[prof] rounds=%u slow=%u | per loop-invocation (n=%llu) cycles: load %.0f gen %.0f eval %.0f seq %.0f join %.0f job %.0f store %.0f total %.0f | final (n=%llu): join %.0f lookups %.0f total %.0f\n", rounds, cnt[2], pr[10], (double)pr[0] / (pr[10] + pr[12] + 1), (double)pr[1] / (pr[10] + 1), (double)pr[2] / (pr[10] + 1), (double)pr[3] / (pr[10] + 1), (double)pr[4] / (pr[10] + 1), (double)pr[5] / (pr[10] + 1), (double)pr[6] / (pr[10] + 1), (double)pr[9] / (pr[10] + 1), pr[12], (double)pr[7] / (pr[12] + 1), (double)pr[8] / (pr[12] + 1), (double)pr[11] / (pr[12] + 1));
         }
 #endif
-        if (cnt[2]) {
-            // reads with non-ACGT bytes (or an alignment outside the band representation): byte-exact wave-wide path
-            O.read_list = ctx->f_slow.as<uint32_t>(); O.n_work = cnt[2];
-            const uint64_t want2 = (cnt[2] + wpw - 1) / wpw;
+        if (n_side) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_ev[1], 0));   // also: the two launches share the per-wave trace
+        if (cnt[2] > n_side) {
+            // reads that left the fast pipeline later (alignment outside the band representation, tail cut): byte-exact
+            // wave-wide path
+            O.read_list = ctx->f_slow.as<uint32_t>() + n_side; O.n_work = cnt[2] - n_side;
+            const uint64_t want2 = (cnt[2] - n_side + wpw - 1) / wpw;
             const int n_wgs2 = (int)std::max<uint64_t>(1, std::min<uint64_t>(want2, (uint64_t)n_wgs));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);

@@ -107,12 +107,12 @@ struct FastBuffers {
     uint16_t* st_nb;                  // [n_reads][lcap]
     unsigned long long* st_fplanes;   // [n_reads][fw][2] 2-bit planes of the padded fragment, {lo, hi} word pairs
     uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, m}
-    // [n_reads][cw] one 16-byte record per 8 columns of the joined window: {4-bit window shifts of the columns,
-    // low | high << 8 bits of the columns' 2-bit base codes, low / high code bit of the 32 fragment rows that follow
+    // [n_reads][cw] one 16-byte record per 8 columns of the joined window: {bits 0-3 of the columns' window shifts,
+    // low | high << 8 bits of the columns' 2-bit base codes | bit 4 of the shifts << 16, low / high code bit of the 32 fragment rows that follow
     // the window at the start of the block}: k_aln never touches the per-read fragment planes again
     uint4* job_cols;
     unsigned long long* job_win;      // [n_reads][2] code planes of the first 64 window rows
-    uint32_t* walk_sh;                // [n_groups][cw][64] shift words per block and lane, written by the forward pass
+    uint32_t* walk_sh;                // [n_groups][cw][64][2] shift words per block and lane, written by the forward pass
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
     uint32_t* aln_res;                // [n_reads][4] {matches, columns, fail, -}
     void* trace;                      // [n_groups][ncap + 1][64] x 16 B
@@ -122,6 +122,10 @@ struct FastBuffers {
     // previous round's job set (double buffered): its jobs are the list of reads that are still running
     const uint32_t* prev_meta; const uint8_t* prev_popd;
     const uint32_t* prefix;           // [n_ranges + 1] exclusive prefix sum of the previous round's per-range job counts
+    // first job id of every range in this round's / the previous round's job set.  Round 0: c * rs; later rounds: the
+    // previous round's counts rounded up to whole waves and packed -- a round's jobs, records and predecessor columns
+    // stay dense as the reads finish (fewer pages touched, no empty waves)
+    const uint32_t* base_cur; const uint32_t* base_prev;
     uint16_t* sv_i; uint8_t* sv_kind; unsigned long long* sv_alt;   // [n_reads][64] draws of an interrupted round
     unsigned long long* prof;         // diagnostic builds (-DTKSM_PROF) only: per-section cycle sums
     uint32_t* slow_list;              // [n_reads]

@@ -822,22 +822,22 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 //              column) through a small LDS staging area filled with ds_or atomics -- the joined bytes and their
 //              owner array are never materialised;
 //  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
-// Returns the job id (bit 31: the job cannot be represented: a shift > 15 or more than 32 rows within 8 columns).
+// Returns the job id (bit 31: the job cannot be represented: a shift > 31 or more than 32 rows within 8 columns).
 DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
                       int p0, int n, int m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
     const int lnw = ncap_l / 64 + 2, lshw = ncap_l / 8 + 16;
-    unsigned long long* pl = reinterpret_cast<unsigned long long*>(stage);
-    uint32_t* shn = reinterpret_cast<uint32_t*>(stage + 16 * (size_t)lnw);
+    unsigned long long* pl = reinterpret_cast<unsigned long long*>(stage);      // planes: code low, code high, shift bit 4
+    uint32_t* shn = reinterpret_cast<uint32_t*>(stage + 24 * (size_t)lnw);
     uint32_t idx = 0;
     if (build) {
-        if (lane == 0) { const uint32_t c = pos / FB.rs; idx = c * FB.rs + atomicAdd(&FB.job_cnt[c * 32u], 1u); }
+        if (lane == 0) { const uint32_t c = pos / FB.rs; idx = FB.base_cur[c] + atomicAdd(&FB.job_cnt[c * 32u], 1u); }
         idx = __shfl(idx, 0, 64);
         if (lane == 0) {
             uint32_t* meta = FB.job_meta + 4ull * idx;
             meta[0] = (uint32_t)r; meta[1] = (uint32_t)p0; meta[2] = (uint32_t)n | ((uint32_t)mode << 31); meta[3] = (uint32_t)m;
         }
         uint32_t* z = reinterpret_cast<uint32_t*>(stage);
-        for (int t = lane; t < 4 * lnw + lshw; t += 64) z[t] = 0u;
+        for (int t = lane; t < 6 * lnw + lshw; t += 64) z[t] = 0u;
         wave_sync();
     }
     bool fail = false;
@@ -853,8 +853,9 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             const unsigned long long below = ne & ((1ull << lane) - 1ull);
             const int prevp = below ? q + 63 - __builtin_clzll(below) : last_nonempty;
             const int sh = max(1, p + 1 - 31) - max(1, prevp + 1 - 31);
-            if (sh > 15) fail = true;
+            if (sh > 31) fail = true;
             atomicOr(&shn[off >> 3], (uint32_t)(sh & 15) << (4 * (off & 7)));
+            if (sh & 16) atomicOr(&pl[2 * lnw + (off >> 6)], 1ull << (off & 63));
             for (int x2 = 0; x2 < len; x2++) {
                 const int c = off + x2;
                 const int cd = code_of(slot_sym(code, x2, orig));
@@ -877,9 +878,9 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
         int tcar = 1;                                             // window top at the start of the chunk's first block
         for (int q = 0; q < nrec; q += 64) {
             const int t = q + lane;
-            const uint32_t shw = t < nrec ? shn[t] : 0u;
+            const uint32_t shw = t < nrec ? shn[t] : 0u, shx = t < nrec ? (uint32_t)plb[16 * lnw + t] : 0u;
             const uint32_t x4 = (shw & 0x0f0f0f0fu) + ((shw >> 4) & 0x0f0f0f0fu);
-            const int adv = (int)((x4 * 0x01010101u) >> 24);
+            const int adv = (int)((x4 * 0x01010101u) >> 24) + 16 * __popc(shx);
             if (adv > 32) fail = true;                            // more rows than one record carries
             const int incl = scan_add_incl(adv, lane);
             const int tk = tcar + incl - adv;                     // window top at the start of block t
@@ -889,7 +890,7 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
                 const int o = p0 + tk - 1 + 64, w = o >> 6, s2 = o & 63;
                 const uint32_t elo = lo32(funnel128(fp[2 * w], fp[2 * w + 2], s2)), ehi = lo32(funnel128(fp[2 * w + 1], fp[2 * w + 3], s2));
                 uint4 rec;
-                rec.x = shw; rec.y = (uint32_t)plb[t] | ((uint32_t)plb[8 * lnw + t] << 8); rec.z = elo; rec.w = ehi;
+                rec.x = shw; rec.y = (uint32_t)plb[t] | ((uint32_t)plb[8 * lnw + t] << 8) | (shx << 16); rec.z = elo; rec.w = ehi;
                 jc[t] = rec;
             }
         }
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const uint32_t target = FB.prefix[c0] + widx;
         uint32_t lo2 = c0, hi2 = c1 - 1;
         while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2 + 1) >> 1; if (FB.prefix[mid] <= target) lo2 = mid; else hi2 = mid - 1; }
-        const uint32_t pjob = lo2 * FB.rs + (target - FB.prefix[lo2]);
+        const uint32_t pjob = FB.base_prev[lo2] + (target - FB.prefix[lo2]);
         r = (uint64_t)__builtin_amdgcn_readfirstlane((int)FB.prev_meta[4ull * pjob]) & 0xffffffffull;
         pos = lo2 * FB.rs;                                        // any position inside the read's range
     }
@@ -1298,7 +1299,7 @@ struct AlnJob {
     const uint4* jc0;                // records of the wave's first job
     int cw;                          // records per job
     ulonglong2 win;                  // code planes of the first 64 window rows
-    uint32_t* wsh0;                  // the wave's [block][lane] shift words for the walk
+    uint2* wsh0;                     // the wave's [block][lane] shift words for the walk
     unsigned long long* trace;       // per-job region of (ncap + 16) 16-byte columns
     unsigned long long* trace0;      // region of the wave's first job
     size_t tstride;                  // u64 words between consecutive jobs
@@ -1348,10 +1349,11 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
             if (!(act && cb < m)) { rec.x = 0u; rec.y = 0u; rec.z = 0u; rec.w = 0u; }
             const uint32_t shw = rec.x, nbits = rec.y;
             uint32_t EA = rec.z, EB = rec.w;                      // the 32 rows after the window
-            J.wsh0[(size_t)(cb >> 3) * 64 + lane] = shw;          // shift words for the walk, one coalesced line per block
+            // shift words for the walk, coalesced lines per block: {bits 0-3 of the 8 shifts, bit 4 of the 8 shifts}
+            J.wsh0[(size_t)(cb >> 3) * 64 + lane] = make_uint2(shw, (nbits >> 16) & 0xffu);
 #pragma unroll
             for (int x = 0; x < 8; x++) {
-                const uint32_t sh = (shw >> (4 * x)) & 15u;
+                const uint32_t sh = ((shw >> (4 * x)) & 15u) | (((nbits >> (16 + x)) & 1u) << 4);
                 t += (int)sh;
                 const bool g = t > 1;
                 // window moves down by sh rows: entering rows take vertical delta +1
@@ -1413,9 +1415,9 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
     const uint32_t lim = (uint32_t)(n + m);
     const uint32_t modem = J.mode ? 0xffu : 0u;
     unsigned long long preA[8], preB[8];        // trace blocks in flight: two sets, two blocks deep
-    uint32_t shA = 0, shB = 0, cur_sh = 0;
+    uint2 shA = make_uint2(0u, 0u), shB = shA, cur_sh = shA;
     // block loads / LDS fills: whole 64-byte lines, 4 threads per job (transposed in LDS)
-    auto load_block = [&](int blk2, unsigned long long* pre, uint32_t& psh) {
+    auto load_block = [&](int blk2, unsigned long long* pre, uint2& psh) {
         blk2 = max(blk2, 0);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -1425,7 +1427,7 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
         }
         psh = J.wsh0[(size_t)blk2 * 64 + lane];
     };
-    auto fill_lds = [&](const unsigned long long* pre, uint32_t psh) {
+    auto fill_lds = [&](const unsigned long long* pre, uint2 psh) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int jl = q * 16 + (lane >> 2), part = lane & 3;
@@ -1437,7 +1439,7 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
     int maxdev = 0;
 #endif
     // one block: the set `nxt` (block blk - 1) was requested while the previous block was walked; `far` is requested now
-    auto walk_block = [&](int blk, unsigned long long* nxt, uint32_t& nsh, unsigned long long* far, uint32_t& fsh) {
+    auto walk_block = [&](int blk, unsigned long long* nxt, uint2& nsh, unsigned long long* far, uint2& fsh) {
         load_block(blk - 2, far, fsh);
         unsigned long long pp = 0ull;          // op bytes of this group of 8 columns
         bool touched = false;
@@ -1464,7 +1466,7 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
             pp |= up ? 0ull : (unsigned long long)(opb & modem) << (8 * c8);
             touched |= !up;
             dpend = up ? dpend + 1 : 0;
-            tt -= up ? 0 : (int)((cur_sh >> (4 * c8)) & 15u);
+            tt -= up ? 0 : (int)(((cur_sh.x >> (4 * c8)) & 15u) | (((cur_sh.y >> c8) & 1u) << 4));
             j -= up ? 0 : 1;
             go = up || c8 != 0;                           // leaving column c8 == 0 leaves the block
         }
@@ -1502,7 +1504,7 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
     for (int c = 0; c < mmax; c++) {
         if (act && c < m) {
             if ((c & 7) == 0) { rec = recn; EA = rec.z; EB = rec.w; recn = c + 8 < m ? J.jc[(c >> 3) + 1] : zero4; }
-            const uint32_t sh = (rec.x >> (4 * (c & 7))) & 15u;
+            const uint32_t sh = ((rec.x >> (4 * (c & 7))) & 15u) | (((rec.y >> (16 + (c & 7))) & 1u) << 4);
             t += (int)sh;
             const bool g = t > 1;
             Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh));
@@ -1537,13 +1539,13 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
     const uint32_t modem = mode ? 0xffu : 0u;
     unsigned long long pp = 0ull;
     bool touched = false;
-    uint32_t cur_sh = 0, pre_sh = 0;
+    uint2 cur_sh = make_uint2(0u, 0u), pre_sh = cur_sh;
     unsigned long long pre[8];
     auto loadb = [&](int blk2) {
         const bool have = act && blk2 >= 0 && blk2 * 4 < m;
 #pragma unroll
         for (int x = 0; x < 8; x++) pre[x] = have ? J.trace[(size_t)blk2 * 8 + x] : 0ull;
-        pre_sh = have ? J.jc[blk2 >> 1].x : 0u;
+        if (have) { const uint4 q4 = J.jc[blk2 >> 1]; pre_sh = make_uint2(q4.x, (q4.y >> 16) & 0xffu); } else pre_sh = make_uint2(0u, 0u);
     };
     wave_sync();
     loadb(topblk);
@@ -1571,7 +1573,7 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             pp |= up ? 0ull : (unsigned long long)(opb & modem) << (8 * c8);
             touched |= !up;
             dpend = up ? dpend + 1 : 0;
-            tt -= up ? 0 : (int)((cur_sh >> (4 * c8)) & 15u);
+            tt -= up ? 0 : (int)(((cur_sh.x >> (4 * c8)) & 15u) | (((cur_sh.y >> c8) & 1u) << 4));
             j -= up ? 0 : 1;
             go = up || cb != 0;
         }
@@ -1594,12 +1596,18 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
     __shared__ uint4 rec_lds[4 * 64];               // 4 KB: the current group of 4 block records per lane
     const int lane = threadIdx.x;
-    const uint32_t job = blockIdx.x * 64u + (uint32_t)lane;          // wave-aligned ranges of rs ids
-    const uint32_t rng = job / FB.rs;
+    const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
+    // job ids of a range start at its wave-aligned base (this round's bases are the packed counts of the previous round)
+    uint32_t rng = 0;
+    {
+        uint32_t hi2 = FB.n_ranges - 1;
+        while (rng < hi2) { const uint32_t mid = (rng + hi2 + 1) >> 1; if (FB.base_cur[mid] <= job0) rng = mid; else hi2 = mid - 1; }
+    }
+    const uint32_t rbase = FB.base_cur[rng];
     const uint32_t in_rng = FB.job_cnt[rng * 32u];
-    if (in_rng <= (blockIdx.x * 64u) % FB.rs) return;                // whole wave beyond the range's job count
+    if (in_rng <= job0 - rbase) return;                               // whole wave beyond the range's job count
     AlnJob J;
-    J.act = job < n_jobs && (job % FB.rs) < in_rng;
+    J.act = job < n_jobs && job - rbase < in_rng;
     uint32_t r = 0;
     J.p0 = 0; J.n = 0; J.m = 0; J.mode = 0;
     if (J.act) {
@@ -1611,7 +1619,7 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     J.jc0 = FB.job_cols + (size_t)(blockIdx.x * 64u) * FB.cw; J.cw = FB.cw;
     J.win.x = 0ull; J.win.y = 0ull;
     if (J.act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
-    J.wsh0 = FB.walk_sh + (size_t)blockIdx.x * FB.cw * 64;
+    J.wsh0 = reinterpret_cast<uint2*>(FB.walk_sh) + (size_t)blockIdx.x * FB.cw * 64;
     J.tstride = (size_t)(P.ncap + 16) * 2;
     J.trace = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)job * J.tstride;
     J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)(blockIdx.x * 64u) * J.tstride;
