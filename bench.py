@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark of the Seq hot path (BASELINE.json: sequenced reads/s + Gbases/s, %HBM roofline).
 
 A "step" = one pass of the hot path (splice -> Badread errors -> q-scores -> FASTQ records) over one batch of
-synthetic molecules with inputs resident in HBM.  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
+synthetic molecules with inputs resident in HBM.  Steps are issued the way the tool streams batches: --pipeline (2)
+contexts per GPU, each on its own stream and host thread, take the steps in turn; the library lets the latency-bound
+tail of one batch (few reads left, one short round after the other) run underneath the bulk of the next.  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
 Badread error+qual model" -- synthetic 24 x 128 Mb genome (GRCh38 is not available offline), nanopore2020 error +
 q-score models, identity 84,99,5.5, FASTQ with computed qualities; the 10 M molecules are processed as 5 steps of
 --batch = 2,097,152 molecules each (the default run).
@@ -95,6 +97,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU sample (0 = sized for ~20 s)")
     ap.add_argument("--skip-qual", action="store_true")
     ap.add_argument("--perfect", action="store_true", help="bench the integer splice path only (--perfect)")
+    ap.add_argument("--pipeline", type=int, default=2, help="contexts in flight per GPU (1 = one batch at a time)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,66 +121,123 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    seqr = Sequencer(local_rank, stream=stream)
+    import threading
 
-    # ---- inputs resident in HBM before the timed region: genome packed on the device, models, one batch
+    # ---- inputs resident in HBM before the timed region: genome packed on the device, models, one batch per context
+    n_ctx = max(1, args.pipeline)
+    clen = args.contig_mb * 1_000_000
+    models = os.path.join(ROOT, "tksm_amd", "models", "badread")
+    target = "perfect" if args.perfect else "badread"
+    compute_q = not args.skip_qual
+    cap = int(args.batch * (2.3 * (args.mean_len + 60) + 256))
+
+    class Ctx:
+        pass
+    ctxs = []
+    for i in range(n_ctx):
+        c = Ctx()
+        c.stream = torch.cuda.Stream(device=dev)
+        c.seqr = Sequencer(local_rank, stream=c.stream.cuda_stream)
+        ctxs.append(c)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    clen = args.contig_mb * 1_000_000
-    for c in range(args.genome_contigs):
+    for ci in range(args.genome_contigs):
         codes = torch.randint(0, 4, (clen,), dtype=torch.uint8, device=dev, generator=gen)
         ascii_t = lut[codes.long()]
-        seqr.add_contig(f"chr{c + 1}", ascii_t)
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.seqr.add_contig(f"chr{ci + 1}", ascii_t)
         del codes, ascii_t
-    models = os.path.join(ROOT, "tksm_amd", "models", "badread")
-    target = "perfect" if args.perfect else "badread"
-    if not args.perfect:
-        seqr.set_identity(84.0, 99.0, 5.5)
-        seqr.load_error_model(os.path.join(models, "nanopore2020.error.gz"))
-        seqr.load_qscore_model(os.path.join(models, "nanopore2020.qscore.gz"))
-    rs = np.random.RandomState(2 + rank)
-    m = synthetic.make_molecules(rs, [clen] * args.genome_contigs, args.batch, args.mean_len, args.mean_len * 0.2, kind=args.kind,
-                                 id_prefix=f"m{rank}")
-    batch = seqr.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
-    cap = int(args.batch * (2.3 * (args.mean_len + 60) + 256))
-    out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
-    seqr.set_output_buffer(out_t.data_ptr(), cap)
-    off_t = torch.empty(args.batch + 1, dtype=torch.int64, device=dev)
-    seqr.set_timing(True)
-    compute_q = not args.skip_qual
+    for i, c in enumerate(ctxs):
+        if not args.perfect:
+            c.seqr.set_identity(84.0, 99.0, 5.5)
+            c.seqr.load_error_model(os.path.join(models, "nanopore2020.error.gz"))
+            c.seqr.load_qscore_model(os.path.join(models, "nanopore2020.qscore.gz"))
+        rs = np.random.RandomState(2 + rank + 1000 * i)
+        c.m = synthetic.make_molecules(rs, [clen] * args.genome_contigs, args.batch, args.mean_len, args.mean_len * 0.2, kind=args.kind,
+                                       id_prefix=f"m{rank}")
+        c.batch = c.seqr.batch_from_arrays(c.m["reads"], c.m["intervals"], c.m["mods"], c.m["literals"], c.m["literal_pool"],
+                                           c.m["ids"], c.m["id_pool"])
+        c.out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+        c.seqr.set_output_buffer(c.out_t.data_ptr(), cap)
+        c.off_t = torch.empty(args.batch + 1, dtype=torch.int64, device=dev)
+        c.seqr.set_timing(True)
+        c.free = threading.Semaphore(1)          # the context's output buffer may be overwritten
+    m = ctxs[0].m
 
     gathered = None
 
-    def step(t):
-        res = seqr.run(batch, target=target, fastq=True, compute_qual=compute_q, seed=42,
-                       first_read_index=t * args.batch * world + rank, stride=world)
+    def run_step(c, t):
+        return c.seqr.run(c.batch, target=target, fastq=True, compute_qual=compute_q, seed=42,
+                          first_read_index=t * args.batch * world + rank, stride=world)
+
+    def exchange(c, res):
+        """FASTQ ordering (N > 1): sizes -> padded gather of record bytes + offsets to rank 0 -> interleave on device."""
+        nonlocal gathered
+        res.copy_to_device(None, c.off_t.data_ptr())
+        c.seqr.synchronize()
+        nbytes = torch.tensor([res.records_bytes], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, nbytes)
+        mx = int(max(int(x.item()) for x in sizes))
+        if rank == 0:
+            if gathered is None or gathered[0][0].numel() < mx:
+                gathered = ([torch.empty(mx + mx // 8, dtype=torch.uint8, device=dev) for _ in range(world)],
+                            [torch.empty(args.batch + 1, dtype=torch.int64, device=dev) for _ in range(world)],
+                            torch.empty(int(cap * world), dtype=torch.uint8, device=dev))
+            width = gathered[0][0].numel()
+        else:
+            width = 0
+        wt = torch.tensor([width], dtype=torch.int64, device=dev)
+        dist.broadcast(wt, 0)
+        width = int(wt.item())
+        dist.gather(c.out_t[:width], gathered[0] if rank == 0 else None, dst=0)
+        dist.gather(c.off_t, gathered[1] if rank == 0 else None, dst=0)
+        if rank == 0:
+            torch.cuda.current_stream().synchronize()
+            c.seqr.interleave_records([g.data_ptr() for g in gathered[0]], [g.data_ptr() for g in gathered[1]],
+                                      [args.batch] * world, gathered[2].data_ptr(), gathered[2].numel())
+            c.seqr.synchronize()
+        torch.cuda.current_stream().synchronize()
+
+    def run_steps(first, count):
+        """steps first .. first+count-1: context t mod n_ctx runs step t on its own thread; with N > 1 the main thread
+        performs the ordering exchange of every step in step order while the other context keeps computing."""
+        results = [None] * count
+        done = [threading.Event() for _ in range(count)]
+        errors = []
+
+        def worker(i):
+            try:
+                torch.cuda.set_device(local_rank)
+                for j in range(i, count, n_ctx):
+                    c = ctxs[i]
+                    c.free.acquire()
+                    results[j] = run_step(c, first + j)
+                    if world == 1:
+                        c.free.release()
+                    done[j].set()
+            except Exception as e:      # surface in the main thread
+                errors.append(e)
+                for d in done:
+                    d.set()
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(min(n_ctx, count))]
+        for x in th:
+            x.start()
         if world > 1:
-            # FASTQ ordering: sizes -> padded gather of record bytes + offsets to rank 0 -> interleave on device
-            res.copy_to_device(None, off_t.data_ptr())
-            nbytes = torch.tensor([res.records_bytes], dtype=torch.int64, device=dev)
-            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(sizes, nbytes)
-            mx = int(max(int(s.item()) for s in sizes))
-            nonlocal gathered
-            if rank == 0:
-                if gathered is None or gathered[0][0].numel() < mx:
-                    gathered = ([torch.empty(mx + mx // 8, dtype=torch.uint8, device=dev) for _ in range(world)],
-                                [torch.empty(args.batch + 1, dtype=torch.int64, device=dev) for _ in range(world)],
-                                torch.empty(int(cap * world), dtype=torch.uint8, device=dev))
-                width = gathered[0][0].numel()
-            else:
-                width = 0
-            wt = torch.tensor([width], dtype=torch.int64, device=dev)
-            dist.broadcast(wt, 0)
-            width = int(wt.item())
-            dist.gather(out_t[:width], gathered[0] if rank == 0 else None, dst=0)
-            dist.gather(off_t, gathered[1] if rank == 0 else None, dst=0)
-            if rank == 0:
-                seqr.interleave_records([g.data_ptr() for g in gathered[0]], [g.data_ptr() for g in gathered[1]],
-                                        [args.batch] * world, gathered[2].data_ptr(), gathered[2].numel())
-        return res
+            for j in range(count):
+                done[j].wait()
+                if errors:
+                    break
+                c = ctxs[j % n_ctx]
+                exchange(c, results[j])
+                c.free.release()
+        for x in th:
+            x.join()
+        if errors:
+            raise errors[0]
+        return results
 
     def fence():
         torch.cuda.synchronize()
@@ -185,21 +245,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for t in range(args.warmup):
-        step(t)
+    if args.warmup:
+        run_steps(0, args.warmup * n_ctx)        # every context warms up (allocations, code objects): untimed
     fence()
     t0 = time.perf_counter()
-    sim_ms, tot_ms, err_ms, aln_ms, oth_ms, rec_bytes, bases_in, bases_out = [], [], [], [], [], 0, 0, 0
-    for t in range(args.warmup, args.warmup + args.steps):
-        res = step(t)
-        sim_ms.append(res.kernel_ms[1])
-        tot_ms.append(res.kernel_ms[4])
-        err_ms.append(res.kernel_ms[5]); aln_ms.append(res.kernel_ms[6]); oth_ms.append(res.kernel_ms[7])
-        rec_bytes += res.records_bytes
-        bases_in += res.bases_in
-        bases_out += res.bases_out
+    results = run_steps(args.warmup * n_ctx, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    sim_ms = [r.kernel_ms[1] for r in results]
+    tot_ms = [r.kernel_ms[4] for r in results]
+    err_ms = [r.kernel_ms[5] for r in results]
+    aln_ms = [r.kernel_ms[6] for r in results]
+    oth_ms = [r.kernel_ms[7] for r in results]
+    rec_bytes = sum(r.records_bytes for r in results)
+    bases_in = sum(r.bases_in for r in results)
+    bases_out = sum(r.bases_out for r in results)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -245,7 +305,7 @@ def main():
                                if not args.perfect else "Bulk molecules, --perfect splice path, FASTQ",
                    "kind": args.kind, "molecules_per_gpu_per_step": args.batch, "mean_len": args.mean_len,
                    "compute_qual": bool(compute_q and not args.perfect), "sharding": f"round-robin x{world}",
-                   "ordering_gather": world > 1},
+                   "ordering_gather": world > 1, "contexts_in_flight_per_gpu": n_ctx},
         "gbases_per_s": bases_in_all / elapsed / 1e9,
         "gbases_out_per_s": bases_out_all / elapsed / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

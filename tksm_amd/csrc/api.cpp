@@ -95,7 +95,7 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_tracefull, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
@@ -602,12 +602,14 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
         HIPCHK(ctx, ctx->f_wsh.ensure(jcap * (size_t)FB.cw * 8 + 64));
         HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
-        HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 16 + 64));
+        HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 8 + 64));
+        FB.full_rows = (uint32_t)std::min<uint64_t>(jcap, 16384);
+        HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(64));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
-        FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.counters = ctx->f_counters.as<uint32_t>();
+        FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
         FB.walk_sh = ctx->f_wsh.as<uint32_t>();
@@ -750,6 +752,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
+            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 3, 0, 4, s));   // rows of the full-width pool
             HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= ctx->small_aln, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);

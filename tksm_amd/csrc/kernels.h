@@ -115,7 +115,9 @@ struct FastBuffers {
     uint32_t* walk_sh;                // [n_groups][cw][64][2] shift words per block and lane, written by the forward pass
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
     uint32_t* aln_res;                // [n_reads][4] {matches, columns, fail, -}
-    void* trace;                      // [n_groups][ncap + 1][64] x 16 B
+    void* trace;                      // [n_jobs][ncap + 16] 8-byte predecessor columns (rows 16..47 of the band)
+    void* trace_full;                 // [full_rows][ncap + 16] 16-byte columns: pool for full-width passes, counters[3] allocates
+    uint32_t full_rows;
     uint32_t* counters;               // [2] slow reads
     uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
     uint32_t rs, n_ranges;

@@ -1620,9 +1620,21 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     J.win.x = 0ull; J.win.y = 0ull;
     if (J.act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
     J.wsh0 = reinterpret_cast<uint2*>(FB.walk_sh) + (size_t)blockIdx.x * FB.cw * 64;
-    J.tstride = (size_t)(P.ncap + 16) * 2;
-    J.trace = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)job * J.tstride;
+    J.tstride = (size_t)(P.ncap + 16);                              // 8-byte predecessor columns
+    J.trace = nullptr;                                               // full-width rows come from a small pool
     J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)(blockIdx.x * 64u) * J.tstride;
+    // full-width pass: 16-byte columns in a row of the pool; a lane that gets no row reports a failure (the read
+    // then takes the wave-wide kernel)
+    auto full_row = [&](bool want) -> bool {
+        const unsigned long long wm = __ballot(want);
+        uint32_t base = 0;
+        if (lane == 0 && wm) base = atomicAdd(&FB.counters[3], (uint32_t)__popcll(wm));
+        base = __shfl(base, 0, 64);
+        const uint32_t slot = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+        const bool ok = want && slot < FB.full_rows;
+        if (ok) J.trace = reinterpret_cast<unsigned long long*>(FB.trace_full) + (size_t)slot * (size_t)(P.ncap + 16) * 2;
+        return ok;
+    };
     J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + (size_t)job * P.ncap);
     int mmax = J.m;
 #pragma unroll
@@ -1631,18 +1643,21 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     if (P.ablate == 10) return;
 #endif
     AlnRes R;
-    if (FULL_ONLY) R = aln_full(J, J.act, mmax, lane, tr_lds);
-    else {
+    if (FULL_ONLY) {
+        const bool ok = full_row(J.act);
+        R = aln_full(J, ok, mmax, lane, tr_lds);
+        if (J.act && !ok) R.fail = true;
+    } else {
         R = aln_fast(J, mmax, (P.ncap + 7) & ~7, lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
         const unsigned long long nf = __ballot(R.needfull);
         if (nf) {
             if (lane == 0) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
-            const bool redo = J.act && R.needfull;
+            const bool redo = full_row(J.act && R.needfull);
             int mm2 = redo ? J.m : 0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
             const AlnRes R2 = aln_full(J, redo, mm2, lane, tr_lds);
-            if (redo) R = R2;
+            if (redo) R = R2;                                         // without a row needfull stays set: reported as failure
         }
     }
     if (J.act) {
