@@ -2,12 +2,13 @@
 """bench.py -- headline benchmark of the Seq hot path (BASELINE.json: sequenced reads/s + Gbases/s, %HBM roofline).
 
 A "step" = one pass of the hot path (splice -> Badread errors -> q-scores -> FASTQ records) over one batch of
-synthetic molecules with inputs resident in HBM.  Steps are issued the way the tool streams batches: --pipeline (2)
-contexts per GPU, each on its own stream and host thread, take the steps in turn; the library lets the latency-bound
-tail of one batch (few reads left, one short round after the other) run underneath the bulk of the next.  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
+synthetic molecules with inputs resident in HBM.  Steps are issued the way a streaming tool issues batches:
+--pipeline (4) contexts per GPU, each on its own stream and host thread, take the steps in turn, so that the kernels of
+consecutive batches fill each other's gaps (the instruction-bound error loop next to the memory-bound alignment, the
+latency-bound last rounds of one batch underneath the bulk of the next).  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
 Badread error+qual model" -- synthetic 24 x 128 Mb genome (GRCh38 is not available offline), nanopore2020 error +
-q-score models, identity 84,99,5.5, FASTQ with computed qualities; the 10 M molecules are processed as 5 steps of
---batch = 2,097,152 molecules each (the default run).
+q-score models, identity 84,99,5.5, FASTQ with computed qualities; processed as 12 steps of --batch = 1,048,576 molecules
+(12.6 M molecules, the default run).
 
 N>1 (torchrun, one rank per GPU): molecules are sharded round-robin (global read g -> rank g mod P, counter-based
 RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RCCL gather of the per-rank record
@@ -86,9 +87,9 @@ def cpu_baseline(n_reads, mean_len, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2097152, help="molecules per GPU per step")
+    ap.add_argument("--batch", type=int, default=1048576, help="molecules per GPU per step")
     ap.add_argument("--mean-len", type=int, default=1000)
     ap.add_argument("--genome-contigs", type=int, default=24)
     ap.add_argument("--contig-mb", type=int, default=128)
@@ -97,7 +98,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU sample (0 = sized for ~20 s)")
     ap.add_argument("--skip-qual", action="store_true")
     ap.add_argument("--perfect", action="store_true", help="bench the integer splice path only (--perfect)")
-    ap.add_argument("--pipeline", type=int, default=2, help="contexts in flight per GPU (1 = one batch at a time)")
+    ap.add_argument("--pipeline", type=int, default=4, help="contexts in flight per GPU (1 = one batch at a time)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

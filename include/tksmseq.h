@@ -8,7 +8,10 @@
  * Every entry point below names the reference code it replaces (file:line into vpc-ccg/tksm).
  * Plain pointers and sizes only; no C++ or torch types; no exceptions cross this boundary.
  * All functions return TKSMSEQ_OK (0) or a TKSMSEQ_E* code; tksmseq_last_error() gives the text.
- * A context is used from one host thread at a time and owns one HIP device + stream.
+ * A context is used from one host thread at a time and owns one HIP device + stream.  Contexts are independent:
+ * several may be driven from different threads on the same device (each on its own stream), and that is how batches
+ * are streamed at full rate -- the kernels of concurrent runs fill each other's gaps (instruction-bound error loop next
+ * to memory-bound alignment, the latency-bound last rounds of one batch underneath the bulk of the next).
  *
  * There is no CPU fallback: every compute entry point runs HIP kernels on gfx950 and fails with
  * TKSMSEQ_EDEVICE when no device is usable.

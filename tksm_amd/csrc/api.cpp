@@ -9,7 +9,6 @@
 #include <cstring>
 #include <cstdlib>
 #include <memory>
-#include <mutex>
 #include <string>
 
 #include "host.h"
@@ -487,12 +486,6 @@ int tksmseq_set_output_buffer(tksmseq_ctx* ctx, void* p, uint64_t cap) {
     return TKSMSEQ_OK;
 }
 
-// Contexts on the same device may be driven from different threads.  A run is bandwidth/occupancy-bound while most
-// reads are still in the error loop and latency-bound afterwards (few reads, one short round after the other): the
-// runs of different contexts take turns in the first phase and leave it as soon as they enter the second, so that the
-// tail of one batch executes underneath the bulk of the next.
-static std::mutex g_bulk_phase[64];
-
 static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params* p, int cap_num, int cap_den, int cap_add,
                     tksmseq_result* res, bool* overflow) {
     *overflow = false;
@@ -500,7 +493,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     hipStream_t s = ctx->stream;
     const bool badread = p->mode == TKSMSEQ_MODE_BADREAD;
     const int k = badread ? ctx->em.k : 0;
-    std::unique_lock<std::mutex> bulk(g_bulk_phase[ctx->device & 63]);
     auto align16 = [](uint64_t v) { return (v + 15) & ~15ull; };
     auto capf = [&](uint64_t raw) { return align16((raw + 2 * (uint64_t)k) * cap_num / cap_den + cap_add); };
     if (b->cache_k != k || b->cache_num != cap_num || b->cache_den != cap_den || b->cache_add != cap_add) {
@@ -740,7 +732,9 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             for (uint32_t c = 0; c < FB.n_ranges; c++) { hprefix[c] = cnt[0]; cnt[0] += hcnt[(size_t)c * 32]; }
             hprefix[FB.n_ranges] = cnt[0];
             if (cnt[0] == 0) break;
-            if (bulk.owns_lock() && cnt[0] * 16ull < n) bulk.unlock();      // latency-bound from here on
+#ifdef TKSM_ABLATE
+            if (P.ablate >= 1 && P.ablate <= 9) break;          // k_err returned early: the reads would never finish
+#endif
             if (cnt[0] < ctx->tail_cut && cnt[0] * 64ull < n) {
                 // tail: every further round costs a full alignment latency for a handful of reads; finish the
                 // stragglers in one launch of the wave-wide kernel instead (same results: it recomputes them)

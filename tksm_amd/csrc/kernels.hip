@@ -824,7 +824,7 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 //  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
 // Returns the job id (bit 31: the job cannot be represented: a shift > 31 or more than 32 rows within 8 columns).
 DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
-                      int p0, int n, int m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
+                      int p0, int n, int& m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
     const int lnw = ncap_l / 64 + 2, lshw = ncap_l / 8 + 16;
     unsigned long long* pl = reinterpret_cast<unsigned long long*>(stage);      // planes: code low, code high, shift bit 4
     uint32_t* shn = reinterpret_cast<uint32_t*>(stage + 24 * (size_t)lnw);
@@ -832,10 +832,6 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
     if (build) {
         if (lane == 0) { const uint32_t c = pos / FB.rs; idx = FB.base_cur[c] + atomicAdd(&FB.job_cnt[c * 32u], 1u); }
         idx = __shfl(idx, 0, 64);
-        if (lane == 0) {
-            uint32_t* meta = FB.job_meta + 4ull * idx;
-            meta[0] = (uint32_t)r; meta[1] = (uint32_t)p0; meta[2] = (uint32_t)n | ((uint32_t)mode << 31); meta[3] = (uint32_t)m;
-        }
         uint32_t* z = reinterpret_cast<uint32_t*>(stage);
         for (int t = lane; t < 6 * lnw + lshw; t += 64) z[t] = 0u;
         wave_sync();
@@ -869,6 +865,15 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
         base += total;
     }
     if (build) {
+        // the joined length is known now; a window that outgrew the staging area leaves an empty job behind (the caller
+        // reports the overflow)
+        m = base;
+        if (lane == 0) {
+            uint32_t* meta = FB.job_meta + 4ull * idx;
+            meta[0] = (uint32_t)r; meta[1] = (uint32_t)p0; meta[2] = (uint32_t)n | ((uint32_t)mode << 31);
+            meta[3] = (uint32_t)(m > ncap_l ? 0 : m);
+        }
+        if (m > ncap_l) return idx;
         wave_sync();
         // one record per 8 columns: {shifts, code bits, entering fragment rows}; one zero record after the end
         uint4* jc = FB.job_cols + (size_t)idx * FB.cw;
@@ -1063,6 +1068,17 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             if (P.ablate == 3) return;
 #endif
             double est_cur = 1.0 - errors / frag_len;
+            // slot writes of the processed draws are deferred: every lane keeps the mask of its own draw and all of
+            // them are written at once (before a dependent draw is evaluated, and at the end of the round)
+            uint32_t wm_mine = 0u;
+            auto flush_writes = [&]() {
+                if (wm_mine) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++)
+                        if ((wm_mine >> jj) & 1u) nb[i + jj] = (uint16_t)((ev.e[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
+                    wm_mine = 0u;
+                }
+            };
             while (mask) {
                 const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
                 uint32_t am_s, lens_s;
@@ -1071,6 +1087,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 const bool isdep = (depm >> src) & 1ull;
                 if (isdep) {
                     // sequential evaluation of this one draw: lanes 0..k-1 take its k slots
+                    flush_writes();
                     wave_sync();
                     const int ai = __builtin_amdgcn_readlane(i, src);
                     const int akind = __builtin_amdgcn_readlane(kind, src);
@@ -1114,12 +1131,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                         errors += (double)new_errors * f15;
                         if (change_count % 25 == 0) { need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
                     }
-                    if (lane == src) {
-                        const uint32_t wm = am_s & ((2u << last) - 1u);
-#pragma unroll
-                        for (int jj = 0; jj < 8; jj++)
-                            if ((wm >> jj) & 1u) nb[i + jj] = (uint16_t)((ev.e[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
-                    }
+                    wm_mine = lane == src ? (am_s & ((2u << last) - 1u)) : wm_mine;
                     if (need_aln) {                            // the round's draws travel with the state
                         FB.sv_i[r * 64 + lane] = (uint16_t)i; FB.sv_kind[r * 64 + lane] = (uint8_t)kind; FB.sv_alt[r * 64 + lane] = alt;
                         break;
@@ -1133,7 +1145,11 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 }
                 mask &= mask - 1;
             }
+            flush_writes();
             wave_sync();
+#ifdef TKSM_ABLATE
+            if (P.ablate == 22) return;
+#endif
             PROF_T(t_r3); PROF_ADD(3, t_r2, t_r3);
             if (!done && !need_aln) {
                 if (dead) { done = true; st_draws = (int)loop_limit; }
@@ -1153,15 +1169,14 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 nrows = 1000;
             }
             PROF_T(t_j0);
-            const int m = joined_len(nb, p0, nrows, lane);
-            PROF_T(t_j1); PROF_ADD(4, t_j0, t_j1);
+            int m = 0;
+            const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
+            PROF_T(t_j2); PROF_ADD(5, t_j0, t_j2);
             if (m > lds_ncap) {                              // output slot overflow: the host reruns with larger slots
                 finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
                 if (lane == 0) FB.state[r].stage = 2;
                 return;
             }
-            const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
-            PROF_T(t_j2); PROF_ADD(5, t_j1, t_j2);
 #ifdef TKSM_ABLATE
             if (P.ablate == 5) return;
 #endif
@@ -1199,7 +1214,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
     if (S.stage == 0 && want_q) {
-        const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m, lds_ncap, aux, nullptr, 0, 0, lane);
+        int m1 = m;
+        const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m1, lds_ncap, aux, nullptr, 0, 0, lane);
         if (job >> 31) { go_slow(FB, r, lane, 2); return; }
         if (lane == 0) {
             S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
@@ -1264,7 +1280,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     } else {
         identity = 1.0 - errors / frag_len;
     }
-    (void)join_job(FB, 0, r, 0, 0, frag, nb, 0, L, m, lds_ncap, aux, out_seq, lo, hi, lane);
+    int m2 = m;
+    (void)join_job(FB, 0, r, 0, 0, frag, nb, 0, L, m2, lds_ncap, aux, out_seq, lo, hi, lane);
     if (P.quirk_perfect) identity = 1.0;
     finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
                 start_trim, end_trim, errors, target, lane);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # diagnostic: time of the first round's k_err launches when the kernel returns early at point $1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for a in 1 6 2 3 4 0; do
+for a in ${ABL:-1 6 2 3 4 0}; do
   rm -rf gpurun_out/abl
   TKSMSEQ_ABLATE=$a TKSMSEQ_TAIL_CUT=0 TKSMSEQ_LIB=libtksmseq_prof.so rocprofv3 --kernel-trace --output-format csv -d gpurun_out/abl -- python tools/quick_stage_times.py 1048576 > gpurun_out/abl.log 2>&1; echo run $a done >> gpurun_out/abl_progress.log
   python - <<PY

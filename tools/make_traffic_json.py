@@ -1,25 +1,27 @@
 """Per-kernel HBM bytes per step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; both report KiB)."""
-import csv, glob, collections, json, sys
+import csv, glob, collections, json, re, sys
 
 d, nsteps = sys.argv[1], int(sys.argv[2])
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1048576
 
 
 def sums(sub, counter):
     f = glob.glob(f"{d}/{sub}/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("tk::", "")
-        if k.startswith("k_") and r["Counter_Name"] == counter:
+        mt = re.search(r"tk::(k_\w+)", r["Kernel_Name"])
+        if mt and r["Counter_Name"] == counter:
+            k = mt.group(1)
             agg[k] += float(r["Counter_Value"]) * 1024.0 / nsteps
     return dict(agg)
 
 
 fe, wr = sums("fetch", "FETCH_SIZE"), sums("write", "WRITE_SIZE")
 print(json.dumps({
-    "batch": 2097152, "kind": "bulk",
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 2 --warmup 1 "
-              f"--no-cpu-baseline; per-kernel sums over the {nsteps} steps divided by {nsteps}",
-    "units": "bytes per step (2,097,152 reads); the counters report KiB",
+    "batch": batch, "kind": "bulk",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 4 --warmup 1 "
+              f"--no-cpu-baseline (4 contexts in flight: 4 warm-up + 4 timed steps); per-kernel sums over the {nsteps} steps divided by {nsteps}",
+    "units": f"bytes per step ({batch:,} reads); the counters report KiB",
     "calibration": "FETCH_SIZE used uncorrected: the dominant loads are 8-byte-per-lane and 64-byte-block accesses, not the "
                    "16 B/lane streaming reads the gfx950 1/2 factor of MI355X_MICROARCH.md applies to",
     "hbm_bytes_per_step": {k: fe.get(k, 0) + wr.get(k, 0) for k in sorted(set(fe) | set(wr))},
