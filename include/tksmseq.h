@@ -44,6 +44,14 @@ const char* tksmseq_last_error(const tksmseq_ctx* ctx);   /* ctx may be NULL: la
 const char* tksmseq_version(void);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = library stream. */
 int tksmseq_set_stream(tksmseq_ctx* ctx, void* hip_stream);
+/* A second context on the same device that SHARES src's packed reference and model tables (read-only views; it gets
+ * its own stream and work buffers).  Replaces what the reference's worker processes inherit by fork from the module
+ * globals (multiprocessing.Pool, py/sequence.py:354-366; reference_seqs / error_model / qscore_model, :336-345).
+ * Destroy clones before src.  Loading another model or contig into a clone gives that clone a private copy. */
+int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out);
+/* Page-locked host memory for tksmseq_result_download destinations (a pageable destination halves the copy rate). */
+int tksmseq_host_alloc(uint64_t bytes, void** out);
+void tksmseq_host_free(void* p);
 int tksmseq_synchronize(tksmseq_ctx* ctx);
 
 /* ---- reference genome (S0) -------------------------------------------------------------------

@@ -357,3 +357,38 @@ def test_output_slot_overflow_triggers_rerun(tmp_path, po):
         assert recs[i] == want, i
     assert grew > 0, "the model did not outgrow the default slot: the test does not exercise the rerun"
     s.close()
+
+
+def test_clone_shares_reference_and_models_across_threads(oracle_models):
+    """tksmseq_clone: contexts that share one packed reference and one set of model tables, driven from their own host
+    threads and streams at the same time, produce the records of the source context run alone."""
+    import threading
+    import torch
+    s, ref, rs = _random_genome_seqr()
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    mols = _make_molecules(rs, ref, 300, 600)
+    text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
+    want = s.run(s.batch_from_mdf(text), seed=SEED, first_read_index=7).download()[0]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    clones = [s.clone(stream=st.cuda_stream) for st in streams]
+    got = [None] * len(clones)
+
+    def work(i):
+        torch.cuda.set_device(0)
+        c = clones[i]
+        b = c.batch_from_mdf(text)
+        for _ in range(3):
+            got[i] = c.run(b, seed=SEED, first_read_index=7).download()[0]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(clones))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(g == want for g in got)
+    # a model loaded into a clone is private to it
+    clones[0].load_error_model("random")
+    assert s.run(s.batch_from_mdf(text), seed=SEED, first_read_index=7).download()[0] == want
+    assert clones[0].run(clones[0].batch_from_mdf(text), seed=SEED, first_read_index=7).download()[0] != want
+    for c in clones:
+        c.close()
+    s.close()

@@ -41,6 +41,7 @@ SYMBOLS = [
     "tksmseq_get_identity", "tksmseq_batch_create", "tksmseq_batch_from_mdf_text", "tksmseq_batch_info",
     "tksmseq_batch_free", "tksmseq_run", "tksmseq_set_output_buffer", "tksmseq_set_timing",
     "tksmseq_result_download", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
+    "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free",
 ]
 
 _lib = None
@@ -63,6 +64,9 @@ def load():
         "tksmseq_last_error": (C.c_char_p, [vp]),
         "tksmseq_version": (C.c_char_p, []),
         "tksmseq_set_stream": (C.c_int, [vp, vp]),
+        "tksmseq_clone": (C.c_int, [vp, C.POINTER(vp)]),
+        "tksmseq_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(vp)]),
+        "tksmseq_host_free": (None, [vp]),
         "tksmseq_synchronize": (C.c_int, [vp]),
         "tksmseq_reference_add_fasta": (C.c_int, [vp, C.c_char_p]),
         "tksmseq_reference_add_contig": (C.c_int, [vp, C.c_char_p, vp, u64, C.c_int]),

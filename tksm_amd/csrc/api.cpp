@@ -32,10 +32,15 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool owned = true;                     // false: a view of another context's buffer (tksmseq_clone), read-only
+    ~DevBuf() { if (p && owned) (void)hipFree(p); }
+    void borrow(const DevBuf& o) { if (p && owned) (void)hipFree(p); p = o.p; cap = o.cap; owned = false; }
     hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
-        if (bytes <= cap) return hipSuccess;
-        size_t ncap = std::max(bytes, cap + cap / 2);
+        if (bytes <= cap && owned) return hipSuccess;
+        // a borrowed buffer is never written: the first write access replaces it by a private copy
+        // large work buffers get 1/8 of headroom: consecutive batches of a stream differ by a few percent, and
+        // re-allocating tens of GB costs more than a batch
+        size_t ncap = std::max(bytes > (64u << 20) ? bytes + bytes / 8 : bytes, owned ? cap + cap / 2 : cap);
         ncap = (ncap + 255) & ~(size_t)255;
         void* np = nullptr;
         hipError_t e = hipMalloc(&np, ncap);
@@ -45,8 +50,8 @@ struct DevBuf {
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) { (void)hipFree(np); return e; }
         }
-        if (p) (void)hipFree(p);
-        p = np; cap = ncap;
+        if (p && owned) (void)hipFree(p);
+        p = np; cap = ncap; owned = true;
         return hipSuccess;
     }
     template <class T> T* as() const { return (T*)p; }
@@ -150,6 +155,30 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     *out = c.release();
     return TKSMSEQ_OK;
 }
+
+int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out) {
+    if (!src || !out) return TKSMSEQ_EINVAL;
+    int rc = tksmseq_create(src->device, out);
+    if (rc != TKSMSEQ_OK) return rc;
+    tksmseq_ctx* c = *out;
+    c->contig_names = src->contig_names; c->contig_index = src->contig_index; c->contigs = src->contigs;
+    c->total_alloc = src->total_alloc; c->total_bases = src->total_bases; c->pool_blocks = src->pool_blocks;
+    c->d_packed.borrow(src->d_packed); c->d_blocktab.borrow(src->d_blocktab); c->d_pool.borrow(src->d_pool); c->d_contigs.borrow(src->d_contigs);
+    c->em = src->em; c->qm = src->qm; c->idm = src->idm; c->em_uniform = src->em_uniform; c->em_alt0 = src->em_alt0;
+    c->d_pself.borrow(src->d_pself); c->d_cdf32.borrow(src->d_cdf32); c->d_cdf.borrow(src->d_cdf); c->d_alts.borrow(src->d_alts);
+    c->d_nalts.borrow(src->d_nalts); c->d_qkeys.borrow(src->d_qkeys); c->d_qoff.borrow(src->d_qoff); c->d_qcnt.borrow(src->d_qcnt);
+    c->d_qcdf.borrow(src->d_qcdf); c->d_qq.borrow(src->d_qq); c->d_qtab.borrow(src->d_qtab); c->d_qent.borrow(src->d_qent);
+    c->d_qpairs.borrow(src->d_qpairs); c->d_qguide.borrow(src->d_qguide);
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return TKSMSEQ_EINVAL;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? TKSMSEQ_OK : TKSMSEQ_ENOMEM;
+}
+
+void tksmseq_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 void tksmseq_destroy(tksmseq_ctx* ctx) {
     if (!ctx) return;

@@ -6,16 +6,29 @@
 //   main block                      py/sequence.py:323-376   (load reference + models, stream the MDF, write)
 //   get_output_file                 py/sequence.py:291-300   (extension decides FASTQ/FASTA; .gz ok)
 //   utility flags                   src/module.h:75-104      (-s/--seed default 42, --verbosity, --log-file)
+//   worker pool                     py/sequence.py:354-366   (multiprocessing.Pool + imap_unordered over molecules)
+// Streaming: the reader cuts the MDF text into batches of whole molecules and numbers their reads; --in-flight worker
+// threads (one context each, sharing the packed reference and the model tables) parse, run and download a batch each,
+// so that parsing, the device work of consecutive batches and the copies overlap; one writer puts the record
+// streams back into MDF order.
 // Exit codes: 0 ok; 1 for `sys.exit("msg")`-style validation and runtime errors; 2 for argparse
 // usage errors (missing -i, neither -o nor --perfect) -- what the embedded interpreter returns.
 #include "sequencer_module.h"
 
 #include <zlib.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tksmseq.h"
@@ -27,9 +40,9 @@ struct Args {
     std::string error_model = "nanopore2020", qscore_model = "nanopore2020", tail_model = "no_noise";
     std::vector<std::string> references;
     bool skip_qual = false, list = false, help = false;
-    int threads = 1, device = 0;
+    int threads = 1, device = 0, in_flight = 3;
     long long seed = 42;
-    uint64_t batch_bytes = 256ull << 20;
+    uint64_t batch_bytes = 64ull << 20;
     std::string verbosity = "INFO", log_file = "stderr";
 };
 
@@ -42,7 +55,7 @@ void usage(FILE* f) {
             "usage: sequence [-h] -i INPUT [-r REFERENCES [REFERENCES ...]] [-o BADREAD] [--perfect PERFECT]\n"
             "                [--skip-qual-compute] [-O {fastq,fasta}] [-t THREADS] [--badread-identity BADREAD_IDENTITY]\n"
             "                [--badread-error-model M] [--badread-qscore-model M] [--badread-tail-model M] [--list]\n"
-            "                [-s SEED] [--devices D] [--verbosity L] [--log-file F]\n");
+            "                [-s SEED] [--devices D] [--batch-bytes B] [--in-flight N] [--verbosity L] [--log-file F]\n");
 }
 
 struct Writer {
@@ -66,6 +79,50 @@ struct Writer {
     }
     void close() { if (g) gzclose(g); if (f) fclose(f); g = nullptr; f = nullptr; }
 };
+
+// reads a batch of MDF text will produce: the depth column of every molecule header (mdf_generator, py/sequence.py:206-213)
+uint64_t count_reads(const char* p, size_t len) {
+    uint64_t n = 0;
+    const char* end = p + len;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        if (*p == '+') {
+            const char* t = (const char*)memchr(p, '\t', (size_t)(le - p));
+            long long d = 0;
+            if (t) { const char* q = t + 1; bool neg = false; if (q < le && *q == '-') { neg = true; q++; } while (q < le && *q >= '0' && *q <= '9') d = d * 10 + (*q++ - '0'); if (neg) d = 0; }
+            n += (uint64_t)d;
+        }
+        p = nl ? nl + 1 : end;
+    }
+    return n;
+}
+
+struct Chunk { uint64_t seq = 0, first_read = 0, n_reads = 0; std::vector<char> text; };
+
+struct ChunkQueue {                                       // bounded, closed by the reader at end of input
+    std::mutex m; std::condition_variable cv_put, cv_get; std::deque<Chunk> q; size_t cap = 2; bool closed = false;
+    void push(Chunk&& c) { std::unique_lock<std::mutex> l(m); cv_put.wait(l, [&] { return q.size() < cap || closed; }); if (closed) return; q.push_back(std::move(c)); cv_get.notify_one(); }
+    bool pop(Chunk& c) { std::unique_lock<std::mutex> l(m); cv_get.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; c = std::move(q.front()); q.pop_front(); cv_put.notify_one(); return true; }
+    void close() { std::lock_guard<std::mutex> l(m); closed = true; cv_get.notify_all(); cv_put.notify_all(); }
+};
+
+struct Worker {                                           // one batch in flight: context + page-locked record buffers
+    tksmseq_ctx* ctx = nullptr;
+    uint8_t* host[2] = {nullptr, nullptr}; uint64_t host_cap[2] = {0, 0};
+    std::mutex m; std::condition_variable cv; bool host_busy = false;     // the writer still reads the buffers
+    bool reserve(int k, uint64_t bytes) {
+        if (bytes <= host_cap[k]) return true;
+        tksmseq_host_free(host[k]); host[k] = nullptr; host_cap[k] = 0;
+        const uint64_t want = bytes + bytes / 4 + 4096;
+        void* p = nullptr;
+        if (tksmseq_host_alloc(want, &p)) return false;
+        host[k] = (uint8_t*)p; host_cap[k] = want;
+        return true;
+    }
+};
+
+struct Finished { int worker = -1; uint64_t bytes[2] = {0, 0}; uint64_t n_reads = 0; };
 
 }  // namespace
 
@@ -101,6 +158,7 @@ class Sequencer_module::impl {
             else if (o == "-s" || o == "--seed") { if (!(v = need(i))) return 2; a.seed = atoll(v); }
             else if (o == "--devices") { if (!(v = need(i))) return 2; a.device = atoi(v); }
             else if (o == "--batch-bytes") { if (!(v = need(i))) return 2; a.batch_bytes = strtoull(v, nullptr, 10); }
+            else if (o == "--in-flight") { if (!(v = need(i))) return 2; a.in_flight = atoi(v); }
             else if (o == "--verbosity") { if (!(v = need(i))) return 2; a.verbosity = v; }
             else if (o == "--log-file") { if (!(v = need(i))) return 2; a.log_file = v; }
             else { usage(stderr); fprintf(stderr, "sequence: error: unrecognized arguments: %s\n", argv[i]); return 2; }
@@ -146,6 +204,7 @@ public:
         if (a.badread.empty() && a.perfect.empty()) { usage(stderr); fprintf(stderr, "sequence: error: Must specify either --output or --perfect.\n"); return 2; }
         if (a.tail_model != "no_noise") return die("Error: tail-noise models other than no_noise are not supported by this build yet");
 
+        const auto t_begin = std::chrono::steady_clock::now();
         tksmseq_ctx* ctx = nullptr;
         if (tksmseq_create(a.device, &ctx)) return die(std::string("Error: ") + tksmseq_last_error(nullptr));
         auto fail = [&](const std::string& what) { std::string m = "Error: " + what + ": " + tksmseq_last_error(ctx); tksmseq_destroy(ctx); return die(m); };
@@ -173,14 +232,124 @@ public:
 
         FILE* in = fopen(a.input.c_str(), "rb");
         if (!in) { tksmseq_destroy(ctx); return die("Error: cannot open " + a.input); }
+        const int n_workers = std::max(1, std::min(a.in_flight, 8));
+        std::vector<std::unique_ptr<Worker>> workers;
+        for (int w = 0; w < n_workers; w++) {
+            workers.emplace_back(new Worker());
+            if (w == 0) workers[w]->ctx = ctx;
+            else if (tksmseq_clone(ctx, &workers[w]->ctx)) {
+                for (int x = 1; x < w; x++) tksmseq_destroy(workers[x]->ctx);
+                return fail("second context");
+            }
+        }
+        ChunkQueue queue;
+        queue.cap = (size_t)n_workers;
+        std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Finished> done;   // by batch number
+        std::atomic<bool> failed{false};
+        std::mutex err_m; std::string first_error;
+        auto set_error = [&](const std::string& msg) {
+            std::lock_guard<std::mutex> l(err_m);
+            if (!failed.exchange(true)) first_error = msg;
+            queue.close();
+            done_cv.notify_all();
+        };
+        uint64_t n_batches = 0; bool reader_done = false;                                          // guarded by done_m
+        // stage clocks (TKSMSEQ_VERBOSE): seconds spent parsing, running, copying, writing, reading
+        const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr;
+        std::mutex clk_m; double clk[6] = {0, 0, 0, 0, 0, 0};
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto add_clk = [&](int k, std::chrono::steady_clock::time_point t0) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::lock_guard<std::mutex> l(clk_m); clk[k] += dt;
+        };
+        const auto t_start = now();
+        if (verbose) fprintf(stderr, "[sequence] device, reference and models ready after %.2f s\n", std::chrono::duration<double>(t_start - t_begin).count());
+        uint64_t total_reads = 0;
+
+        auto work = [&](int wi) {
+            Worker& W = *workers[wi];
+            Chunk c;
+            while (queue.pop(c)) {
+                if (failed) continue;
+                tksmseq_batch* b = nullptr;
+                const auto t_parse = now();
+                if (tksmseq_batch_from_mdf_text(W.ctx, c.text.data(), c.text.size(), &b)) { set_error(tksmseq_last_error(W.ctx)); continue; }
+                add_clk(0, t_parse);
+                uint64_t n = 0;
+                tksmseq_batch_info(b, &n, nullptr, nullptr);
+                Finished fin; fin.worker = wi; fin.n_reads = n;
+                bool ok = n == c.n_reads;
+                if (!ok) set_error("internal: the reader and the parser disagree on the number of reads of a batch");
+                bool waited = false;
+                auto emit = [&](int k, bool fastq, int mode, int quirk) -> bool {
+                    tksmseq_run_params p{};
+                    p.seed = (uint64_t)a.seed; p.first_read_index = c.first_read; p.read_index_stride = 1;
+                    p.mode = mode; p.fastq = fastq; p.compute_qual = compute_q; p.perfect_of_badread = quirk;
+                    tksmseq_result r{};
+                    const auto t_run = now();
+                    if (tksmseq_run(W.ctx, b, &p, &r)) { set_error(tksmseq_last_error(W.ctx)); return false; }
+                    add_clk(1, t_run);
+                    const auto t_wait = now();
+                    if (!waited) {                                  // the previous batch of this worker has been written
+                        std::unique_lock<std::mutex> l(W.m);
+                        W.cv.wait(l, [&] { return !W.host_busy || failed.load(); });
+                        waited = true;
+                    }
+                    add_clk(4, t_wait);
+                    if (failed) return false;
+                    const auto t_copy = now();
+                    if (!W.reserve(k, r.records_bytes)) { set_error("out of page-locked host memory"); return false; }
+                    if (tksmseq_result_download(W.ctx, W.host[k], nullptr)) { set_error(tksmseq_last_error(W.ctx)); return false; }
+                    add_clk(2, t_copy);
+                    fin.bytes[k] = r.records_bytes;
+                    return true;
+                };
+                if (ok && n) {
+                    if (!a.badread.empty()) ok = emit(0, wb.fastq, TKSMSEQ_MODE_BADREAD, 0);
+                    if (ok && !a.perfect.empty()) ok = a.badread.empty() ? emit(1, wp.fastq, TKSMSEQ_MODE_PERFECT, 0) : emit(1, wp.fastq, TKSMSEQ_MODE_BADREAD, 1);
+                }
+                tksmseq_batch_free(W.ctx, b);
+                if (!ok) continue;
+                { std::lock_guard<std::mutex> l(W.m); W.host_busy = true; }
+                { std::lock_guard<std::mutex> l(done_m); done[c.seq] = fin; }
+                done_cv.notify_all();
+            }
+        };
+        auto write_all = [&]() {
+            uint64_t next = 0;
+            for (;;) {
+                Finished fin;
+                {
+                    std::unique_lock<std::mutex> l(done_m);
+                    done_cv.wait(l, [&] { return done.count(next) || failed.load() || (reader_done && next >= n_batches); });
+                    if (failed || !done.count(next)) return;
+                    fin = done[next]; done.erase(next);
+                }
+                Worker& W = *workers[fin.worker];
+                bool ok = true;
+                const auto t_write = now();
+                if (fin.bytes[0]) ok = wb.write(W.host[0], fin.bytes[0]);
+                if (ok && fin.bytes[1]) ok = wp.write(W.host[1], fin.bytes[1]);
+                add_clk(3, t_write);
+                { std::lock_guard<std::mutex> l(W.m); W.host_busy = false; }
+                W.cv.notify_all();
+                if (!ok) { set_error("write failed"); return; }
+                total_reads += fin.n_reads;
+                next++;
+            }
+        };
+        std::vector<std::thread> threads;
+        for (int w = 0; w < n_workers; w++) threads.emplace_back(work, w);
+        std::thread writer(write_all);
+
+        // reader: batches of whole molecules, numbered; the first read index of a batch is known before it is parsed
         std::vector<char> buf;
-        std::vector<uint8_t> rec;
-        uint64_t read_index = 0, total_reads = 0;
+        uint64_t read_index = 0, seq = 0;
         bool eof = false;
         size_t have = 0;
-        int status = 0;
-        while (!eof || have) {
+        while ((!eof || have) && !failed) {
             // fill up to batch_bytes, then cut at the last molecule header so a batch holds whole molecules
+            const auto t_read = now();
             buf.resize(have + a.batch_bytes);
             size_t got = eof ? 0 : fread(buf.data() + have, 1, a.batch_bytes, in);
             if (got < a.batch_bytes) eof = true;
@@ -193,34 +362,38 @@ public:
                 cut = p;
             }
             if (cut == 0) break;
-            tksmseq_batch* b = nullptr;
-            if (tksmseq_batch_from_mdf_text(ctx, buf.data(), cut, &b)) { status = 1; fprintf(stderr, "Error: %s\n", tksmseq_last_error(ctx)); break; }
-            uint64_t n = 0;
-            tksmseq_batch_info(b, &n, nullptr, nullptr);
-            auto emit = [&](Writer& w, int mode, int quirk) -> bool {
-                tksmseq_run_params p{};
-                p.seed = (uint64_t)a.seed; p.first_read_index = read_index; p.read_index_stride = 1;
-                p.mode = mode; p.fastq = w.fastq; p.compute_qual = compute_q; p.perfect_of_badread = quirk;
-                tksmseq_result r{};
-                if (tksmseq_run(ctx, b, &p, &r)) return false;
-                rec.resize(r.records_bytes);
-                if (tksmseq_result_download(ctx, rec.data(), nullptr)) return false;
-                return w.write(rec.data(), rec.size());
-            };
-            bool ok = true;
-            if (n) {
-                if (!a.badread.empty()) ok = emit(wb, TKSMSEQ_MODE_BADREAD, 0);
-                if (ok && !a.perfect.empty()) ok = a.badread.empty() ? emit(wp, TKSMSEQ_MODE_PERFECT, 0) : emit(wp, TKSMSEQ_MODE_BADREAD, 1);
-            }
-            tksmseq_batch_free(ctx, b);
-            if (!ok) { status = 1; fprintf(stderr, "Error: %s\n", tksmseq_last_error(ctx)); break; }
-            read_index += n; total_reads += n;
+            Chunk c;
+            c.seq = seq++; c.first_read = read_index;
+            c.text.assign(buf.begin(), buf.begin() + (ptrdiff_t)cut);
+            c.n_reads = count_reads(c.text.data(), c.text.size());
+            read_index += c.n_reads;
+            add_clk(5, t_read);
+            queue.push(std::move(c));
             memmove(buf.data(), buf.data() + cut, have - cut);
             have -= cut;
         }
+        { std::lock_guard<std::mutex> l(done_m); n_batches = seq; reader_done = true; }
+        queue.close();
+        done_cv.notify_all();
+        for (auto& t : threads) t.join();
+        done_cv.notify_all();
+        writer.join();
+        int status = failed ? 1 : 0;
+        if (status) fprintf(stderr, "Error: %s\n", first_error.c_str());
+        if (verbose)
+            fprintf(stderr, "[sequence] %d batches, %d in flight, %.2f s streaming: parse %.2f, run %.2f, copy %.2f, wait for writer %.2f "
+                            "(summed over workers); write %.2f; read + count %.2f\n", (int)seq, n_workers,
+                    std::chrono::duration<double>(now() - t_start).count(), clk[0], clk[1], clk[2], clk[4], clk[3], clk[5]);
+        for (auto& W : workers) { tksmseq_host_free(W->host[0]); tksmseq_host_free(W->host[1]); }
+        for (int w = 1; w < n_workers; w++) tksmseq_destroy(workers[w]->ctx);
+        const auto t_close = now();
         fclose(in);
         wb.close(); wp.close();
+        const auto t_destroy = now();
         tksmseq_destroy(ctx);
+        if (verbose)
+            fprintf(stderr, "[sequence] closing the outputs %.2f s, releasing the device %.2f s\n",
+                    std::chrono::duration<double>(t_destroy - t_close).count(), std::chrono::duration<double>(now() - t_destroy).count());
         if (!status) fprintf(stderr, "Sequencing: %llu reads\n", (unsigned long long)total_reads);
         return status;
     }

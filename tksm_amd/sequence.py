@@ -87,6 +87,19 @@ class Sequencer:
         if stream is not None:
             self._chk(self._lib.tksmseq_set_stream(self._ctx, C.c_void_p(stream)))
 
+    def clone(self, stream=None):
+        """A second Sequencer on the same device that shares this one's packed reference and model tables (for another
+        host thread / batch in flight).  Close clones before the source."""
+        other = object.__new__(Sequencer)
+        other._lib = self._lib
+        ctx = C.c_void_p()
+        self._chk(self._lib.tksmseq_clone(self._ctx, C.byref(ctx)))
+        other._ctx = ctx
+        other._parent = self          # keeps the source alive
+        if stream is not None:
+            other._chk(self._lib.tksmseq_set_stream(other._ctx, C.c_void_p(stream)))
+        return other
+
     def close(self):
         if self._ctx:
             self._lib.tksmseq_destroy(self._ctx)

@@ -3,6 +3,7 @@ import os, sys, time, subprocess, numpy as np
 sys.path.insert(0, os.getcwd())
 from tksm_amd import synthetic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+extra = sys.argv[2:]                                   # e.g. --in-flight 1 --batch-bytes 16777216
 d = "/tmp/e2e"; os.makedirs(d, exist_ok=True)
 rs = np.random.RandomState(1)
 lens = [8_000_000] * 4
@@ -13,11 +14,13 @@ with open(f"{d}/ref.fa", "w") as f:
 m = synthetic.make_molecules(rs, lens, n, 1000, 200)
 t = time.time(); text = synthetic.mdf_text(m, [f"chr{c+1}" for c in range(4)]); open(f"{d}/mols.mdf", "w").write(text)
 print(f"MDF text {len(text)/1e6:.0f} MB for {n} molecules (generated in {time.time()-t:.0f} s)", flush=True)
-env = dict(os.environ, TKSM_MODELS=os.path.join(os.getcwd(), "tksm_amd", "models"))
+env = dict(os.environ, TKSMSEQ_VERBOSE="1", TKSM_MODELS=os.path.join(os.getcwd(), "tksm_amd", "models"))
 for args, name in ((["--perfect", f"{d}/p.fastq"], "perfect"), (["-o", f"{d}/b.fastq"], "badread+qual")):
     t = time.time()
-    r = subprocess.run([os.path.join("tksm_amd", "tksm"), "sequence", "-i", f"{d}/mols.mdf", "-r", f"{d}/ref.fa"] + args, capture_output=True, text=True, env=env)
+    r = subprocess.run([os.path.join("tksm_amd", "tksm"), "sequence", "-i", f"{d}/mols.mdf", "-r", f"{d}/ref.fa"] + args + extra, capture_output=True, text=True, env=env)
     dt = time.time() - t
     out = args[-1]
-    print(f"{name}: rc={r.returncode} {dt:.2f} s wall -> {n/dt:.0f} reads/s end to end, output {os.path.getsize(out)/1e6:.0f} MB", flush=True)
+    print(f"{name} {' '.join(extra)}: rc={r.returncode} {dt:.2f} s wall -> {n/dt:.0f} reads/s end to end, output {os.path.getsize(out)/1e6:.0f} MB", flush=True)
     if r.returncode: print(r.stderr[-500:])
+    for line in r.stderr.splitlines():
+        if line.startswith("[sequence]"): print(line)
