@@ -99,7 +99,7 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_tracefull, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
@@ -603,27 +603,36 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     } else {
         // ---- fast pipeline: k_init, then rounds of k_err (wave per read) + k_aln (lane per alignment)
         tk::FastBuffers FB{};
-        FB.fw = lcap / 64 + 8; FB.cw = (ncap / 8 + 8 + 3) & ~3;
+        FB.fw = lcap / 64 + 8;
         // job-id ranges: ~256 ranges of rs (multiple of 64) consecutive reads of the sorted order
         FB.rs = (uint32_t)((((n + 255) / 256) + 63) & ~63ull);
         FB.n_ranges = (uint32_t)((n + FB.rs - 1) / FB.rs);
         const uint64_t jcap = (uint64_t)FB.n_ranges * FB.rs;     // job slots (>= n)
-        const uint64_t groups = jcap / 64;
+        // rows of a range's jobs are sized by the range's longest read
+        std::vector<uint32_t> r_ncap(FB.n_ranges), r_cw(FB.n_ranges);
+        uint64_t tot_trace = 0, tot_jc = 0, tot_popd = 0;
+        for (uint32_t c = 0; c < FB.n_ranges; c++) {
+            const uint64_t last = std::min<uint64_t>((uint64_t)(c + 1) * FB.rs, n) - 1;
+            r_ncap[c] = (uint32_t)capf(b->raw_len[b->order[last]]);
+            r_cw[c] = (r_ncap[c] / 8 + 8 + 3) & ~3u;
+            tot_trace += (uint64_t)FB.rs * (r_ncap[c] + 16); tot_jc += (uint64_t)FB.rs * r_cw[c]; tot_popd += (uint64_t)FB.rs * r_ncap[c];
+        }
         HIPCHK(ctx, ctx->f_state.ensure(n * sizeof(tk::ReadState) + 64));
         HIPCHK(ctx, ctx->f_frag.ensure(n * (size_t)lcap + 64));
         HIPCHK(ctx, ctx->f_nb.ensure(n * (size_t)lcap * 2 + 64));
         HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
         for (int z = 0; z < 2; z++) {
             HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
-            HIPCHK(ctx, ctx->f_jcols[z].ensure(jcap * (size_t)FB.cw * 16 + 64));
+            HIPCHK(ctx, ctx->f_jcols[z].ensure(tot_jc * 16 + 64));
             HIPCHK(ctx, ctx->f_jwin[z].ensure(jcap * 16 + 64));
-            HIPCHK(ctx, ctx->f_jpopd[z].ensure(jcap * (size_t)ncap + 64));
+            HIPCHK(ctx, ctx->f_jpopd[z].ensure(tot_popd + 64));
             HIPCHK(ctx, ctx->f_jobcnt[z].ensure((size_t)FB.n_ranges * 128 + 64));
         }
         HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
-        HIPCHK(ctx, ctx->f_wsh.ensure(jcap * (size_t)FB.cw * 8 + 64));
+        HIPCHK(ctx, ctx->f_geo.ensure((size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo) + 64));
+        HIPCHK(ctx, ctx->f_wsh.ensure(tot_jc * 8 + 64));
         HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
-        HIPCHK(ctx, ctx->f_trace.ensure(groups * 64 * (size_t)(ncap + 16) * 8 + 64));
+        HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 8 + 64));
         FB.full_rows = (uint32_t)std::min<uint64_t>(jcap, 16384);
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(64));
@@ -634,6 +643,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
         FB.walk_sh = ctx->f_wsh.as<uint32_t>();
+        FB.geo_cur = ctx->f_geo.as<tk::RangeGeo>(); FB.geo_prev = FB.geo_cur + FB.n_ranges;
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
             FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[z].as<uint4>(); FB.job_win = ctx->f_jwin[z].as<unsigned long long>();
@@ -649,6 +659,22 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         uint32_t* hbase_cur = hgeo.data() + 2 * nr1;
         for (uint32_t c = 0; c <= FB.n_ranges; c++) hbase_cur[c] = hbase_prev[c] = c * FB.rs;
         HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
+        // where the rows of every range start in this round's (first half) and the previous round's (second half) job set
+        std::vector<tk::RangeGeo> hrg(2 * (size_t)FB.n_ranges);
+        auto place_ranges = [&]() {
+            uint64_t ot = 0, oj = 0, op = 0;
+            for (uint32_t c = 0; c < FB.n_ranges; c++) {
+                hrg[FB.n_ranges + c] = hrg[c];
+                const uint64_t slots = hbase_cur[c + 1] - hbase_cur[c];
+                tk::RangeGeo g{};
+                g.trace_off = ot; g.jc_off = oj; g.popd_off = op; g.wsh_off = oj;
+                g.tstride = r_ncap[c] + 16; g.cw = r_cw[c]; g.ncap = r_ncap[c];
+                hrg[c] = g;
+                ot += slots * g.tstride; oj += slots * g.cw; op += slots * g.ncap;
+            }
+            return hipMemcpyAsync(ctx->f_geo.p, hrg.data(), hrg.size() * sizeof(tk::RangeGeo), hipMemcpyHostToDevice, s);
+        };
+        HIPCHK(ctx, place_ranges());
         HIPCHK(ctx, ctx->f_svi.ensure(n * 128 + 64));
         HIPCHK(ctx, ctx->f_svk.ensure(n * 64 + 64));
         HIPCHK(ctx, ctx->f_sva.ensure(n * 512 + 64));
@@ -785,6 +811,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 for (uint32_t c = 0; c < FB.n_ranges; c++) { hbase_prev[c] = hbase_cur[c]; hbase_cur[c] = acc; acc += (hcnt[(size_t)c * 32] + 63) & ~63u; }
                 hbase_prev[FB.n_ranges] = hbase_cur[FB.n_ranges]; hbase_cur[FB.n_ranges] = acc;
                 HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
+                HIPCHK(ctx, place_ranges());
             }
         }
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];

@@ -101,6 +101,19 @@ struct ReadState {
     uint32_t res_mt, res_cols, res_fail, pad3;
 };
 
+// Where the jobs of one range of the sorted read order live in this round's job set.  Rows are as long as the longest
+// read of the range needs (a batch's longest read is twice its mean), and ranges are packed one after the other.
+struct RangeGeo {
+    uint64_t trace_off;   // u64 words into trace
+    uint64_t jc_off;      // records into job_cols
+    uint64_t popd_off;    // bytes into job_popd
+    uint64_t wsh_off;     // uint2 entries into walk_sh
+    uint32_t tstride;     // ncap + 16: predecessor columns per job row
+    uint32_t cw;          // block records per job row
+    uint32_t ncap;        // joined-window capacity of the range (multiple of 16)
+    uint32_t pad;
+};
+
 struct FastBuffers {
     ReadState* state;                 // [n_reads]
     uint8_t* st_frag;                 // [n_reads][lcap]
@@ -128,10 +141,11 @@ struct FastBuffers {
     // previous round's counts rounded up to whole waves and packed -- a round's jobs, records and predecessor columns
     // stay dense as the reads finish (fewer pages touched, no empty waves)
     const uint32_t* base_cur; const uint32_t* base_prev;
+    const RangeGeo* geo_cur; const RangeGeo* geo_prev;   // [n_ranges]
     uint16_t* sv_i; uint8_t* sv_kind; unsigned long long* sv_alt;   // [n_reads][64] draws of an interrupted round
     unsigned long long* prof;         // diagnostic builds (-DTKSM_PROF) only: per-section cycle sums
     uint32_t* slow_list;              // [n_reads]
-    int fw, cw;
+    int fw;
 };
 
 hipError_t launch_pack(const uint8_t* ascii, uint64_t n, uint64_t gstart, uint32_t* packed, uint32_t* blockflag,

@@ -92,6 +92,32 @@ DEV unsigned long long funnel128(unsigned long long x0, unsigned long long x1, i
     return mk64(alignbit(y2, y1, b), alignbit(y1, y0, b));
 }
 
+// fp64 helpers of the error loop's bookkeeping: the IEEE (correctly rounded) sequences the compiler emits for `sqrt(x)`
+// and `a / b`, without the range scaling (operands here are between 1e-3 and 1e5) and with the part that depends only
+// on the divisor computed once per read.  Bit-identical to the compiler's expansion, hence to the CPU oracle.
+DEV double sqrt_inrange(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+DEV double rcp_refined(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double r = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, r, y);
+    r = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, r, y);
+}
+DEV double div_inrange(double a, double b, double yb) {
+    const double q = a * yb;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, yb, q);
+}
+
 DEV uint8_t ref_base(const RefView& R, uint64_t g) {
     uint32_t ex = R.blocktab[g >> BLOCK_SHIFT];
     if (ex != NO_BLOCK) return R.pool[((uint64_t)ex << BLOCK_SHIFT) + (g & ((1u << BLOCK_SHIFT) - 1))];
@@ -829,8 +855,10 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
     unsigned long long* pl = reinterpret_cast<unsigned long long*>(stage);      // planes: code low, code high, shift bit 4
     uint32_t* shn = reinterpret_cast<uint32_t*>(stage + 24 * (size_t)lnw);
     uint32_t idx = 0;
+    const uint32_t rc = pos / FB.rs;                       // the read's range of the sorted order
     if (build) {
-        if (lane == 0) { const uint32_t c = pos / FB.rs; idx = FB.base_cur[c] + atomicAdd(&FB.job_cnt[c * 32u], 1u); }
+        ncap_l = min(ncap_l, (int)FB.geo_cur[rc].ncap);    // rows of the range's jobs are this long
+        if (lane == 0) idx = FB.base_cur[rc] + atomicAdd(&FB.job_cnt[rc * 32u], 1u);
         idx = __shfl(idx, 0, 64);
         uint32_t* z = reinterpret_cast<uint32_t*>(stage);
         for (int t = lane; t < 6 * lnw + lshw; t += 64) z[t] = 0u;
@@ -876,7 +904,8 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
         if (m > ncap_l) return idx;
         wave_sync();
         // one record per 8 columns: {shifts, code bits, entering fragment rows}; one zero record after the end
-        uint4* jc = FB.job_cols + (size_t)idx * FB.cw;
+        const RangeGeo G = FB.geo_cur[rc];
+        uint4* jc = FB.job_cols + G.jc_off + (size_t)(idx - FB.base_cur[rc]) * G.cw;
         const uint8_t* plb = stage;
         const unsigned long long* fp = FB.st_fplanes + r * 2ull * FB.fw;
         const int nrec = m / 8 + 2;
@@ -997,6 +1026,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const long long loop_limit = 100ll * L;
         bool done = false, need_aln = false;
         int r_src = 0, r_j = 0; double r_est = 0.0;
+        const double rcp_len = rcp_refined(frag_len);
+        int cc25 = change_count % 25;                       // changes since the last re-estimation point
         if (!resume && !S.pending)
             if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
         while (!done && !need_aln) {
@@ -1067,7 +1098,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
 #ifdef TKSM_ABLATE
             if (P.ablate == 3) return;
 #endif
-            double est_cur = 1.0 - errors / frag_len;
+            double est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
             // slot writes of the processed draws are deferred: every lane keeps the mask of its own draw and all of
             // them are written at once (before a dependent draw is evaluated, and at the end of the round)
             uint32_t wm_mine = 0u;
@@ -1118,25 +1149,38 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                     lens_s = __builtin_amdgcn_readlane(ev.lens, src);
                 }
                 if (am_s) {
-                    const double f15 = est * sqrt(est);
+                    const double f15 = est * sqrt_inrange(est);
                     uint32_t rem = am_s;
                     int last = -1;
-                    while (rem) {
-                        const int jj = __builtin_ctz(rem);
-                        rem &= rem - 1;
-                        last = jj;
-                        change_count++;
-                        const int len_j = (int)((lens_s >> (3 * jj)) & 7u);
-                        const int new_errors = len_j < 2 ? 1 : len_j - 1;
-                        errors += (double)new_errors * f15;
-                        if (change_count % 25 == 0) { need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
+                    const int cnt = __builtin_popcount(am_s);
+                    if (cc25 + cnt < 25) {
+                        // no re-estimation point inside this draw (the common case)
+                        while (rem) {
+                            const int jj = __builtin_ctz(rem);
+                            rem &= rem - 1;
+                            const int len_j = (int)((lens_s >> (3 * jj)) & 7u);
+                            errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
+                        }
+                        last = 31 - __builtin_clz(am_s);
+                        change_count += cnt; cc25 += cnt;
+                    } else {
+                        while (rem) {
+                            const int jj = __builtin_ctz(rem);
+                            rem &= rem - 1;
+                            last = jj;
+                            change_count++;
+                            const int len_j = (int)((lens_s >> (3 * jj)) & 7u);
+                            const int new_errors = len_j < 2 ? 1 : len_j - 1;
+                            errors += (double)new_errors * f15;
+                            if (++cc25 == 25) { cc25 = 0; need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
+                        }
                     }
                     wm_mine = lane == src ? (am_s & ((2u << last) - 1u)) : wm_mine;
                     if (need_aln) {                            // the round's draws travel with the state
                         FB.sv_i[r * 64 + lane] = (uint16_t)i; FB.sv_kind[r * 64 + lane] = (uint8_t)kind; FB.sv_alt[r * 64 + lane] = alt;
                         break;
                     }
-                    est_cur = 1.0 - errors / frag_len;
+                    est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
                 }
                 // stop rules at the top of the next iteration (also after a resumed draw that applied nothing more:
                 // the re-estimation changed `errors`)
@@ -1172,7 +1216,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             int m = 0;
             const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
             PROF_T(t_j2); PROF_ADD(5, t_j0, t_j2);
-            if (m > lds_ncap) {                              // output slot overflow: the host reruns with larger slots
+            if (m > min(lds_ncap, (int)FB.geo_cur[pos / FB.rs].ncap)) {   // output slot overflow: the host reruns with larger slots
                 finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
                 if (lane == 0) FB.state[r].stage = 2;
                 return;
@@ -1230,7 +1274,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
         if (fail) { go_slow(FB, r, lane, 3); return; }
         identity = cols ? (double)mt / (double)cols : 0.0;
-        const uint8_t* gp = FB.prev_popd + (size_t)S.job * P.ncap;
+        const uint32_t rc1 = pos / FB.rs;
+        const uint8_t* gp = FB.prev_popd + FB.geo_prev[rc1].popd_off + (size_t)(S.job - FB.base_prev[rc1]) * FB.geo_prev[rc1].ncap;
         wave_sync();
         for (int t = lane; t < m; t += 64) popd[t] = gp[t];
         wave_sync();
@@ -1632,14 +1677,16 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
     }
     J.fp = FB.st_fplanes + (size_t)r * 2 * FB.fw;
-    J.jc = FB.job_cols + (size_t)job * FB.cw;
-    J.jc0 = FB.job_cols + (size_t)(blockIdx.x * 64u) * FB.cw; J.cw = FB.cw;
+    const RangeGeo G = FB.geo_cur[rng];
+    const uint32_t rel0 = job0 - rbase;                              // the wave's first job within its range
+    J.jc0 = FB.job_cols + G.jc_off + (size_t)rel0 * G.cw; J.cw = (int)G.cw;
+    J.jc = J.jc0 + (size_t)lane * G.cw;
     J.win.x = 0ull; J.win.y = 0ull;
     if (J.act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
-    J.wsh0 = reinterpret_cast<uint2*>(FB.walk_sh) + (size_t)blockIdx.x * FB.cw * 64;
-    J.tstride = (size_t)(P.ncap + 16);                              // 8-byte predecessor columns
+    J.wsh0 = reinterpret_cast<uint2*>(FB.walk_sh) + G.wsh_off + (size_t)rel0 * G.cw;
+    J.tstride = (size_t)G.tstride;                                  // 8-byte predecessor columns
     J.trace = nullptr;                                               // full-width rows come from a small pool
-    J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + (size_t)(blockIdx.x * 64u) * J.tstride;
+    J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + G.trace_off + (size_t)rel0 * J.tstride;
     // full-width pass: 16-byte columns in a row of the pool; a lane that gets no row reports a failure (the read
     // then takes the wave-wide kernel)
     auto full_row = [&](bool want) -> bool {
@@ -1652,7 +1699,7 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         if (ok) J.trace = reinterpret_cast<unsigned long long*>(FB.trace_full) + (size_t)slot * (size_t)(P.ncap + 16) * 2;
         return ok;
     };
-    J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + (size_t)job * P.ncap);
+    J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + G.popd_off + (size_t)(rel0 + (uint32_t)lane) * G.ncap);
     int mmax = J.m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
@@ -1665,7 +1712,7 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         R = aln_full(J, ok, mmax, lane, tr_lds);
         if (J.act && !ok) R.fail = true;
     } else {
-        R = aln_fast(J, mmax, (P.ncap + 7) & ~7, lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
+        R = aln_fast(J, mmax, (int)((G.ncap + 7) & ~7u), lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
         const unsigned long long nf = __ballot(R.needfull);
         if (nf) {
             if (lane == 0) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
