@@ -3,12 +3,13 @@
 
 A "step" = one pass of the hot path (splice -> Badread errors -> q-scores -> FASTQ records) over one batch of
 synthetic molecules with inputs resident in HBM.  Steps are issued the way a streaming tool issues batches:
---pipeline (4) contexts per GPU, each on its own stream and host thread, take the steps in turn, so that the kernels of
+--pipeline (3) contexts per GPU, each on its own stream and host thread, take the steps in turn, so that the kernels of
 consecutive batches fill each other's gaps (the instruction-bound error loop next to the memory-bound alignment, the
 latency-bound last rounds of one batch underneath the bulk of the next).  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
 Badread error+qual model" -- synthetic 24 x 128 Mb genome (GRCh38 is not available offline), nanopore2020 error +
-q-score models, identity 84,99,5.5, FASTQ with computed qualities; processed as 12 steps of --batch = 1,048,576 molecules
-(12.6 M molecules, the default run).
+q-score models, identity 84,99,5.5, FASTQ with computed qualities; processed as 9 steps of --batch = 1,310,720 molecules
+(11.8 M molecules, the default run; sized so that rank 0 of an 8-GPU run also holds the gathered record streams:
+3 x 59 GB of contexts + 53 GB of gather and interleave buffers).
 
 N>1 (torchrun, one rank per GPU): molecules are sharded round-robin (global read g -> rank g mod P, counter-based
 RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RCCL gather of the per-rank record
@@ -87,9 +88,9 @@ def cpu_baseline(n_reads, mean_len, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1048576, help="molecules per GPU per step")
+    ap.add_argument("--batch", type=int, default=1310720, help="molecules per GPU per step")
     ap.add_argument("--mean-len", type=int, default=1000)
     ap.add_argument("--genome-contigs", type=int, default=24)
     ap.add_argument("--contig-mb", type=int, default=128)
@@ -98,7 +99,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU sample (0 = sized for ~20 s)")
     ap.add_argument("--skip-qual", action="store_true")
     ap.add_argument("--perfect", action="store_true", help="bench the integer splice path only (--perfect)")
-    ap.add_argument("--pipeline", type=int, default=4, help="contexts in flight per GPU (1 = one batch at a time)")
+    ap.add_argument("--pipeline", type=int, default=3, help="contexts in flight per GPU (1 = one batch at a time)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,8 +139,9 @@ def main():
     for i in range(n_ctx):
         c = Ctx()
         c.stream = torch.cuda.Stream(device=dev)
-        c.seqr = Sequencer(local_rank, stream=c.stream.cuda_stream)
         ctxs.append(c)
+    first = ctxs[0]
+    first.seqr = Sequencer(local_rank, stream=first.stream.cuda_stream)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
@@ -147,14 +149,19 @@ def main():
         codes = torch.randint(0, 4, (clen,), dtype=torch.uint8, device=dev, generator=gen)
         ascii_t = lut[codes.long()]
         torch.cuda.synchronize()
-        for c in ctxs:
-            c.seqr.add_contig(f"chr{ci + 1}", ascii_t)
+        first.seqr.add_contig(f"chr{ci + 1}", ascii_t)
         del codes, ascii_t
-    for i, c in enumerate(ctxs):
-        if not args.perfect:
-            c.seqr.set_identity(84.0, 99.0, 5.5)
+    torch.cuda.empty_cache()
+    if not args.perfect:
+        first.seqr.set_identity(84.0, 99.0, 5.5)
+        first.seqr.load_error_model(os.path.join(models, "nanopore2020.error.gz"))
+        first.seqr.load_qscore_model(os.path.join(models, "nanopore2020.qscore.gz"))
+    for c in ctxs[1:]:
+        c.seqr = first.seqr.clone(stream=c.stream.cuda_stream)      # shares the packed reference and the model tables
+        if os.environ.get("BENCH_PRIVATE_TABLES"):                    # diagnostic: private copies of the model tables
             c.seqr.load_error_model(os.path.join(models, "nanopore2020.error.gz"))
             c.seqr.load_qscore_model(os.path.join(models, "nanopore2020.qscore.gz"))
+    for i, c in enumerate(ctxs):
         rs = np.random.RandomState(2 + rank + 1000 * i)
         c.m = synthetic.make_molecules(rs, [clen] * args.genome_contigs, args.batch, args.mean_len, args.mean_len * 0.2, kind=args.kind,
                                        id_prefix=f"m{rank}")
@@ -316,6 +323,8 @@ def main():
     }
     out["cpu_baseline"] = cpu_base
     print(json.dumps(out))
+    for c in reversed(ctxs):
+        c.seqr.close()
     if world > 1:
         dist.destroy_process_group()
 

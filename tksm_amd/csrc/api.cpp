@@ -554,7 +554,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     HIPCHK(ctx, ctx->w_status.ensure(n * 4 + 16));
     HIPCHK(ctx, ctx->w_scan.ensure(tk::scan_temp_bytes(n) + 64));
     HIPCHK(ctx, ctx->w_trace.ensure((size_t)n_wgs * wpw * trace_words * 4 + 64));
-    HIPCHK(ctx, ctx->w_counter.ensure(64));
+    HIPCHK(ctx, ctx->w_counter.ensure(8192));
     HIPCHK(ctx, ctx->w_sums.ensure(64));
     HIPCHK(ctx, ctx->w_scratch.ensure(b->cache_scratch + 64));
     if (p->collect_stats) {
@@ -592,7 +592,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     O.read_list = nullptr; O.n_work = n;
     float ms_err = 0, ms_aln = 0, ms_other = 0;
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
-    HIPCHK(ctx, hipMemsetAsync(ctx->w_counter.p, 0, 8, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->w_counter.p, 0, 8192, s));
     HIPCHK(ctx, tk::launch_read_lengths(B, R, k, cap_num, cap_den, cap_add, ctx->w_rawlen.as<uint32_t>(), ctx->w_slotcap.as<uint64_t>(),
                                         ctx->w_status.as<uint32_t>(), s));
     HIPCHK(ctx, tk::launch_scan(ctx->w_slotcap.as<uint64_t>(), ctx->w_slotoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
@@ -722,26 +722,30 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         uint32_t cnt[4] = {0, 0, 0, 0};
         // reads with non-ACGT bytes are known after k_init: their wave-wide kernel (latency-bound, a few waves) starts
         // now on a second stream and runs underneath the rounds
-        uint32_t n_side = 0;
-        HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        if (cnt[2]) {
-            n_side = cnt[2];
+        // ... and so does the kernel of every read that leaves the fast pipeline later (an alignment the band
+        // representation cannot hold: about one read in two million): launched as soon as the host sees it
+        uint32_t n_side = 0, side_launches = 0;
+        auto launch_side = [&](uint32_t upto) -> int {
+            if (upto <= n_side || side_launches + 2 >= 1024) return TKSMSEQ_OK;
             if (!ctx->side) {
                 HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
                 HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
                 HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
             }
             tk::SimBuffers O2 = O;
-            O2.read_list = ctx->f_slow.as<uint32_t>(); O2.n_work = n_side;
-            O2.work_counter = ctx->w_counter.as<unsigned long long>() + 1;
+            O2.read_list = ctx->f_slow.as<uint32_t>() + n_side; O2.n_work = upto - n_side;
+            O2.work_counter = ctx->w_counter.as<unsigned long long>() + 1 + side_launches;     // zeroed at the start of the run
             HIPCHK(ctx, hipEventRecord(ctx->side_ev[0], s));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[0], 0));
-            HIPCHK(ctx, hipMemsetAsync((void*)O2.work_counter, 0, 8, ctx->side));
-            const uint64_t want2 = (n_side + wpw - 1) / wpw;
+            const uint64_t want2 = (O2.n_work + wpw - 1) / wpw;
             HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O2, (int)std::max<uint64_t>(1, std::min<uint64_t>(want2, (uint64_t)n_wgs)), wpw, ctx->side));
             HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], ctx->side));
-        }
+            n_side = upto; side_launches++;
+            return TKSMSEQ_OK;
+        };
+        HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
         uint32_t rounds = 0;
         for (;; rounds++) {
             select_set(rounds);
@@ -783,6 +787,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), (const void*)FB.job_cnt, (size_t)FB.n_ranges * 128, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
+            { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
             cnt[0] = 0;
             for (uint32_t c = 0; c < FB.n_ranges; c++) { hprefix[c] = cnt[0]; cnt[0] += hcnt[(size_t)c * 32]; }
             hprefix[FB.n_ranges] = cnt[0];

@@ -2,7 +2,7 @@
 import csv, glob, collections, json, re, sys
 
 d, nsteps = sys.argv[1], int(sys.argv[2])
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1048576
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1310720
 
 
 def sums(sub, counter):
@@ -19,8 +19,8 @@ def sums(sub, counter):
 fe, wr = sums("fetch", "FETCH_SIZE"), sums("write", "WRITE_SIZE")
 print(json.dumps({
     "batch": batch, "kind": "bulk",
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 4 --warmup 1 "
-              f"--no-cpu-baseline (4 contexts in flight: 4 warm-up + 4 timed steps); per-kernel sums over the {nsteps} steps divided by {nsteps}",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --steps 3 --warmup 1 "
+              f"--no-cpu-baseline (3 contexts in flight: 3 warm-up + 3 timed steps); per-kernel sums over the {nsteps} steps divided by {nsteps}",
     "units": f"bytes per step ({batch:,} reads); the counters report KiB",
     "calibration": "FETCH_SIZE used uncorrected: the dominant loads are 8-byte-per-lane and 64-byte-block accesses, not the "
                    "16 B/lane streaming reads the gfx950 1/2 factor of MI355X_MICROARCH.md applies to",
