@@ -129,7 +129,7 @@ def _make_molecules(rs, ref, n, mean_len, literal=True):
 
 
 @pytest.mark.parametrize("path", ["fast", "fast-small", "slow"])
-@pytest.mark.parametrize("mean_len,n,compute_q", [(300, 96, True), (1000, 64, True), (1000, 32, False), (2600, 24, True)])
+@pytest.mark.parametrize("mean_len,n,compute_q", [(300, 96, True), (1000, 64, True), (1000, 32, False), (2600, 24, True), (9000, 6, True)])
 def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n, compute_q, path):
     """whole records of the stochastic path, GPU vs oracle, same (seed, read index).  mean_len 2600 exercises
     the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = k_err per length bucket +

@@ -76,8 +76,12 @@ struct tksmseq_ctx : ContigLookup {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;            // wave-wide kernel for reads classified at k_init, underneath the rounds
-    hipEvent_t side_ev[2] = {};
+    // wave-wide kernel for the reads that cannot take the fast pipeline, underneath the rounds: a few streams, each with
+    // its own slice of the per-wave trace buffer, so that launches for reads found in different rounds overlap
+    static constexpr int N_SIDE = 4, SIDE_WAVES = 512;
+    hipStream_t side[N_SIDE] = {};
+    hipEvent_t side_start = nullptr, side_done[N_SIDE] = {};
+    bool side_used[N_SIDE] = {};
     bool own_stream = false;
     std::string err;
 
@@ -186,8 +190,9 @@ void tksmseq_destroy(tksmseq_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->evpool) (void)hipEventDestroy(ev);
-    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
-    for (auto& ev : ctx->side_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& st : ctx->side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto& ev : ctx->side_done) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->side_start) (void)hipEventDestroy(ctx->side_start);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -553,7 +558,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     HIPCHK(ctx, ctx->w_recoff.ensure((n + 1) * 8 + 16));
     HIPCHK(ctx, ctx->w_status.ensure(n * 4 + 16));
     HIPCHK(ctx, ctx->w_scan.ensure(tk::scan_temp_bytes(n) + 64));
-    HIPCHK(ctx, ctx->w_trace.ensure((size_t)n_wgs * wpw * trace_words * 4 + 64));
+    HIPCHK(ctx, ctx->w_trace.ensure(((size_t)n_wgs * wpw + (size_t)tksmseq_ctx::N_SIDE * tksmseq_ctx::SIDE_WAVES) * trace_words * 4 + 64));
     HIPCHK(ctx, ctx->w_counter.ensure(8192));
     HIPCHK(ctx, ctx->w_sums.ensure(64));
     HIPCHK(ctx, ctx->w_scratch.ensure(b->cache_scratch + 64));
@@ -725,21 +730,26 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         // ... and so does the kernel of every read that leaves the fast pipeline later (an alignment the band
         // representation cannot hold: about one read in two million): launched as soon as the host sees it
         uint32_t n_side = 0, side_launches = 0;
+        for (bool& u : ctx->side_used) u = false;
         auto launch_side = [&](uint32_t upto) -> int {
             if (upto <= n_side || side_launches + 2 >= 1024) return TKSMSEQ_OK;
-            if (!ctx->side) {
-                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
-                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_ev[1], hipEventDisableTiming));
+            const int k2 = (int)(side_launches % tksmseq_ctx::N_SIDE);
+            if (!ctx->side_start) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_start, hipEventDisableTiming));
+            if (!ctx->side[k2]) {
+                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[k2], hipStreamNonBlocking));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->side_done[k2], hipEventDisableTiming));
             }
             tk::SimBuffers O2 = O;
             O2.read_list = ctx->f_slow.as<uint32_t>() + n_side; O2.n_work = upto - n_side;
             O2.work_counter = ctx->w_counter.as<unsigned long long>() + 1 + side_launches;     // zeroed at the start of the run
-            HIPCHK(ctx, hipEventRecord(ctx->side_ev[0], s));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_ev[0], 0));
+            O2.trace = O.trace + ((size_t)n_wgs * wpw + (size_t)k2 * tksmseq_ctx::SIDE_WAVES) * trace_words;
+            HIPCHK(ctx, hipEventRecord(ctx->side_start, s));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side[k2], ctx->side_start, 0));
             const uint64_t want2 = (O2.n_work + wpw - 1) / wpw;
-            HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O2, (int)std::max<uint64_t>(1, std::min<uint64_t>(want2, (uint64_t)n_wgs)), wpw, ctx->side));
-            HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], ctx->side));
+            const int wgs2 = (int)std::max<uint64_t>(1, std::min<uint64_t>(want2, (uint64_t)(tksmseq_ctx::SIDE_WAVES / wpw)));
+            HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O2, wgs2, wpw, ctx->side[k2]));
+            HIPCHK(ctx, hipEventRecord(ctx->side_done[k2], ctx->side[k2]));
+            ctx->side_used[k2] = true;
             n_side = upto; side_launches++;
             return TKSMSEQ_OK;
         };
@@ -837,7 +847,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             fprintf(stderr, "[prof] rounds=%u slow=%u | per loop-invocation (n=%llu) cycles: load %.0f gen %.0f eval %.0f seq %.0f join %.0f job %.0f store %.0f total %.0f | final (n=%llu): join %.0f lookups %.0f total %.0f\n", rounds, cnt[2], pr[10], (double)pr[0] / (pr[10] + pr[12] + 1), (double)pr[1] / (pr[10] + 1), (double)pr[2] / (pr[10] + 1), (double)pr[3] / (pr[10] + 1), (double)pr[4] / (pr[10] + 1), (double)pr[5] / (pr[10] + 1), (double)pr[6] / (pr[10] + 1), (double)pr[9] / (pr[10] + 1), pr[12], (double)pr[7] / (pr[12] + 1), (double)pr[8] / (pr[12] + 1), (double)pr[11] / (pr[12] + 1));
         }
 #endif
-        if (n_side) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_ev[1], 0));   // also: the two launches share the per-wave trace
+        for (int k2 = 0; k2 < tksmseq_ctx::N_SIDE; k2++)
+            if (ctx->side_used[k2]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_done[k2], 0));
         if (cnt[2] > n_side) {
             // reads that left the fast pipeline later (alignment outside the band representation, tail cut): byte-exact
             // wave-wide path

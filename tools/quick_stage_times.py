@@ -15,7 +15,9 @@ m_=os.path.join('tksm_amd','models','badread')
 s.set_identity(84.0,99.0,5.5); s.load_error_model(os.path.join(m_,'nanopore2020.error.gz')); s.load_qscore_model(os.path.join(m_,'nanopore2020.qscore.gz'))
 B=int(sys.argv[1]) if len(sys.argv)>1 else 65536
 rs=np.random.RandomState(2)
-m=synthetic.make_molecules(rs,[16_000_000]*4,B,1000,200)
+KIND=sys.argv[2] if len(sys.argv)>2 else 'bulk'
+MEAN=int(sys.argv[3]) if len(sys.argv)>3 else 1000
+m=synthetic.make_molecules(rs,[16_000_000]*4,B,MEAN,MEAN//5,kind=KIND)
 b=s.batch_from_arrays(m["reads"],m["intervals"],m["mods"],m["literals"],m["literal_pool"],m["ids"],m["id_pool"])
 s.set_timing(True)
 print('setup %.1f s' % (time.time() - _t0), flush=True)
