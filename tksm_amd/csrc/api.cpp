@@ -103,7 +103,7 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_res, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_jobcnt[2], f_prof, f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_jobcnt[2], f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
@@ -636,7 +636,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
         HIPCHK(ctx, ctx->f_geo.ensure((size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo) + 64));
         HIPCHK(ctx, ctx->f_wsh.ensure(tot_jc * 8 + 64));
-        HIPCHK(ctx, ctx->f_res.ensure(n * 16 + 64));
         HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 8 + 64));
         FB.full_rows = (uint32_t)std::min<uint64_t>(jcap, 16384);
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * (size_t)(ncap + 16) * 16 + 64));
@@ -644,7 +643,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
-        FB.aln_res = ctx->f_res.as<uint32_t>(); FB.trace = ctx->f_trace.p; FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
+        FB.trace = ctx->f_trace.p; FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
         FB.walk_sh = ctx->f_wsh.as<uint32_t>();
@@ -684,11 +683,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_svk.ensure(n * 64 + 64));
         HIPCHK(ctx, ctx->f_sva.ensure(n * 512 + 64));
         FB.sv_i = ctx->f_svi.as<uint16_t>(); FB.sv_kind = ctx->f_svk.as<uint8_t>(); FB.sv_alt = ctx->f_sva.as<unsigned long long>();
-        HIPCHK(ctx, ctx->f_prof.ensure(256));
-        FB.prof = ctx->f_prof.as<unsigned long long>();
-#ifdef TKSM_PROF
-        HIPCHK(ctx, hipMemsetAsync(ctx->f_prof.p, 0, 256, s));
-#endif
         std::vector<uint32_t> hcnt((size_t)FB.n_ranges * 32);
         // length buckets over the sorted read order: each bucket gets its own LDS geometry
         struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; };
@@ -839,14 +833,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             fprintf(stderr, "[tksmseq] walk deviation from the generative row: <=3 %u, <=5 %u, <=7 %u, <=9 %u, <=11 %u, more %u\n", cc[10], cc[11], cc[12], cc[13], cc[14], cc[15]);
 #endif
         }
-#ifdef TKSM_PROF
-        {
-            unsigned long long pr[16];
-            HIPCHK(ctx, hipMemcpy(pr, ctx->f_prof.p, 128, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[prof] aln: waves %llu, waves with a full-width redo %llu, jobs redone %llu\n", pr[15], pr[14], pr[13]);
-            fprintf(stderr, "[prof] rounds=%u slow=%u | per loop-invocation (n=%llu) cycles: load %.0f gen %.0f eval %.0f seq %.0f join %.0f job %.0f store %.0f total %.0f | final (n=%llu): join %.0f lookups %.0f total %.0f\n", rounds, cnt[2], pr[10], (double)pr[0] / (pr[10] + pr[12] + 1), (double)pr[1] / (pr[10] + 1), (double)pr[2] / (pr[10] + 1), (double)pr[3] / (pr[10] + 1), (double)pr[4] / (pr[10] + 1), (double)pr[5] / (pr[10] + 1), (double)pr[6] / (pr[10] + 1), (double)pr[9] / (pr[10] + 1), pr[12], (double)pr[7] / (pr[12] + 1), (double)pr[8] / (pr[12] + 1), (double)pr[11] / (pr[12] + 1));
-        }
-#endif
         for (int k2 = 0; k2 < tksmseq_ctx::N_SIDE; k2++)
             if (ctx->side_used[k2]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_done[k2], 0));
         if (cnt[2] > n_side) {

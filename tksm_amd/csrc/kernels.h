@@ -127,11 +127,10 @@ struct FastBuffers {
     unsigned long long* job_win;      // [n_reads][2] code planes of the first 64 window rows
     uint32_t* walk_sh;                // [n_groups][cw][64][2] shift words per block and lane, written by the forward pass
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
-    uint32_t* aln_res;                // [n_reads][4] {matches, columns, fail, -}
     void* trace;                      // [n_jobs][ncap + 16] 8-byte predecessor columns (rows 16..47 of the band)
     void* trace_full;                 // [full_rows][ncap + 16] 16-byte columns: pool for full-width passes, counters[3] allocates
     uint32_t full_rows;
-    uint32_t* counters;               // [2] slow reads
+    uint32_t* counters;               // [16]: [2] reads on the slow list, [3] rows taken from the full-width pool, [4..] diagnostics
     uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
     uint32_t rs, n_ranges;
     // previous round's job set (double buffered): its jobs are the list of reads that are still running
@@ -143,7 +142,6 @@ struct FastBuffers {
     const uint32_t* base_cur; const uint32_t* base_prev;
     const RangeGeo* geo_cur; const RangeGeo* geo_prev;   // [n_ranges]
     uint16_t* sv_i; uint8_t* sv_kind; unsigned long long* sv_alt;   // [n_reads][64] draws of an interrupted round
-    unsigned long long* prof;         // diagnostic builds (-DTKSM_PROF) only: per-section cycle sums
     uint32_t* slow_list;              // [n_reads]
     int fw;
 };

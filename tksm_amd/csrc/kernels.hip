@@ -1,8 +1,11 @@
 // kernels.hip -- hand-written gfx950 kernels of the TKSM Seq hot path.
 //
-// One wavefront (64 lanes) owns one read from splice to finished sequence/qualities; its working
-// set (padded fragment, per-position edit slots, joined new sequence, per-position alignment ops)
-// lives in LDS.  Reference behaviour restated per stage (file:line into vpc-ccg/tksm):
+// Two implementations of the Badread path share the stage code below:
+//   * the fast pipeline: k_init, then rounds of k_err (one wavefront per read: error loop up to the next identity
+//     re-estimation, alignment job packed from LDS) and k_aln (one LANE per alignment, bit-parallel) -- ACGT reads;
+//   * k_simulate: one wavefront owns one read from splice to finished sequence/qualities, alignment done across the
+//     wave -- byte-exact for any alphabet; the exact fallback and the --perfect path.
+// Reference behaviour restated per stage (file:line into vpc-ccg/tksm):
 //   S0 pack        py/sequence.py:168-194  (FASTA text -> contig strings; here 2 bit/base + byte blocks)
 //   S1 splice      py/sequence.py:303-313, :224-239
 //   S2 identity    py/tksm_badread.py:741-745
@@ -937,13 +940,6 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
     return idx | (__ballot(fail) ? 0x80000000u : 0u);
 }
 
-#ifdef TKSM_PROF
-#define PROF_T(x) unsigned long long x = __builtin_amdgcn_s_memtime()
-#define PROF_ADD(slot, t0, t1) do { if (lane == 0) atomicAdd(&FB.prof[slot], (t1) - (t0)); } while (0)
-#else
-#define PROF_T(x)
-#define PROF_ADD(slot, t0, t1)
-#endif
 // ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | N[ncap] | aux[2*ncap] (owner u16 / popd)
 __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
                                               FastBuffers FB, const uint32_t* __restrict__ order, uint32_t begin, uint32_t count,
@@ -968,7 +964,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     }
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
-    PROF_T(t_begin);
     // LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (job staging / per-position alignment ops)
     const int per_wave = lds_lcap * 3 + lds_ncap + 128;
     uint8_t* frag = lds_raw + (size_t)wave * per_wave;
@@ -995,7 +990,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
     }
     wave_sync();
-    PROF_T(t_loaded); PROF_ADD(0, t_begin, t_loaded);
 #ifdef TKSM_ABLATE
     if (P.ablate == 1) return;
 #endif
@@ -1031,7 +1025,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         if (!resume && !S.pending)
             if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
         while (!done && !need_aln) {
-            PROF_T(t_r0);
             const uint32_t n = n_base + (uint32_t)lane;
             const bool live = (long long)n + 1 <= loop_limit;
             int i, kind = 0;
@@ -1041,14 +1034,14 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             const Ph4 d = philox(P.seed, g, ST_DRAW, n);
             i = (int)__umulhi(d.x, (uint32_t)(max_kmer_index + 1));
 #ifdef TKSM_ABLATE
-            if (P.ablate == 6) { if (i == -12345 || d.y == 77u) FB.prof[0] = d.z + d.w; return; }
+            if (P.ablate == 6) { if (i == -12345 || d.y == 77u) FB.counters[15] = d.z + d.w; return; }
 #endif
             if (live) {
                 int kidx = 0; bool valid = true;
                 for (int jj = 0; jj < k; jj++) { const int cc = code_of(frag[i + jj]); valid &= cc >= 0; kidx = (kidx << 2) | (cc & 3); }
 #ifdef TKSM_ABLATE
-                if (P.ablate == 7) { if (kidx == -12345) FB.prof[0] = d.z + d.w + d.y; return; }
-                if (P.ablate == 8) { const uint2 q2 = EM.pself2[kidx]; if (q2.x == 12345u && q2.y == d.y) FB.prof[0] = d.z + d.w; return; }
+                if (P.ablate == 7) { if (kidx == -12345) FB.counters[15] = d.z + d.w + d.y; return; }
+                if (P.ablate == 8) { const uint2 q2 = EM.pself2[kidx]; if (q2.x == 12345u && q2.y == d.y) FB.counters[15] = d.z + d.w; return; }
 #endif
                 if (EM.type == 0 || !valid) kind = 2;
                 else {
@@ -1068,7 +1061,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 }
             }
             }
-            PROF_T(t_r1); PROF_ADD(1, t_r0, t_r1);
 #ifdef TKSM_ABLATE
             if (P.ablate == 2) return;
 #endif
@@ -1094,7 +1086,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 depm = __ballot(acc && dep);
                 if (resume) depm |= 1ull << S.resume_src;
             }
-            PROF_T(t_r2); PROF_ADD(2, t_r1, t_r2);
 #ifdef TKSM_ABLATE
             if (P.ablate == 3) return;
 #endif
@@ -1194,7 +1185,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
 #ifdef TKSM_ABLATE
             if (P.ablate == 22) return;
 #endif
-            PROF_T(t_r3); PROF_ADD(3, t_r2, t_r3);
             if (!done && !need_aln) {
                 if (dead) { done = true; st_draws = (int)loop_limit; }
                 else n_base += 64;
@@ -1212,10 +1202,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
                 nrows = 1000;
             }
-            PROF_T(t_j0);
             int m = 0;
             const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
-            PROF_T(t_j2); PROF_ADD(5, t_j0, t_j2);
             if (m > min(lds_ncap, (int)FB.geo_cur[pos / FB.rs].ncap)) {   // output slot overflow: the host reruns with larger slots
                 finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
                 if (lane == 0) FB.state[r].stage = 2;
@@ -1232,8 +1220,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
                 FB.state[r] = S;
             }
-            PROF_T(t_j3); PROF_ADD(6, t_j2, t_j3); PROF_ADD(9, t_begin, t_j3);
-            if (lane == 0) atomicAdd(&FB.prof[10], 1ull);
             return;
         }
         // the loop has ended: write the final slots back once (the FINAL stage re-joins from them)
@@ -1243,7 +1229,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     }
 
     // ---- :434-437 trims and the joined sequence (both stages)
-    PROF_T(t_f0);
     int start_trim, end_trim;
     {
         int v1 = lane < k ? slot_len(nb[lane]) : 0, v2 = lane < k ? slot_len(nb[L - k + lane]) : 0;
@@ -1268,7 +1253,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         }
         return;
     }
-    PROF_T(t_f1); PROF_ADD(7, t_f0, t_f1);
     if (want_q) {
         // ---- S5 q-scores from the alignment k_aln left in job_popd (py/tksm_badread.py:607-655)
         const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
@@ -1331,8 +1315,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
                 start_trim, end_trim, errors, target, lane);
     if (lane == 0) FB.state[r].stage = 2;
-    PROF_T(t_f2); PROF_ADD(8, t_f1, t_f2); PROF_ADD(11, t_begin, t_f2);
-    if (lane == 0) atomicAdd(&FB.prof[12], 1ull);
 }
 
 // ---- tail cut: reads still in the error loop when few are left are finished by the wave-wide kernel in one launch
@@ -1356,7 +1338,6 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
 // back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
 struct AlnJob {
     bool act; int p0, n, m, mode;
-    const unsigned long long* fp;    // fragment planes of the read, {lo, hi} word pairs (full-width redo only)
     const uint4* jc;                 // the job's block records
     const uint4* jc0;                // records of the wave's first job
     int cw;                          // records per job
@@ -1676,7 +1657,6 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         const uint32_t* meta = FB.job_meta + 4ull * job;
         r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
     }
-    J.fp = FB.st_fplanes + (size_t)r * 2 * FB.fw;
     const RangeGeo G = FB.geo_cur[rng];
     const uint32_t rel0 = job0 - rbase;                              // the wave's first job within its range
     J.jc0 = FB.job_cols + G.jc_off + (size_t)rel0 * G.cw; J.cw = (int)G.cw;
