@@ -392,3 +392,34 @@ def test_clone_shares_reference_and_models_across_threads(oracle_models):
     for c in clones:
         c.close()
     s.close()
+
+
+@pytest.mark.parametrize("kind", ["bulk", "scrna"])
+def test_perfect_direct_kernel_equals_wave_wide_kernel(monkeypatch, kind):
+    """--perfect: the direct kernel (packed reference -> records) and the wave-wide kernel (splice into LDS, emit) write
+    the same bytes for 65 536 synthetic molecules (both strands, substitutions, literals, N / IUPAC / lower-case blocks)."""
+    from tksm_amd import synthetic
+    from tksm_amd.sequence import Sequencer
+    rs = np.random.RandomState(3)
+    lens = [1_000_000] * 3
+    contigs = []
+    for n in lens:
+        seq = bytearray(rs.choice(np.frombuffer(b"ACGTacgt", np.uint8), n).tobytes())
+        for _ in range(20):
+            p = int(rs.randint(0, n - 500))
+            seq[p:p + int(rs.randint(1, 400))] = b"N" * 400 if rs.rand() < 0.5 else b"RYKM" * 100
+        contigs.append(bytes(seq[:n]))
+    m = synthetic.make_molecules(rs, lens, 65536, 700, 200, kind=kind)
+    out = {}
+    for mode in ("direct", "wave"):
+        monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if mode == "wave" else "0")
+        s = Sequencer(0)
+        for c, seq in enumerate(contigs):
+            s.add_contig(f"chr{c + 1}", seq)
+        b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+        for fastq in (True, False):
+            out[mode, fastq] = s.run(b, target="perfect", fastq=fastq, seed=9, first_read_index=5, stride=2).download()
+        s.close()
+    for fastq in (True, False):
+        assert out["direct", fastq][0] == out["wave", fastq][0]
+        assert (out["direct", fastq][1] == out["wave", fastq][1]).all()

@@ -603,7 +603,10 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     HIPCHK(ctx, tk::launch_scan(ctx->w_slotcap.as<uint64_t>(), ctx->w_slotoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     const bool fast = badread && !ctx->force_slow && n > 0;
-    if (!fast) {
+    const bool direct = !badread && !ctx->force_slow && !p->collect_stats;   // --perfect: packed reference -> records, no working set
+    if (direct) {
+        HIPCHK(ctx, tk::launch_perfect_lengths(B, R, P, O, s));
+    } else if (!fast) {
         HIPCHK(ctx, tk::launch_simulate(B, R, EM, QM, IM, P, O, n_wgs, wpw, s));
     } else {
         // ---- fast pipeline: k_init, then rounds of k_err (wave per read) + k_aln (lane per alignment)
@@ -882,7 +885,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->w_records.ensure(total + 64));
         records = ctx->w_records.as<uint8_t>();
     }
-    HIPCHK(ctx, tk::launch_emit(B, P, O, ctx->w_recoff.as<uint64_t>(), records, s));
+    if (direct) HIPCHK(ctx, tk::launch_perfect(B, R, P, O, ctx->w_recoff.as<uint64_t>(), records, ctx->n_cus, s));
+    else HIPCHK(ctx, tk::launch_emit(B, P, O, ctx->w_recoff.as<uint64_t>(), records, s));
     if (T) {
         HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
         HIPCHK(ctx, hipEventSynchronize(ctx->ev[4]));

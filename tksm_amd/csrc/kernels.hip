@@ -1720,6 +1720,29 @@ DEV int put_u(uint8_t* o, unsigned long long v) {
     return d;
 }
 
+// record header up to "molecule_id=" (py/sequence.py:252-288): "@<uuid> length=.. error_free_length=.. read_identity=..% molecule_id="
+DEV int format_header(uint8_t* hdr, const SimParams& P, uint64_t g, uint32_t out_len, uint32_t raw_len, double identity) {
+    int kx = 0;
+    hdr[kx++] = P.fastq ? '@' : '>';
+    const Ph4 id = philox(P.seed, g, ST_ID, 0);
+    const uint32_t w[4] = {id.x, id.y, id.z, id.w};
+    int nib = 0;
+    for (int a = 0; a < 4; a++)
+        for (int b = 7; b >= 0; b--) {
+            if (nib == 8 || nib == 12 || nib == 16 || nib == 20) hdr[kx++] = '-';
+            const uint32_t v = (w[a] >> (4 * b)) & 15u;
+            hdr[kx++] = (uint8_t)(v < 10 ? '0' + v : 'a' + v - 10); nib++;
+        }
+    kx += put_str(hdr + kx, " length="); kx += put_u(hdr + kx, out_len);
+    kx += put_str(hdr + kx, " error_free_length="); kx += put_u(hdr + kx, raw_len);
+    kx += put_str(hdr + kx, " read_identity=");
+    const long long h = pct_hundredths(identity);
+    kx += put_u(hdr + kx, (unsigned long long)(h / 100));
+    hdr[kx++] = '.'; hdr[kx++] = (uint8_t)('0' + (h % 100) / 10); hdr[kx++] = (uint8_t)('0' + h % 10);
+    kx += put_str(hdr + kx, "% molecule_id=");
+    return kx;
+}
+
 __global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
                                                uint8_t* __restrict__ records) {
     __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
@@ -1730,27 +1753,7 @@ __global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffe
     const uint64_t g = P.first_read + r * P.stride;
     const uint32_t out_len = O.out_len[r], raw_len = P.quirk_perfect ? O.out_len[r] : O.raw_len[r];
     int hl = 0;
-    if (lane == 0) {
-        int kx = 0;
-        hdr[kx++] = P.fastq ? '@' : '>';
-        const Ph4 id = philox(P.seed, g, ST_ID, 0);
-        const uint32_t w[4] = {id.x, id.y, id.z, id.w};
-        int nib = 0;
-        for (int a = 0; a < 4; a++)
-            for (int b = 7; b >= 0; b--) {
-                if (nib == 8 || nib == 12 || nib == 16 || nib == 20) hdr[kx++] = '-';
-                const uint32_t v = (w[a] >> (4 * b)) & 15u;
-                hdr[kx++] = (uint8_t)(v < 10 ? '0' + v : 'a' + v - 10); nib++;
-            }
-        kx += put_str(hdr + kx, " length="); kx += put_u(hdr + kx, out_len);
-        kx += put_str(hdr + kx, " error_free_length="); kx += put_u(hdr + kx, raw_len);
-        kx += put_str(hdr + kx, " read_identity=");
-        const long long h = pct_hundredths(O.identity[r]);
-        kx += put_u(hdr + kx, (unsigned long long)(h / 100));
-        hdr[kx++] = '.'; hdr[kx++] = (uint8_t)('0' + (h % 100) / 10); hdr[kx++] = (uint8_t)('0' + h % 10);
-        kx += put_str(hdr + kx, "% molecule_id=");
-        hl = kx;
-    }
+    if (lane == 0) hl = format_header(hdr, P, g, out_len, raw_len, O.identity[r]);
     hl = __shfl(hl, 0, 64);
     wave_sync();
     uint8_t* dst = records + rec_off[r];
@@ -1775,6 +1778,77 @@ __global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffe
         for (uint32_t t = lane; t < out_len; t += 64) dst[t] = real_q ? qual[t] : (uint8_t)'K';
         dst += out_len;
         if (lane == 0) dst[0] = '\n';
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// --perfect (py/sequence.py:261-270, :303-313): the error-free sequence goes from the packed reference straight into
+// its record -- no per-read working set, no intermediate copy.  k_perfect_lengths gives every record its length
+// (then a scan), k_perfect writes header, bases and the constant quality line.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_perfect_lengths(BatchView B, RefView R, SimParams P, SimBuffers O) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.n_reads) return;
+    const uint32_t L = O.raw_len[r], idl = B.ids[2 * r + 1];
+    // a substitution outside its slice is an error of the input (the reference raises IndexError)
+    uint32_t status = 0;
+    const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+    for (uint32_t ii = 0; ii < ic; ii++) {
+        const Ivl iv = load_interval(B, R, ib + ii);
+        for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++)
+            if (B.mods[2ull * mi] >= iv.len) status |= 2;
+    }
+    if (status) O.status[r] |= status;
+    uint64_t rec = 1 + 36 + 8 + ndigits(L) + 19 + ndigits(L) + 15 + 3 + 3 + 14 + idl + 1;   // identity "100.00"
+    rec += (uint64_t)L + 1;
+    if (P.fastq) rec += 2 + (uint64_t)L + 1;
+    O.out_len[r] = L; O.identity[r] = 1.0; O.rec_len[r] = rec;
+}
+
+__global__ __launch_bounds__(256) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
+                                                  uint8_t* __restrict__ records) {
+    __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t* hdr = hdr_all[wave];
+    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_PER_WG;
+    for (uint64_t r = (uint64_t)blockIdx.x * WAVES_PER_WG + wave; r < B.n_reads; r += n_waves) {
+        const uint32_t L = O.raw_len[r];
+        int hl = 0;
+        wave_sync();
+        if (lane == 0) hl = format_header(hdr, P, P.first_read + r * P.stride, L, L, 1.0);
+        hl = __shfl(hl, 0, 64);
+        wave_sync();
+        uint8_t* dst = records + rec_off[r];
+        for (int t = lane; t < hl; t += 64) dst[t] = hdr[t];
+        dst += hl;
+        const uint32_t ido = B.ids[2 * r], idl = B.ids[2 * r + 1];
+        for (uint32_t t = lane; t < idl; t += 64) dst[t] = B.idpool[ido + t];
+        dst += idl;
+        if (lane == 0) dst[0] = '\n';
+        dst += 1;
+        // splice: slices of the contigs / literals, substitutions applied before the strand flip, later ones win
+        const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+        for (uint32_t ii = 0; ii < ic; ii++) {
+            const Ivl iv = load_interval(B, R, ib + ii);
+            const uint32_t len = iv.len;
+            for (uint32_t t = lane; t < len; t += 64) {
+                const uint32_t src = iv.minus ? len - 1 - t : t;             // position in the slice
+                uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + iv.s + src]) : ref_base(R, iv.gbase + iv.s + src);
+                for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++)
+                    if (B.mods[2ull * mi] == src) b = (uint8_t)B.mods[2ull * mi + 1];
+                dst[t] = iv.minus ? comp(b) : b;
+            }
+            dst += len;
+        }
+        if (lane == 0) dst[0] = '\n';
+        dst += 1;
+        if (P.fastq) {
+            if (lane == 0) { dst[0] = '+'; dst[1] = '\n'; }
+            dst += 2;
+            for (uint32_t t = lane; t < L; t += 64) dst[t] = (uint8_t)'K';
+            dst += L;
+            if (lane == 0) dst[0] = '\n';
+        }
     }
 }
 
@@ -1926,6 +2000,18 @@ hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records, hipStream_t s) {
     if (!b.n_reads) return hipSuccess;
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((b.n_reads + WAVES_PER_WG - 1) / WAVES_PER_WG)), dim3(256), 0, s, b, p, o, rec_off, records);
+    return hipGetLastError();
+}
+hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    hipLaunchKernelGGL(k_perfect_lengths, dim3((unsigned)((b.n_reads + 255) / 256)), dim3(256), 0, s, b, r, p, o);
+    return hipGetLastError();
+}
+hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,
+                          int n_cus, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    const uint64_t want = (b.n_reads + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    hipLaunchKernelGGL(k_perfect, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)n_cus * 8)), dim3(64 * WAVES_PER_WG), 0, s, b, r, p, o, rec_off, records);
     return hipGetLastError();
 }
 hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank, uint64_t n_total,
