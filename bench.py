@@ -103,6 +103,10 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries the one JSON line and nothing else: libraries that print while they initialise (RCCL) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     cpu_base = None
     if world == 1 and not args.no_cpu_baseline and not args.perfect:
         # oracle leg first, before this process touches the GPU (it forks worker processes)
@@ -121,8 +125,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the Seq hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # TKSM_BENCH_FORCE_EXCHANGE=1: run the N > 1 code path (RCCL gather + device interleave of every step) on one rank,
+    # to exercise it where only one GPU is available
+    exchange_on = world > 1 or bool(os.environ.get("TKSM_BENCH_FORCE_EXCHANGE"))
+    if exchange_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     import threading
 
     # ---- inputs resident in HBM before the timed region: genome packed on the device, models, one batch per context
@@ -223,7 +232,7 @@ def main():
                     c = ctxs[i]
                     c.free.acquire()
                     results[j] = run_step(c, first + j)
-                    if world == 1:
+                    if not exchange_on:
                         c.free.release()
                     done[j].set()
             except Exception as e:      # surface in the main thread
@@ -233,7 +242,7 @@ def main():
         th = [threading.Thread(target=worker, args=(i,)) for i in range(min(n_ctx, count))]
         for x in th:
             x.start()
-        if world > 1:
+        if exchange_on:
             for j in range(count):
                 done[j].wait()
                 if errors:
@@ -249,7 +258,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchange_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -268,7 +277,7 @@ def main():
     rec_bytes = sum(r.records_bytes for r in results)
     bases_in = sum(r.bases_in for r in results)
     bases_out = sum(r.bases_out for r in results)
-    if world > 1:
+    if exchange_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -278,8 +287,7 @@ def main():
     else:
         bases_in_all, bases_out_all = float(bases_in), float(bases_out)
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     reads = args.batch * world * args.steps
     value = reads / elapsed
@@ -316,7 +324,7 @@ def main():
                                if not args.perfect else "Bulk molecules, --perfect splice path, FASTQ",
                    "kind": args.kind, "molecules_per_gpu_per_step": args.batch, "mean_len": args.mean_len,
                    "compute_qual": bool(compute_q and not args.perfect), "sharding": f"round-robin x{world}",
-                   "ordering_gather": world > 1, "contexts_in_flight_per_gpu": n_ctx},
+                   "ordering_gather": exchange_on, "contexts_in_flight_per_gpu": n_ctx},
         "gbases_per_s": bases_in_all / elapsed / 1e9,
         "gbases_out_per_s": bases_out_all / elapsed / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -325,10 +333,13 @@ def main():
                      "all_kernels_ms": float(np.mean(tot_ms)), "stage_ms": stage},
     }
     out["cpu_baseline"] = cpu_base
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     for c in reversed(ctxs):
         c.seqr.close()
-    if world > 1:
+    if exchange_on:
         dist.destroy_process_group()
 
 
