@@ -642,7 +642,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 8 + 64));
         FB.full_rows = (uint32_t)std::min<uint64_t>(jcap, 16384);
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * (size_t)(ncap + 16) * 16 + 64));
-        HIPCHK(ctx, ctx->f_counters.ensure(64));
+        HIPCHK(ctx, ctx->f_counters.ensure(256));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
@@ -716,7 +716,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         };
         std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other, 1 err, 2 aln, -1 host gap
         HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, n * (size_t)lcap * 2, s));
-        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 64, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 256, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, tk::WAVES_PER_WG, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
@@ -833,6 +833,15 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
                     (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);
 #ifdef TKSM_ABLATE
+            {
+                uint32_t hh[64];
+                HIPCHK(ctx, hipMemcpy(hh, ctx->f_counters.p, 256, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[tksmseq] full-width walks, lowest band row visited (bins of 4):");
+                for (int q = 0; q < 16; q++) fprintf(stderr, " %u", hh[16 + q]);
+                fprintf(stderr, "\n[tksmseq] full-width walks, highest band row visited (bins of 4):");
+                for (int q = 0; q < 16; q++) fprintf(stderr, " %u", hh[32 + q]);
+                fprintf(stderr, "\n");
+            }
             fprintf(stderr, "[tksmseq] walk deviation from the generative row: <=3 %u, <=5 %u, <=7 %u, <=9 %u, <=11 %u, more %u\n", cc[10], cc[11], cc[12], cc[13], cc[14], cc[15]);
 #endif
         }

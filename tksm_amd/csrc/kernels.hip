@@ -1497,6 +1497,12 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
             code = i == 0 ? 1 : code;                     // row 0: only left
             const bool bad = (i > 0 && b < 0) || cols > lim;
             const bool out = i > 0 && b >= 0 && b <= 63 && (uint32_t)bs > 31u;
+#ifdef TKSM_ABLATE
+            if (ablate == 21 && out && !bad) {      // where does the walk leave the stored rows? [0]: j < 64, [1]: j > m - 64, [2]: elsewhere; [3]: above, [4]: below
+                atomicAdd(&devhist[j < 64 ? 0 : (j > m - 64 ? 1 : 2)], 1u);
+                atomicAdd(&devhist[bs < 0 ? 3 : 4], 1u);
+            }
+#endif
             if (bad || out) { fail |= bad; needfull |= out && !bad; break; }
 #ifdef TKSM_ABLATE
             if (tt > 1) maxdev = max(maxdev, abs(bs - 15));
@@ -1535,7 +1541,7 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
 }
 
 // ---- full-width redo (rare): all 64 rows of every column, 16 bytes per column, 4 columns per LDS block
-DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds) {
+DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds, uint32_t* hist = nullptr) {
     const int n = J.n, m = J.m, mode = J.mode;
     const unsigned long long M64 = mode ? ~0ull : 0ull;
     unsigned long long Pv = ~0ull, Mv = 0ull;
@@ -1574,6 +1580,9 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
         }
     }
     // walk back: every lane on its own job, 4 columns (64 bytes) per block, next block requested one block ahead
+#ifdef TKSM_ABLATE
+    int minb = 63, maxb = -1;
+#endif
     int i = n, j = m, tt = t;
     uint32_t mt = 0, cols = 0;
     int dpend = 0;
@@ -1608,6 +1617,9 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             code = b > 63 ? 0 : code;
             code = i == 0 ? 1 : code;
             if ((i > 0 && b < 0) || cols > (uint32_t)(n + m)) { fail = true; break; }
+#ifdef TKSM_ABLATE
+            if (tt > 1 && i > 0 && b <= 63) { minb = min(minb, b); maxb = max(maxb, b); }
+#endif
             cols++;
             const bool up = code == 0;
             i -= code != 1 ? 1 : 0;
@@ -1627,13 +1639,47 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
         }
     }
     if (act && !fail && i > 0) { cols += (uint32_t)i; i = 0; }
+#ifdef TKSM_ABLATE
+    if (hist && act && !fail && maxb >= 0) { atomicAdd(&hist[16 + minb / 4], 1u); atomicAdd(&hist[32 + maxb / 4], 1u); }
+#endif
     AlnRes R;
     R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = false;
     return R;
 }
 
+// Job geometry shared by the alignment kernels: `job0` is the first job id of the wave (all 64 lanes of a k_aln wave
+// belong to one range), `job` the lane's own.
+DEV uint32_t range_of_job(const FastBuffers& FB, uint32_t job0) {
+    uint32_t rng = 0, hi2 = FB.n_ranges - 1;
+    while (rng < hi2) { const uint32_t mid = (rng + hi2 + 1) >> 1; if (FB.base_cur[mid] <= job0) rng = mid; else hi2 = mid - 1; }
+    return rng;
+}
+DEV void load_job(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act, AlnJob& J, uint32_t& r) {
+    J.act = act;
+    r = 0;
+    J.p0 = 0; J.n = 0; J.m = 0; J.mode = 0;
+    if (act) {
+        const uint32_t* meta = FB.job_meta + 4ull * job;
+        r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
+    }
+    const RangeGeo G = FB.geo_cur[rng];
+    const uint32_t rel = job - FB.base_cur[rng];
+    J.cw = (int)G.cw;
+    J.jc = FB.job_cols + G.jc_off + (size_t)rel * G.cw;
+    J.win.x = 0ull; J.win.y = 0ull;
+    if (act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
+    J.tstride = (size_t)G.tstride;                                  // 8-byte predecessor columns
+    J.trace = nullptr;                                               // full-width rows come from a small pool
+    J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + G.popd_off + (size_t)rel * G.ncap);
+}
+DEV void store_result(const FastBuffers& FB, uint32_t r, const AlnRes& R) {
+    ReadState* st = FB.state + r;
+    st->res_mt = R.mt; st->res_cols = R.cols; st->res_fail = (R.fail || R.needfull) ? 1u : 0u;
+}
+
 // FULL_ONLY: rounds with few jobs are bound by the latency of one lane's pass; they go straight to the full-width
-// pass (no redo to wait for, traffic is irrelevant)
+// pass (traffic is irrelevant).  Otherwise: 8-byte columns, and the lanes whose walk leaves the stored rows are redone at
+// full width in place.  counters[3] allocates rows of the full-width pool in both cases.
 template <bool FULL_ONLY>
 __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
     __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
@@ -1641,45 +1687,27 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
     const int lane = threadIdx.x;
     const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
     // job ids of a range start at its wave-aligned base (this round's bases are the packed counts of the previous round)
-    uint32_t rng = 0;
-    {
-        uint32_t hi2 = FB.n_ranges - 1;
-        while (rng < hi2) { const uint32_t mid = (rng + hi2 + 1) >> 1; if (FB.base_cur[mid] <= job0) rng = mid; else hi2 = mid - 1; }
-    }
+    const uint32_t rng = range_of_job(FB, job0);
     const uint32_t rbase = FB.base_cur[rng];
     const uint32_t in_rng = FB.job_cnt[rng * 32u];
     if (in_rng <= job0 - rbase) return;                               // whole wave beyond the range's job count
     AlnJob J;
-    J.act = job < n_jobs && job - rbase < in_rng;
-    uint32_t r = 0;
-    J.p0 = 0; J.n = 0; J.m = 0; J.mode = 0;
-    if (J.act) {
-        const uint32_t* meta = FB.job_meta + 4ull * job;
-        r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
-    }
+    uint32_t r;
+    load_job(FB, job, rng, job < n_jobs && job - rbase < in_rng, J, r);
     const RangeGeo G = FB.geo_cur[rng];
     const uint32_t rel0 = job0 - rbase;                              // the wave's first job within its range
-    J.jc0 = FB.job_cols + G.jc_off + (size_t)rel0 * G.cw; J.cw = (int)G.cw;
-    J.jc = J.jc0 + (size_t)lane * G.cw;
-    J.win.x = 0ull; J.win.y = 0ull;
-    if (J.act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
+    J.jc0 = FB.job_cols + G.jc_off + (size_t)rel0 * G.cw;
     J.wsh0 = reinterpret_cast<uint2*>(FB.walk_sh) + G.wsh_off + (size_t)rel0 * G.cw;
-    J.tstride = (size_t)G.tstride;                                  // 8-byte predecessor columns
-    J.trace = nullptr;                                               // full-width rows come from a small pool
     J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + G.trace_off + (size_t)rel0 * J.tstride;
-    // full-width pass: 16-byte columns in a row of the pool; a lane that gets no row reports a failure (the read
-    // then takes the wave-wide kernel)
-    auto full_row = [&](bool want) -> bool {
+    // a row of the full-width pool for every lane that wants one (wave-aggregated allocation)
+    auto pool_row = [&](bool want, uint32_t& slot) -> bool {
         const unsigned long long wm = __ballot(want);
         uint32_t base = 0;
         if (lane == 0 && wm) base = atomicAdd(&FB.counters[3], (uint32_t)__popcll(wm));
         base = __shfl(base, 0, 64);
-        const uint32_t slot = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
-        const bool ok = want && slot < FB.full_rows;
-        if (ok) J.trace = reinterpret_cast<unsigned long long*>(FB.trace_full) + (size_t)slot * (size_t)(P.ncap + 16) * 2;
-        return ok;
+        slot = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+        return want && slot < FB.full_rows;
     };
-    J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + G.popd_off + (size_t)(rel0 + (uint32_t)lane) * G.ncap);
     int mmax = J.m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
@@ -1688,25 +1716,29 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
 #endif
     AlnRes R;
     if (FULL_ONLY) {
-        const bool ok = full_row(J.act);
-        R = aln_full(J, ok, mmax, lane, tr_lds);
+        uint32_t slot;
+        const bool ok = pool_row(J.act, slot);
+        if (ok) J.trace = reinterpret_cast<unsigned long long*>(FB.trace_full) + (size_t)slot * (size_t)(P.ncap + 16) * 2;
+        R = aln_full(J, ok, mmax, lane, tr_lds, P.ablate == 23 ? FB.counters : nullptr);
         if (J.act && !ok) R.fail = true;
+        if (J.act) store_result(FB, r, R);
     } else {
         R = aln_fast(J, mmax, (int)((G.ncap + 7) & ~7u), lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
-        const unsigned long long nf = __ballot(R.needfull);
-        if (nf) {
-            if (lane == 0) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
-            const bool redo = full_row(J.act && R.needfull);
+        uint32_t slot;
+        const bool redo = pool_row(J.act && R.needfull, slot);
+        // the few lanes whose walk left the stored rows are redone at full width here, underneath the other waves of the
+        // launch (handing them to a packed follow-up launch was tried: its latency costs more per round than it saves)
+        if (__ballot(redo)) {
+            if (redo) J.trace = reinterpret_cast<unsigned long long*>(FB.trace_full) + (size_t)slot * (size_t)(P.ncap + 16) * 2;
             int mm2 = redo ? J.m : 0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
             const AlnRes R2 = aln_full(J, redo, mm2, lane, tr_lds);
-            if (redo) R = R2;                                         // without a row needfull stays set: reported as failure
+            if (redo) R = R2;                                         // without a row needfull stays set: reported as a failure
         }
-    }
-    if (J.act) {
-        ReadState* st = FB.state + r;
-        st->res_mt = R.mt; st->res_cols = R.cols; st->res_fail = (R.fail || R.needfull) ? 1u : 0u;
+        if (J.act) store_result(FB, r, R);
+        const unsigned long long nf = __ballot(R.needfull);
+        if (lane == 0 && nf) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
     }
 }
 
