@@ -203,6 +203,19 @@ def test_cli_end_to_end_matches_goldens_and_oracle(tmp_path, po, oracle_models):
     p2 = per2.read_bytes().split(b"\n")
     assert b2[1::4][: len(p2[1::2])] == p2[1::2]                       # same (badread) sequences in the "perfect" file
     assert all(b"read_identity=100.00%" in h for h in p2[0::2] if h)
+    # the streaming skeleton: one batch in flight gives the same bytes as several; a malformed line in a late batch
+    # ends the run with exit code 1 and a message, whatever the other workers are doing
+    one = tmp_path / "one.fastq"
+    r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", str(one),
+                        "-s", "7", "--batch-bytes", "4096", "--in-flight", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and one.read_bytes() == got
+    broken = tmp_path / "broken.mdf"
+    text = open(os.path.join(d, "mols.mdf")).read()
+    cut = text.rfind("\n+", 0, len(text) * 3 // 4)
+    broken.write_text(text[:cut + 1] + "chr1\tnot-a-number\t10\t+\t\n" + text[cut + 1:])
+    r = subprocess.run([exe, "sequence", "-i", str(broken), "-r", os.path.join(d, "ref.fa"), "-o", str(tmp_path / "x.fastq"),
+                        "--batch-bytes", "4096"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 1 and "MDF line" in r.stderr
 
 
 def test_full_size_properties_and_shard_invariance():
