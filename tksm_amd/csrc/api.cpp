@@ -727,6 +727,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         // ... and so does the kernel of every read that leaves the fast pipeline later (an alignment the band
         // representation cannot hold: about one read in two million): launched as soon as the host sees it
         uint32_t n_side = 0, side_launches = 0;
+        bool late_flushed = false;
         for (bool& u : ctx->side_used) u = false;
         auto launch_side = [&](uint32_t upto) -> int {
             if (upto <= n_side || side_launches + 2 >= 1024) return TKSMSEQ_OK;
@@ -794,10 +795,15 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), (const void*)FB.job_cnt, (size_t)FB.n_ranges * 128, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
-            { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
             cnt[0] = 0;
             for (uint32_t c = 0; c < FB.n_ranges; c++) { hprefix[c] = cnt[0]; cnt[0] += hcnt[(size_t)c * 32]; }
             hprefix[FB.n_ranges] = cnt[0];
+            // reads that left the fast pipeline in this round: a launch of the wave-wide kernel costs the latency of its
+            // slowest read (25-45 ms), so they are collected while the rounds are busy and flushed in batches
+            // (128 at a time, once more when the rounds become latency-bound; what comes after that waits for the end)
+            const bool late = cnt[0] * 16ull < n;
+            if (cnt[2] - n_side >= 128 || (cnt[2] > n_side && late && !late_flushed)) { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
+            late_flushed = late_flushed || late;
             if (cnt[0] == 0) break;
 #ifdef TKSM_ABLATE
             if (P.ablate >= 1 && P.ablate <= 9) break;          // k_err returned early: the reads would never finish

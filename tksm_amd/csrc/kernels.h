@@ -127,7 +127,7 @@ struct FastBuffers {
     unsigned long long* job_win;      // [n_reads][2] code planes of the first 64 window rows
     uint32_t* walk_sh;                // [n_groups][cw][64][2] shift words per block and lane, written by the forward pass
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
-    void* trace;                      // [n_jobs][ncap + 16] 8-byte predecessor columns (rows 16..47 of the band)
+    void* trace;                      // [n_jobs][ncap + 16] 8-byte predecessor columns (rows 12..43 of the band)
     void* trace_full;                 // [full_rows][ncap + 16] 16-byte columns: pool for full-width passes, counters[3] allocates
     uint32_t full_rows;
     uint32_t* counters;               // [16]: [2] reads on the slow list, [3] rows taken from the full-width pool, [4..] diagnostics
