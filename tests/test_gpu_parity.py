@@ -128,17 +128,19 @@ def _make_molecules(rs, ref, n, mean_len, literal=True):
     return mols
 
 
-@pytest.mark.parametrize("path", ["fast", "fast-small", "slow"])
+@pytest.mark.parametrize("path", ["fast", "fast-hbm", "fast-small", "slow"])
 @pytest.mark.parametrize("mean_len,n,compute_q", [(300, 96, True), (1000, 64, True), (1000, 32, False), (2600, 24, True), (9000, 6, True)])
 def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n, compute_q, path):
     """whole records of the stochastic path, GPU vs oracle, same (seed, read index).  mean_len 2600 exercises
     the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = k_err per length bucket +
     k_aln with 8-byte predecessor columns and full-width redo (what large batches run; reads touching N / IUPAC bytes
-    still take the wave-wide kernel), "fast-small" = the latency-bound variant small rounds switch to (one k_err launch,
+    still take the wave-wide kernel), "fast-hbm" = the same with k_err's long-read variant for every length, "fast-small" = the latency-bound variant small rounds switch to (one k_err launch,
     full-width k_aln), "slow" = wave-wide kernel for all."""
     monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
-    if path == "fast":
+    if path in ("fast", "fast-hbm"):
         monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_TAIL_CUT", "0")
+    if path == "fast-hbm":          # the long-read variant of k_err (fragment state edited in HBM) for every length
+        monkeypatch.setenv("TKSMSEQ_HBM_STATE_LEN", "0")
     s, ref, rs = _random_genome_seqr()
     s.set_identity(84.0, 99.0, 5.5)
     s.load_error_model(ERR_MODEL)

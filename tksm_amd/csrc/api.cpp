@@ -108,6 +108,7 @@ struct tksmseq_ctx : ContigLookup {
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
     uint32_t n_buckets = 16;
+    int hbm_state_len = 2304;   // fragments longer than this are edited in HBM instead of being staged in LDS every round
     std::vector<hipEvent_t> evpool;
     uint32_t last_rounds = 0, last_slow = 0;
     void* user_out = nullptr; uint64_t user_out_cap = 0;
@@ -149,6 +150,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_TAIL_CUT")) c->tail_cut = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ROUND")) c->small_round = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
+    if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* nbk = getenv("TKSMSEQ_BUCKETS")) c->n_buckets = (uint32_t)std::max(1, atoi(nbk));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -688,7 +690,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.sv_i = ctx->f_svi.as<uint16_t>(); FB.sv_kind = ctx->f_svk.as<uint8_t>(); FB.sv_alt = ctx->f_sva.as<unsigned long long>();
         std::vector<uint32_t> hcnt((size_t)FB.n_ranges * 32);
         // length buckets over the sorted read order: each bucket gets its own LDS geometry
-        struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; };
+        struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; bool hbm; };
         std::vector<Bucket> buckets;
         {
             const uint32_t minr = b->raw_len[b->order.front()], maxr = b->raw_len[b->order.back()];
@@ -702,8 +704,9 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 Bucket bk;
                 bk.begin = (uint32_t)i0; bk.count = (uint32_t)(i1 - i0);
                 bk.lcap = (int)((mx + 2 * k + 7) & ~7u); bk.ncap = (int)capf(mx);
+                bk.hbm = bk.lcap > ctx->hbm_state_len;            // long reads: fragment state edited in HBM (kernels.hip, k_err)
                 bk.wpw = tk::WAVES_PER_WG;
-                while (bk.wpw > 1 && tk::err_lds_bytes(bk.lcap, bk.ncap, bk.wpw) > 64 * 1024) bk.wpw >>= 1;
+                while (bk.wpw > 1 && tk::err_lds_bytes(bk.lcap, bk.ncap, bk.wpw, bk.hbm) > 64 * 1024) bk.wpw >>= 1;
                 buckets.push_back(bk);
                 i0 = i1;
             }
@@ -762,7 +765,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             kinds.push_back(-1);
             if (rounds == 0) {
                 for (const Bucket& bk : buckets)
-                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, 0, 0, 0, bk.wpw, s));
+                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, 0, 0, 0, bk.wpw, bk.hbm, s));
             } else {
                 // one wave per job of the previous round; ranges are chunks of the sorted order, so a bucket is a run of ranges
                 const uint32_t total = hprefix[FB.n_ranges];
@@ -770,7 +773,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     // few reads left: the round is bound by launch and single-wave latency, not by occupancy -- one
                     // launch with the geometry of the longest bucket instead of one per bucket
                     const Bucket& bk = buckets.back();
-                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, total, bk.lcap, bk.ncap, 1, 0, FB.n_ranges, bk.wpw, s));
+                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, total, bk.lcap, bk.ncap, 1, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
                 } else {
                 size_t bi = 0;
                 uint32_t c = 0;
@@ -785,7 +788,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     }
                     const uint32_t cntw = hprefix[c1] - hprefix[c];
                     if (cntw)
-                        HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, buckets[bi].ncap, 1, c, c1, buckets[bi].wpw, s));
+                        HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, buckets[bi].ncap, 1, c, c1, buckets[bi].wpw, buckets[bi].hbm, s));
                     c = c1;
                 }
                 }

@@ -157,10 +157,10 @@ hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelV
                            int waves_per_wg, hipStream_t s);
 hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView& em, const IdentView& im, const SimParams& p,
                        const SimBuffers& o, const FastBuffers& fb, int waves_per_wg, hipStream_t s);
-int err_lds_bytes(int lcap, int ncap, int waves_per_wg);
+int err_lds_bytes(int lcap, int ncap, int waves_per_wg, bool state_in_hbm);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
-                      int from_jobs, uint32_t c0, uint32_t c1, int waves_per_wg, hipStream_t s);
+                      int from_jobs, uint32_t c0, uint32_t c1, int waves_per_wg, bool state_in_hbm, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, hipStream_t s);
 hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s);

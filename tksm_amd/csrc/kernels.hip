@@ -940,7 +940,11 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
     return idx | (__ballot(fail) ? 0x80000000u : 0u);
 }
 
-// ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | N[ncap] | aux[2*ncap] (owner u16 / popd)
+// ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (job staging / alignment ops).
+// STATE_IN_HBM (long reads): the fragment and its slot codes stay in HBM and are edited in place -- a round touches ~130
+// candidate positions and a 1000-slot window, so staging the whole fragment costs more than it saves, and its LDS
+// footprint would leave a handful of waves per CU; only the aux area is in LDS.
+template <bool STATE_IN_HBM>
 __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
                                               FastBuffers FB, const uint32_t* __restrict__ order, uint32_t begin, uint32_t count,
                                               int lds_lcap, int lds_ncap, int from_jobs, uint32_t c0, uint32_t c1) {
@@ -964,11 +968,12 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     }
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
-    // LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (job staging / per-position alignment ops)
-    const int per_wave = lds_lcap * 3 + lds_ncap + 128;
-    uint8_t* frag = lds_raw + (size_t)wave * per_wave;
-    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + lds_lcap);
-    uint8_t* aux = frag + 3 * (size_t)lds_lcap;
+    uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
+    const int per_wave = STATE_IN_HBM ? lds_ncap + 128 : lds_lcap * 3 + lds_ncap + 128;
+    uint8_t* lds_wave = lds_raw + (size_t)wave * per_wave;
+    uint8_t* frag = STATE_IN_HBM ? FB.st_frag + r * (size_t)P.lcap : lds_wave;
+    uint16_t* nb = STATE_IN_HBM ? gnb : reinterpret_cast<uint16_t*>(lds_wave + lds_lcap);
+    uint8_t* aux = STATE_IN_HBM ? lds_wave : lds_wave + 3 * (size_t)lds_lcap;
     uint8_t* popd = aux;
     const int k = EM.k;
     const uint64_t g = P.first_read + r * P.stride;
@@ -978,13 +983,12 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const int cap = __builtin_amdgcn_readfirstlane((int)((O.slot_off[r + 1] - slot) >> 1));
     uint8_t* out_seq = O.scratch + slot;
     uint8_t* out_qual = out_seq + cap;
-    uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
     // the draws of the round that was interrupted by the re-estimation come back with the state (no regeneration)
     int sv_i = 0, sv_kind = 0; uint64_t sv_alt = 0;
     if (S.stage == 0 && S.resume_src >= 0) {
         sv_i = FB.sv_i[r * 64 + lane]; sv_kind = FB.sv_kind[r * 64 + lane]; sv_alt = FB.sv_alt[r * 64 + lane];
     }
-    {
+    if (!STATE_IN_HBM) {
         const uint8_t* gfrag0 = FB.st_frag + r * (size_t)P.lcap;
         for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag0 + t);
         for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
@@ -1213,7 +1217,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             if (P.ablate == 5) return;
 #endif
             if (job >> 31) { go_slow(FB, r, lane, 1); return; }
-            for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
+            if (!STATE_IN_HBM)
+                for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
             if (lane == 0) {
                 S.errors = errors; S.est = r_est; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
                 S.resume_src = (int16_t)r_src; S.resume_j = (int16_t)r_j; S.pending = 1; S.stage = 0;
@@ -1223,7 +1228,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             return;
         }
         // the loop has ended: write the final slots back once (the FINAL stage re-joins from them)
-        for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
+        if (!STATE_IN_HBM)
+            for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
     } else {
         st_draws = S.st_draws;
     }
@@ -2010,15 +2016,16 @@ hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView&
     hipLaunchKernelGGL(k_init, dim3((unsigned)((b.n_reads + wpw - 1) / wpw)), dim3(64 * wpw), lds, s, b, r, em, im, p, o, fb);
     return hipGetLastError();
 }
-int err_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap + 128); }
+int err_lds_bytes(int lcap, int ncap, int wpw, bool state_in_hbm) { return wpw * ((state_in_hbm ? 0 : lcap * 3) + ncap + 128); }
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
-                      int from_jobs, uint32_t c0, uint32_t c1, int wpw, hipStream_t s) {
+                      int from_jobs, uint32_t c0, uint32_t c1, int wpw, bool state_in_hbm, hipStream_t s) {
     if (!count) return hipSuccess;
-    const int lds = err_lds_bytes(lds_lcap, lds_ncap, wpw);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_err), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int lds = err_lds_bytes(lds_lcap, lds_ncap, wpw, state_in_hbm);
+    auto kern = state_in_hbm ? k_err<true> : k_err<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_err, dim3((count + wpw - 1) / wpw), dim3(64 * wpw), lds, s, b, em, qm, p, o, fb, order, begin, count, lds_lcap,
+    hipLaunchKernelGGL(kern, dim3((count + wpw - 1) / wpw), dim3(64 * wpw), lds, s, b, em, qm, p, o, fb, order, begin, count, lds_lcap,
                        lds_ncap, from_jobs, c0, c1);
     return hipGetLastError();
 }
