@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU sample (0 = sized for ~20 s)")
     ap.add_argument("--skip-qual", action="store_true")
     ap.add_argument("--perfect", action="store_true", help="bench the integer splice path only (--perfect)")
+    ap.add_argument("--lognormal-sigma", type=float, default=0.0, help="transcript-like skewed lengths: lognormal, median --mean-len")
     ap.add_argument("--pipeline", type=int, default=3, help="contexts in flight per GPU (1 = one batch at a time)")
     args = ap.parse_args()
 
@@ -140,7 +141,7 @@ def main():
     models = os.path.join(ROOT, "tksm_amd", "models", "badread")
     target = "perfect" if args.perfect else "badread"
     compute_q = not args.skip_qual
-    cap = int(args.batch * (2.3 * (args.mean_len + 60) + 256))
+    cap = int(args.batch * (2.3 * (args.mean_len * (1.25 if args.lognormal_sigma else 1.0) + 60) + 256))
 
     class Ctx:
         pass
@@ -173,7 +174,7 @@ def main():
     for i, c in enumerate(ctxs):
         rs = np.random.RandomState(2 + rank + 1000 * i)
         c.m = synthetic.make_molecules(rs, [clen] * args.genome_contigs, args.batch, args.mean_len, args.mean_len * 0.2, kind=args.kind,
-                                       id_prefix=f"m{rank}")
+                                       id_prefix=f"m{rank}", lognormal_sigma=args.lognormal_sigma or None)
         c.batch = c.seqr.batch_from_arrays(c.m["reads"], c.m["intervals"], c.m["mods"], c.m["literals"], c.m["literal_pool"],
                                            c.m["ids"], c.m["id_pool"])
         c.out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -323,6 +324,7 @@ def main():
                                f"{args.genome_contigs} x {args.contig_mb} Mb random genome, FASTQ"
                                if not args.perfect else "Bulk molecules, --perfect splice path, FASTQ",
                    "kind": args.kind, "molecules_per_gpu_per_step": args.batch, "mean_len": args.mean_len,
+                   "length_distribution": f"lognormal(median {args.mean_len}, sigma {args.lognormal_sigma})" if args.lognormal_sigma else f"normal({args.mean_len}, {args.mean_len * 0.2:.0f})",
                    "compute_qual": bool(compute_q and not args.perfect), "sharding": f"round-robin x{world}",
                    "ordering_gather": exchange_on, "contexts_in_flight_per_gpu": n_ctx},
         "gbases_per_s": bases_in_all / elapsed / 1e9,

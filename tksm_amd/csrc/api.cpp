@@ -103,11 +103,12 @@ struct tksmseq_ctx : ContigLookup {
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
         w_scratch, w_records, w_istats, w_dstats, w_sums;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_jobcnt[2], f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_svi, f_svk, f_sva;
     bool force_slow = false;
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
     uint32_t n_buckets = 16;
+    int defer_len = 2304;       // reads longer than this align for their q-scores after the regular rounds, all together
     int hbm_state_len = 2304;   // fragments longer than this are edited in HBM instead of being staged in LDS every round
     std::vector<hipEvent_t> evpool;
     uint32_t last_rounds = 0, last_slow = 0;
@@ -151,6 +152,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_SMALL_ROUND")) c->small_round = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
+    if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
     if (const char* nbk = getenv("TKSMSEQ_BUCKETS")) c->n_buckets = (uint32_t)std::max(1, atoi(nbk));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -650,6 +652,10 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
         FB.trace = ctx->f_trace.p; FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
+        HIPCHK(ctx, ctx->f_defer.ensure(n * 8 + 64));
+        HIPCHK(ctx, ctx->f_defercnt.ensure((size_t)FB.n_ranges * 128 + 64));
+        FB.defer_list = ctx->f_defer.as<uint2>(); FB.defer_cnt = ctx->f_defercnt.as<uint32_t>(); FB.defer_len = ctx->defer_len;
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_defercnt.p, 0, (size_t)FB.n_ranges * 128, s));
         FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
         FB.walk_sh = ctx->f_wsh.as<uint32_t>();
         FB.geo_cur = ctx->f_geo.as<tk::RangeGeo>(); FB.geo_prev = FB.geo_cur + FB.n_ranges;
@@ -757,7 +763,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
         { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
-        uint32_t rounds = 0;
+        uint32_t rounds = 0, n_deferred = 0;
+        bool revive = false, revived = false;
         for (;; rounds++) {
             select_set(rounds);
             HIPCHK(ctx, hipMemsetAsync((void*)FB.job_cnt, 0, (size_t)FB.n_ranges * 128, s));
@@ -766,6 +773,11 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (rounds == 0) {
                 for (const Bucket& bk : buckets)
                     HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, 0, 0, 0, bk.wpw, bk.hbm, s));
+            } else if (revive) {
+                // the deferred long reads build their q-score jobs now, all in this one round
+                const Bucket& bk = buckets.back();
+                HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, n_deferred, bk.lcap, bk.ncap, 2, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
+                revive = false;
             } else {
                 // one wave per job of the previous round; ranges are chunks of the sorted order, so a bucket is a run of ranges
                 const uint32_t total = hprefix[FB.n_ranges];
@@ -807,7 +819,19 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             const bool late = cnt[0] * 16ull < n;
             if (cnt[2] - n_side >= 128 || (cnt[2] > n_side && late && !late_flushed)) { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
             late_flushed = late_flushed || late;
-            if (cnt[0] == 0) break;
+            if (cnt[0] == 0) {
+                if (cnt[1] == 0 || revived) break;
+                // every other read is done: job slots for the deferred reads (per-range counts), then their rounds
+                revived = revive = true; n_deferred = cnt[1];
+                std::vector<uint32_t> hd((size_t)FB.n_ranges * 32);
+                HIPCHK(ctx, hipMemcpy(hd.data(), ctx->f_defercnt.p, hd.size() * 4, hipMemcpyDeviceToHost));
+                uint32_t acc = 0;
+                for (uint32_t c = 0; c < FB.n_ranges; c++) { hbase_prev[c] = hbase_cur[c]; hbase_cur[c] = acc; acc += (hd[(size_t)c * 32] + 63) & ~63u; hprefix[c] = 0; }
+                hbase_prev[FB.n_ranges] = hbase_cur[FB.n_ranges]; hbase_cur[FB.n_ranges] = acc; hprefix[FB.n_ranges] = 0;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
+                HIPCHK(ctx, place_ranges());
+                continue;
+            }
 #ifdef TKSM_ABLATE
             if (P.ablate >= 1 && P.ablate <= 9) break;          // k_err returned early: the reads would never finish
 #endif

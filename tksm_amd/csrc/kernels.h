@@ -92,7 +92,7 @@ struct ReadState {
     int32_t change_count;
     uint32_t n_base, aln_no;
     int16_t resume_src, resume_j;   // draw (lane of its round) and slot to resume at; src < 0: none in progress
-    uint8_t stage;                  // 0 error loop, 1 waiting for the q-score alignment, 2 done
+    uint8_t stage;                  // 0 error loop, 1 waiting for the q-score alignment, 2 done, 3 error loop done, q-score alignment deferred
     uint8_t pending, slow, pad;
     int32_t st_draws, st_aligns;
     uint32_t job;
@@ -143,6 +143,10 @@ struct FastBuffers {
     const RangeGeo* geo_cur; const RangeGeo* geo_prev;   // [n_ranges]
     uint16_t* sv_i; uint8_t* sv_kind; unsigned long long* sv_alt;   // [n_reads][64] draws of an interrupted round
     uint32_t* slow_list;              // [n_reads]
+    // reads longer than defer_len wait (stage 3) with their q-score alignment until the regular rounds are over
+    uint2* defer_list;                // [n_reads] {read, range}; counters[1] counts
+    uint32_t* defer_cnt;              // [n_ranges] per range, one counter per 128 B
+    int defer_len;
     int fw;
 };
 

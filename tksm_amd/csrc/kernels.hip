@@ -956,7 +956,12 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (widx >= count) return;
     uint64_t r; uint32_t pos;
     if (!from_jobs) { pos = begin + widx; r = (uint64_t)__builtin_amdgcn_readfirstlane((int)order[pos]) & 0xffffffffull; }   // round 0: every read, in sorted order
-    else {
+    else if (from_jobs == 2) {
+        // the reads whose q-score alignment was deferred (below), all at once after the last regular round
+        const uint2 e = FB.defer_list[widx];
+        r = (uint64_t)__builtin_amdgcn_readfirstlane((int)e.x) & 0xffffffffull;
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y) * FB.rs;
+    } else {
         // later rounds: one wave per job of the previous round (= per read still running); a dispatched wave costs
         // ~1-2 ns even if it returns at once, and most reads are finished long before the last round
         const uint32_t target = FB.prefix[c0] + widx;
@@ -1248,7 +1253,20 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (m > jcap) { status |= 1; lo = hi = 0; }
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
-    if (S.stage == 0 && want_q) {
+    if (S.stage == 0 && want_q && L > FB.defer_len) {
+        // A q-score alignment spans the whole read: on one lane, thousands of columns -- it would set the duration of
+        // this round's k_aln for everybody.  Long reads wait here (stage 3) and align together after the last round.
+        if (lane == 0) {
+            S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
+            S.resume_src = -1; S.pending = 0; S.stage = 3; S.st_draws = st_draws; S.st_aligns = st_aligns;
+            FB.state[r] = S;
+            const uint32_t rc3 = pos / FB.rs;
+            atomicAdd(&FB.defer_cnt[rc3 * 32u], 1u);
+            FB.defer_list[atomicAdd(&FB.counters[1], 1u)] = make_uint2((uint32_t)r, rc3);
+        }
+        return;
+    }
+    if ((S.stage == 0 || S.stage == 3) && want_q) {
         int m1 = m;
         const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m1, lds_ncap, aux, nullptr, 0, 0, lane);
         if (job >> 31) { go_slow(FB, r, lane, 2); return; }
