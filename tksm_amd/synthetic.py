@@ -14,10 +14,10 @@ import numpy as np
 
 def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", id_prefix="mol", lognormal_sigma=None):
     """Returns dict(reads, intervals, mods, literals, literal_pool, ids, id_pool, raw_len) as numpy arrays.
-    lognormal_sigma: transcript-like skewed lengths, median mean_len, clipped to [200, 20000] (instead of the normal)."""
+    lognormal_sigma: transcript-like skewed lengths, median mean_len, clipped to [200, 16000] (instead of the normal)."""
     contig_lens = np.asarray(contig_lens, np.int64)
     if lognormal_sigma:
-        length = np.clip(np.rint(mean_len * np.exp(rs.normal(0.0, lognormal_sigma, n))), 200, 20000).astype(np.int64)
+        length = np.clip(np.rint(mean_len * np.exp(rs.normal(0.0, lognormal_sigma, n))), 200, 16000).astype(np.int64)
     else:
         length = np.maximum(200, np.rint(rs.normal(mean_len, sd_len, n))).astype(np.int64)
     S = rs.randint(1, 5, n)
