@@ -336,10 +336,14 @@ def test_edge_cases_empty_short_constant_identity_and_limits(po, oracle_models):
         with pytest.raises(TksmSeqError):
             s.run(s.batch_from_mdf(bad), target="perfect")
     # documented limit: a molecule beyond the LDS-resident working set
-    s.add_contig("big", rs.choice(np.frombuffer(b"ACGT", np.uint8), 80_000).tobytes())
+    s_big = rs.choice(np.frombuffer(b"ACGT", np.uint8), 80_000).tobytes().decode()
+    s.add_contig("big", s_big.encode())
     with pytest.raises(TksmSeqError) as e:
         s.run(s.batch_from_mdf("+huge\t1\t\nbig\t0\t70000\t+\t\n"), target="badread")
     assert e.value.code == 6
+    # ... which the --perfect path does not have
+    big = s.run(s.batch_from_mdf("+huge\t1\t\nbig\t5\t70005\t-\t17C\n"), target="perfect", seed=3).records()[0]
+    assert big == po.perfect_record(True, 3, 0, po.splice({"big": s_big}, [("big", 5, 70005, "-", "17C")]), "huge")
     s.close()
 
 

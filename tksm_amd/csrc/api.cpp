@@ -544,7 +544,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     int wpw = tk::WAVES_PER_WG;
     while (wpw > 1 && tk::simulate_lds_bytes(lcap, ncap, wpw) > 160 * 1024) wpw >>= 1;
     const int lds = tk::simulate_lds_bytes(lcap, ncap, wpw);
-    if (lds > 160 * 1024 || ncap >= 65000 || lcap >= 65000) {
+    const bool direct = !badread && !ctx->force_slow && !p->collect_stats;   // --perfect: packed reference -> records, no working set
+    if (!direct && (lds > 160 * 1024 || ncap >= 65000 || lcap >= 65000)) {
         ctx->err = "molecule of " + std::to_string(b->max_raw) + " bases exceeds the LDS-resident limit of this build";
         return TKSMSEQ_ELIMIT;
     }
@@ -607,7 +608,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     HIPCHK(ctx, tk::launch_scan(ctx->w_slotcap.as<uint64_t>(), ctx->w_slotoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     const bool fast = badread && !ctx->force_slow && n > 0;
-    const bool direct = !badread && !ctx->force_slow && !p->collect_stats;   // --perfect: packed reference -> records, no working set
     if (direct) {
         HIPCHK(ctx, tk::launch_perfect_lengths(B, R, P, O, s));
     } else if (!fast) {
