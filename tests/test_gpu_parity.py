@@ -341,6 +341,15 @@ def test_edge_cases_empty_short_constant_identity_and_limits(po, oracle_models):
     with pytest.raises(TksmSeqError) as e:
         s.run(s.batch_from_mdf("+huge\t1\t\nbig\t0\t70000\t+\t\n"), target="badread")
     assert e.value.code == 6
+    # between the two limits (18 k: the exact wave-wide kernel, 43 k: the fast pipeline) a plain ACGT molecule runs,
+    # bit-exact with the oracle; one that needs the wave-wide kernel (an N) is refused, by name
+    em, qm = oracle_models["em"], oracle_models["qm"]
+    long_ivs = [("big", 100, 30100, "+", "")]
+    got = s.run(s.batch_from_mdf("+long\t1\t\nbig\t100\t30100\t+\t\n"), target="badread", seed=SEED).records()[0]
+    assert got == po.badread_record(True, SEED, 0, po.splice({"big": s_big}, long_ivs), ident, em, qm, True, "long")[0]
+    with pytest.raises(TksmSeqError) as e:
+        s.run(s.batch_from_mdf("+long\t1\t\nbig\t100\t30100\t+\t200N\n"), target="badread", seed=SEED)
+    assert e.value.code == 6 and "wave-wide kernel" in str(e.value)
     # ... which the --perfect path does not have
     big = s.run(s.batch_from_mdf("+huge\t1\t\nbig\t5\t70005\t-\t17C\n"), target="perfect", seed=3).records()[0]
     assert big == po.perfect_record(True, 3, 0, po.splice({"big": s_big}, [("big", 5, 70005, "-", "17C")]), "huge")

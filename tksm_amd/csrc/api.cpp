@@ -541,10 +541,18 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     // LDS geometry from the longest molecule of the batch
     const int lcap = (int)((b->max_raw + 2 * k + 7) & ~7u);   // multiple of 8: 64-bit LDS words follow 3 * lcap bytes
     const int ncap = badread ? (int)capf(b->max_raw) : 4;
-    int wpw = tk::WAVES_PER_WG;
-    while (wpw > 1 && tk::simulate_lds_bytes(lcap, ncap, wpw) > 160 * 1024) wpw >>= 1;
-    const int lds = tk::simulate_lds_bytes(lcap, ncap, wpw);
     const bool direct = !badread && !ctx->force_slow && !p->collect_stats;   // --perfect: packed reference -> records, no working set
+    // the wave-wide kernel keeps a read's whole working set in LDS: 3 L + 4 x capacity bytes.  Longer molecules can
+    // still take the fast pipeline (fragment state in HBM); only if one of them needs the wave-wide kernel (non-ACGT
+    // bytes, an alignment outside the band representation) the run fails with TKSMSEQ_ELIMIT.
+    int s_lcap = lcap, s_ncap = ncap;
+    if (badread && !ctx->force_slow && tk::simulate_lds_bytes(s_lcap, s_ncap, 1) > 160 * 1024) {
+        while (s_lcap > 64 && tk::simulate_lds_bytes(s_lcap, (int)capf((uint64_t)(s_lcap - 2 * k)), 1) > 160 * 1024) s_lcap -= 64;
+        s_ncap = (int)capf((uint64_t)(s_lcap - 2 * k));
+    }
+    int wpw = tk::WAVES_PER_WG;
+    while (wpw > 1 && tk::simulate_lds_bytes(s_lcap, s_ncap, wpw) > 160 * 1024) wpw >>= 1;
+    const int lds = tk::simulate_lds_bytes(s_lcap, s_ncap, wpw);
     if (!direct && (lds > 160 * 1024 || ncap >= 65000 || lcap >= 65000)) {
         ctx->err = "molecule of " + std::to_string(b->max_raw) + " bases exceeds the LDS-resident limit of this build";
         return TKSMSEQ_ELIMIT;
@@ -552,7 +560,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     int wgs_per_cu = std::min(std::min(32 / wpw, 16), std::max(1, (160 * 1024) / std::max(lds, 1)));
     const uint64_t want = (n + wpw - 1) / wpw;
     const int n_wgs = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->n_cus * wgs_per_cu));
-    const int trace_words = (ncap + 2) * 4;   // {up mask, left mask} u64 per column of the final alignment
+    const int trace_words = (s_ncap + 2) * 4;   // {up mask, left mask} u64 per column of the final alignment
 
     HIPCHK(ctx, ctx->w_rawlen.ensure(n * 4 + 16));
     HIPCHK(ctx, ctx->w_slotcap.ensure(n * 8 + 16));
@@ -589,7 +597,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     P.quirk_perfect = (badread && p->perfect_of_badread) ? 1 : 0;
     P.compute_q = (badread && p->compute_qual && p->fastq && !P.quirk_perfect) ? 1 : 0;
     P.ablate = getenv("TKSMSEQ_ABLATE") ? atoi(getenv("TKSMSEQ_ABLATE")) : 0;
-    P.lcap = lcap; P.ncap = ncap; P.trace_words = trace_words; P.cap_num = cap_num; P.cap_den = cap_den; P.cap_add = cap_add;
+    P.lcap = lcap; P.ncap = ncap; P.s_lcap = s_lcap; P.s_ncap = s_ncap; P.trace_words = trace_words; P.cap_num = cap_num; P.cap_den = cap_den; P.cap_add = cap_add;
     tk::SimBuffers O{};
     O.raw_len = ctx->w_rawlen.as<uint32_t>(); O.slot_off = ctx->w_slotoff.as<uint64_t>(); O.scratch = ctx->w_scratch.as<uint8_t>();
     O.out_len = ctx->w_outlen.as<uint32_t>(); O.identity = ctx->w_ident.as<double>(); O.rec_len = ctx->w_reclen.as<uint64_t>();
@@ -644,7 +652,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_geo.ensure((size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo) + 64));
         HIPCHK(ctx, ctx->f_wsh.ensure(tot_jc * 8 + 64));
         HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 8 + 64));
-        FB.full_rows = (uint32_t)std::min<uint64_t>(jcap, 16384);
+        FB.full_rows = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(jcap, 16384), (6ull << 30) / ((uint64_t)(ncap + 16) * 16));   // pool of at most 6 GB
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(256));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
@@ -727,7 +735,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, n * (size_t)lcap * 2, s));
         HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 256, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
-        HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, tk::WAVES_PER_WG, s));
+        HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, lcap * tk::WAVES_PER_WG <= 150 * 1024 ? tk::WAVES_PER_WG : (lcap * 2 <= 150 * 1024 ? 2 : 1), s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         kinds.push_back(0);
         uint32_t cnt[4] = {0, 0, 0, 0};
@@ -917,6 +925,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         for (uint64_t i = 0; i < n; i++) if (st[i]) { if (!any) first = i; any |= st[i]; }
         if (any & 2) { ctx->err = "modification position outside its interval at read " + std::to_string(first); return TKSMSEQ_EINVAL; }
         if (any & 4) { ctx->err = "internal: alignment band failure at read " + std::to_string(first); return TKSMSEQ_EDEVICE; }
+        if (any & 8) {
+            uint64_t f8 = 0;
+            for (uint64_t i = 0; i < n; i++) if (st[i] & 8) { f8 = i; break; }
+            ctx->err = "read " + std::to_string(f8) + " (" + std::to_string(b->raw_len[f8]) + " bases) needs the exact wave-wide kernel (non-ACGT bytes or an alignment outside "
+                       "the band representation), which is limited to molecules of " + std::to_string(s_lcap - 2 * k) + " bases";
+            return TKSMSEQ_ELIMIT;
+        }
         if (any & 1) { *overflow = true; return TKSMSEQ_OK; }
     }
     uint8_t* records;

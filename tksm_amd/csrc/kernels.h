@@ -66,6 +66,7 @@ struct SimParams {
     int lcap;          // LDS capacity for the padded fragment (bytes, multiple of 4)
     int ncap;          // LDS capacity for the joined new sequence (bytes, multiple of 4)
     int trace_words;   // u32 words per wave in the traceback scratch
+    int s_lcap, s_ncap; // LDS geometry of the wave-wide kernel (k_simulate); reads beyond it get status 8
     int ablate;        // diagnostic builds only
     int cap_num, cap_den, cap_add;   // per-read scratch capacity = (raw+2k)*num/den + add, 16-aligned
 };

@@ -321,13 +321,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                                                                  QsModelView QM, IdentView IM, SimParams P,
                                                                  SimBuffers O) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per_wave = P.lcap * 3 + P.ncap * 4;
+    const int per_wave = P.s_lcap * 3 + P.s_ncap * 4;
     const int wpw = blockDim.x >> 6;
     uint8_t* frag = lds_raw + (size_t)wave * per_wave;
-    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + P.lcap);
-    uint8_t* N = frag + 3 * (size_t)P.lcap;
-    uint8_t* popd = N + P.ncap;
-    uint16_t* owner = reinterpret_cast<uint16_t*>(popd + P.ncap);
+    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + P.s_lcap);
+    uint8_t* N = frag + 3 * (size_t)P.s_lcap;
+    uint8_t* popd = N + P.s_ncap;
+    uint16_t* owner = reinterpret_cast<uint16_t*>(popd + P.s_ncap);
     unsigned long long* trace = reinterpret_cast<unsigned long long*>(O.trace) + ((size_t)blockIdx.x * wpw + wave) * (size_t)(P.trace_words / 2);
     const int k = EM.k;
 
@@ -345,6 +345,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
         uint8_t* out_seq = O.scratch + slot;
         uint8_t* out_qual = out_seq + cap;
         uint32_t status = 0;
+        if (L > P.s_lcap) {
+            // longer than this kernel's LDS-resident working set allows (the fast pipeline takes such reads as long as
+            // they are plain ACGT): reported to the host
+            if (lane == 0) { O.status[r] |= 8u; O.out_len[r] = 0; O.rec_len[r] = 0; O.identity[r] = 0.0; }
+            continue;
+        }
 
         // ---- S1 splice (py/sequence.py:303-313) into frag[k .. k+raw_len)
         {
@@ -487,9 +493,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                                 p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
                                 nrows = 1000;
                             }
-                            const int m = join_window(frag, nb, p0, nrows, N, owner, P.ncap, lane);
+                            const int m = join_window(frag, nb, p0, nrows, N, owner, P.s_ncap, lane);
                             wave_sync();
-                            if (m > P.ncap) status |= 1;
+                            if (m > P.s_ncap) status |= 1;
                             else {
                                 const AlnOut a = band_align<0, false>(frag + p0, nrows, N, owner, m, lane, nullptr);
                                 if (is_inf(a.dist)) status |= 4;
@@ -525,12 +531,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                 start_trim = __shfl(scan_add_incl(v1, lane), 63, 64);
                 end_trim = __shfl(scan_add_incl(v2, lane), 63, 64);
             }
-            const int m = join_window(frag, nb, 0, L, N, owner, min(P.ncap, cap), lane);
+            const int m = join_window(frag, nb, 0, L, N, owner, min(P.s_ncap, cap), lane);
             wave_sync();
             st_newlen = m; st_strim = start_trim; st_etrim = end_trim;
             int lo = start_trim, hi = end_trim == 0 ? 0 : m - end_trim;   // seq[start_trim:-end_trim]
             lo = min(lo, m); hi = max(hi, lo);
-            if (m > min(P.ncap, cap)) { status |= 1; lo = hi = 0; }
+            if (m > min(P.s_ncap, cap)) { status |= 1; lo = hi = 0; }
             out_len = hi - lo;
             if (P.compute_q && m > 0 && !(status & 1)) {
                 // ---- S5 q-scores (py/tksm_badread.py:607-655): align read vs fragment with path
@@ -2019,7 +2025,7 @@ int simulate_max_wgs(int lds_bytes) {
 hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
                            const IdentView& im, const SimParams& p, const SimBuffers& o, int n_wgs, int wpw, hipStream_t s) {
     if (!b.n_reads) return hipSuccess;
-    const int lds = simulate_lds_bytes(p.lcap, p.ncap, wpw);
+    const int lds = simulate_lds_bytes(p.s_lcap, p.s_ncap, wpw);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_simulate), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_simulate, dim3(n_wgs), dim3(64 * wpw), lds, s, b, r, em, qm, im, p, o);
