@@ -451,3 +451,31 @@ def test_perfect_direct_kernel_equals_wave_wide_kernel(monkeypatch, kind):
     for fastq in (True, False):
         assert out["direct", fastq][0] == out["wave", fastq][0]
         assert (out["direct", fastq][1] == out["wave", fastq][1]).all()
+
+
+@pytest.mark.parametrize("path", ["fast", "slow"])
+def test_band_failure_falls_back_to_the_unbanded_alignment(oracle_models, po, monkeypatch, path):
+    """three reads of a 262 144-read scRNA-like run (polyA ~ N(40, 20); tools/dump_unbanded_reads.py) in which the
+    nanopore2020 model deletes so much of the polyA tail that the last window of the guided band misses the end cell.
+    The specification (oracle: full_align) prescribes the unbanded alignment for such a window; the GPU path gives the
+    oracle's records, band failures included.  Replayed as literal molecules at their original read indices."""
+    import json
+    monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
+    from tksm_amd.sequence import Sequencer
+    s = Sequencer(0)
+    s.add_contig("chr1", b"ACGT" * 64)
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    em, qm = oracle_models["em"], oracle_models["qm"]
+    for x in json.load(open(os.path.join(GOLDEN, "unbanded_reads.json"))):
+        seq = x["sequence"]
+        text = f"+mol_{x['index']}\t1\t\n{seq}\t0\t{len(seq)}\t+\t\n"
+        res = s.run(s.batch_from_mdf(text), target="badread", fastq=True, compute_qual=True, seed=42, first_read_index=x["index"],
+                    collect_stats=True)
+        want, st = po.badread_record(True, 42, x["index"], seq.encode(), ident, em, qm, True, f"mol_{x['index']}")
+        assert st.band_fail > 0
+        assert res.records()[0] == want
+        assert res.stats()[0][0, 7] & 16                    # the run reports that it took the unbanded path
+    s.close()

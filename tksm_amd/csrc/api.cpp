@@ -101,7 +101,8 @@ struct tksmseq_ctx : ContigLookup {
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
-        w_scratch, w_records, w_istats, w_dstats, w_sums;
+        w_scratch, w_records, w_istats, w_dstats, w_sums, w_fullpool;
+    unsigned long long full_pool_bytes = 1ull << 30;
     // fast Badread pipeline state (see kernels.h FastBuffers)
     DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_svi, f_svk, f_sva;
     bool force_slow = false;
@@ -153,6 +154,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
+    if (const char* fp = getenv("TKSMSEQ_FULL_POOL_MB")) c->full_pool_bytes = (unsigned long long)atoll(fp) << 20;
     if (const char* nbk = getenv("TKSMSEQ_BUCKETS")) c->n_buckets = (uint32_t)std::max(1, atoi(nbk));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -603,6 +605,12 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     O.out_len = ctx->w_outlen.as<uint32_t>(); O.identity = ctx->w_ident.as<double>(); O.rec_len = ctx->w_reclen.as<uint64_t>();
     O.status = ctx->w_status.as<uint32_t>(); O.trace = ctx->w_trace.as<uint32_t>();
     O.work_counter = ctx->w_counter.as<unsigned long long>();
+    if (badread) {
+        // memory for the unbanded alignments of the wave-wide kernel (rare: kernels.hip, full_align_wave)
+        HIPCHK(ctx, ctx->w_fullpool.ensure(ctx->full_pool_bytes));
+        O.full_pool = ctx->w_fullpool.as<uint8_t>(); O.full_pool_bytes = ctx->full_pool_bytes;
+        O.full_pool_used = ctx->w_counter.as<unsigned long long>() + 1023;      // zeroed with the work counters
+    }
     O.istats = p->collect_stats ? ctx->w_istats.as<int32_t>() : nullptr;
     O.dstats = p->collect_stats ? ctx->w_dstats.as<double>() : nullptr;
 
@@ -923,8 +931,14 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, hipMemcpy(st.data(), ctx->w_status.p, n * 4, hipMemcpyDeviceToHost));
         uint32_t any = 0; uint64_t first = 0;
         for (uint64_t i = 0; i < n; i++) if (st[i]) { if (!any) first = i; any |= st[i]; }
+        if ((any & 16) && getenv("TKSMSEQ_VERBOSE")) {
+            std::string l;
+            int shown = 0;
+            for (uint64_t i = 0; i < n && shown < 16; i++) if (st[i] & 16) { l += " " + std::to_string(i); shown++; }
+            fprintf(stderr, "[tksmseq] reads with an unbanded alignment (first %d):%s\n", shown, l.c_str());
+        }
         if (any & 2) { ctx->err = "modification position outside its interval at read " + std::to_string(first); return TKSMSEQ_EINVAL; }
-        if (any & 4) { ctx->err = "internal: alignment band failure at read " + std::to_string(first); return TKSMSEQ_EDEVICE; }
+        if (any & 4) { ctx->err = "out of memory for the unbanded alignment fallback at read " + std::to_string(first) + " (TKSMSEQ_FULL_POOL_MB)"; return TKSMSEQ_ENOMEM; }
         if (any & 8) {
             uint64_t f8 = 0;
             for (uint64_t i = 0; i < n; i++) if (st[i] & 8) { f8 = i; break; }

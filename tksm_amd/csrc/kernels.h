@@ -78,11 +78,13 @@ struct SimBuffers {
     uint32_t* out_len;           // [n_reads]
     double* identity;            // [n_reads]
     uint64_t* rec_len;           // [n_reads] formatted record length
-    uint32_t* status;            // [n_reads] 0 ok, bit0 overflow, bit1 bad mod position, bit2 band failure
+    uint32_t* status;            // [n_reads] 0 ok, bit0 overflow, bit1 bad mod position, bit2 alignment fallback out of memory, bit3 too long for the wave-wide kernel, bit4 (informational) an alignment took the unbanded fallback
     uint32_t* trace;             // [n_waves][trace_words]
     unsigned long long* work_counter;
     int32_t* istats;             // optional [n_reads][16]
     double* dstats;              // optional [n_reads][2]
+    // k_simulate only: memory for the unbanded alignment of the rare window the guided band cannot hold (bump allocator)
+    uint8_t* full_pool; unsigned long long full_pool_bytes; unsigned long long* full_pool_used;
     const uint32_t* read_list;   // k_simulate only: optional list of reads to process (slow path), else all
     uint64_t n_work;             // k_simulate only: number of work items (list length or n_reads)
 };

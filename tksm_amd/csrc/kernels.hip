@@ -277,6 +277,95 @@ DEV AlnOut band_align(const uint8_t* F, int n, const uint8_t* N, const uint16_t*
     return o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Unbanded alignment, for the rare window whose optimal path the guided band cannot hold (the end cell outside the last
+// window: a homopolymer that lost more than 32 bases at the end of the read, ...).  Same recurrence and predecessor
+// preference as band_align, every row: 64 rows per pass over the columns, lane = row, the last row of a pass is the
+// boundary of the next; per (pass, column) the masks {up ok, left ok}; then the walk from (n, m).  Restates full_align of
+// the oracle (oracle/tksm_oracle.c), which the specification prescribes for exactly this case.
+// Returns false when the pool cannot hold the masks (the caller reports status bit 2).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+DEV bool full_align_wave(const uint8_t* F, int n, const uint8_t* N, int m, int lane, const SimBuffers& O, int& mt_out, int& cols_out,
+                         uint8_t* popd) {
+    const int nblk = (n + 63) / 64;
+    const size_t stride = (size_t)(m + 1) * 2;                          // u64 words per pass
+    const unsigned long long bytes = (((unsigned long long)nblk * stride * 8ull + 2ull * (unsigned long long)(m + 64) * 4ull) + 255ull) & ~255ull;
+    unsigned long long off = 0;
+    if (lane == 0) off = atomicAdd(O.full_pool_used, bytes);
+    off = (unsigned long long)__shfl((long long)off, 0, 64);
+    if (!O.full_pool || off + bytes > O.full_pool_bytes) return false;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(O.full_pool + off);
+    int* hprev = reinterpret_cast<int*>(masks + (size_t)nblk * stride);
+    int* hcur = hprev + (m + 64);
+    for (int j = lane; j <= m; j += 64) hprev[j] = j;                    // row 0: H[0][j] = j
+    wave_sync();
+    for (int b = 0; b < nblk; b++) {
+        const int i = 64 * b + lane + 1;
+        const bool valid = i <= n;
+        const int fc = valid ? (int)F[i - 1] : 257;
+        int H = valid ? i : BIG;                                         // column 0: H[i][0] = i
+        if (lane == 63) hcur[0] = H;
+        int chunk = hprev[min(lane, m)];                                 // boundary values of columns 0..63
+        int outv = 0;
+        for (int j = 1; j <= m; j++) {
+            const int top_d = __shfl(chunk, (j - 1) & 63, 64);           // H[64b][j-1]
+            if ((j & 63) == 0) chunk = hprev[min(j + lane, m)];
+            const int top_u = __shfl(chunk, j & 63, 64);                 // H[64b][j]
+            const int match = fc == (int)N[j - 1];
+            int hd = __shfl_up(H, 1, 64);
+            if (lane == 0) hd = top_d;
+            const int vd = !is_inf(hd) ? hd + 1 - match : BIG;
+            const int vl = !is_inf(H) ? H + 1 : BIG;
+            const int vu0 = lane == 0 ? top_u + 1 : BIG;
+            const int tmin = valid ? min(min(vd, vl), vu0) : BIG;
+            const int x = scan_min_incl(tmin - lane, lane) + lane;       // vertical moves inside the pass
+            const int h = (valid && !is_inf(x)) ? x : BIG;
+            int hup = __shfl_up(h, 1, 64);
+            if (lane == 0) hup = top_u;
+            const bool upok = valid && hup + 1 == h;
+            const bool leftok = valid && vl == h;
+            const unsigned long long um = __ballot(upok), lm = __ballot(leftok);
+            if (lane == 0) { masks[(size_t)b * stride + 2 * (size_t)j] = um; masks[(size_t)b * stride + 2 * (size_t)j + 1] = lm; }
+            const int last = __shfl(h, 63, 64);                          // row 64(b+1): boundary of the next pass
+            if (lane == (j & 63)) outv = last;
+            if ((j & 63) == 63 || j == m) { const int j0 = j & ~63; if (j0 + lane <= j && j0 + lane >= 1) hcur[j0 + lane] = outv; }
+            H = h;
+        }
+        wave_sync();
+        int* tswap = hprev; hprev = hcur; hcur = tswap;
+    }
+    // walk from (n, m)
+    int i = n, j = m, mt = 0, cols = 0, dpend = 0;
+    while (i > 0 || j > 0) {
+        int mv;                                                          // 0 up, 1 left, 2 diagonal
+        if (j == 0) mv = 0;
+        else if (i == 0) mv = 1;
+        else {
+            const size_t at = (size_t)((i - 1) >> 6) * stride + 2 * (size_t)j;
+            const unsigned long long um = masks[at], lm = masks[at + 1];
+            const bool up = (um >> ((i - 1) & 63)) & 1ull, left = (lm >> ((i - 1) & 63)) & 1ull;
+            mv = MODE == 0 ? (up ? 0 : (left ? 1 : 2)) : (left ? 1 : (up ? 0 : 2));
+        }
+        cols++;
+        if (mv == 1) {
+            if (popd && lane == 0) popd[j - 1] = (uint8_t)(2 | (min(dpend, 63) << 2));
+            dpend = 0; j--;
+        } else if (mv == 0) {
+            dpend++; i--;
+        } else {
+            const bool eq = F[i - 1] == N[j - 1];
+            mt += eq;
+            if (popd && lane == 0) popd[j - 1] = (uint8_t)((eq ? 0 : 1) | (min(dpend, 63) << 2));
+            dpend = 0; i--; j--;
+        }
+    }
+    mt_out = mt; cols_out = cols;
+    // give the memory back if nobody allocated after this wave (the usual case: these alignments are rare)
+    if (lane == 0) atomicCAS(O.full_pool_used, off + bytes, off);
+    return true;
+}
+
 // joins slots [p0, p0+n) into N, owner[j] = window-relative slot of joined base j; returns the joined length
 // (may exceed ncap: nothing is written past ncap and the caller flags the overflow).
 DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint8_t* N, uint16_t* owner, int ncap, int lane) {
@@ -498,8 +587,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                             if (m > P.s_ncap) status |= 1;
                             else {
                                 const AlnOut a = band_align<0, false>(frag + p0, nrows, N, owner, m, lane, nullptr);
-                                if (is_inf(a.dist)) status |= 4;
-                                const int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
+                                int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
+                                if (is_inf(a.dist)) status |= full_align_wave<0>(frag + p0, nrows, N, m, lane, O, mt, cols, nullptr) ? 16u : 4u;
                                 const double ident = cols ? (double)mt / (double)cols : 0.0;
                                 if (L <= 1000) errors = (1.0 - ident) * frag_len;
                                 else {
@@ -541,10 +630,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
             if (P.compute_q && m > 0 && !(status & 1)) {
                 // ---- S5 q-scores (py/tksm_badread.py:607-655): align read vs fragment with path
                 const AlnOut a = band_align<1, true>(frag, L, N, owner, m, lane, trace);
-                if (is_inf(a.dist)) status |= 4;
                 wave_sync();
                 int mt = 0, cols = 0;
-                if (!(status & 4)) {
+                const bool banded = !is_inf(a.dist);
+                if (!banded) status |= full_align_wave<1>(frag, L, N, m, lane, O, mt, cols, popd) ? 16u : 4u;
+                if (banded) {
                     int rr2 = L, j = m, dpend = 0;
                     while (rr2 > 0 || j > 0) {
                         int mv;                                  // 0 up, 1 left, 2 diagonal

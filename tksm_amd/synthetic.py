@@ -12,7 +12,8 @@ Arrays are produced directly in the binary batch layout of include/tksmseq.h.
 import numpy as np
 
 
-def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", id_prefix="mol", lognormal_sigma=None):
+def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", id_prefix="mol", lognormal_sigma=None,
+                   polya_mean=15.0):
     """Returns dict(reads, intervals, mods, literals, literal_pool, ids, id_pool, raw_len) as numpy arrays.
     lognormal_sigma: transcript-like skewed lengths, median mean_len, clipped to [200, 16000] (instead of the normal)."""
     contig_lens = np.asarray(contig_lens, np.int64)
@@ -41,7 +42,7 @@ def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", i
         # barcode whitelist of 4096 16-mers, UMIs unique per molecule, polyA of variable length
         wl = rs.choice(np.frombuffer(b"ACGT", np.uint8), (4096, 16))
         umi = rs.choice(np.frombuffer(b"ACGT", np.uint8), (n, 10))
-        pa_len = np.clip(np.rint(rs.normal(15, 7.5, n)), 0, 5000).astype(np.int64)
+        pa_len = np.clip(np.rint(rs.normal(polya_mean, polya_mean / 2.0, n)), 0, 5000).astype(np.int64)
         max_pa = int(pa_len.max()) if n else 0
         pool_arr = np.concatenate([wl.reshape(-1), umi.reshape(-1), np.full(max_pa, ord("A"), np.uint8)])
         pool = pool_arr.tobytes()

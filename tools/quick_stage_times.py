@@ -18,7 +18,8 @@ rs=np.random.RandomState(2)
 KIND=sys.argv[2] if len(sys.argv)>2 else 'bulk'
 MEAN=int(sys.argv[3]) if len(sys.argv)>3 else 1000
 SIG=float(sys.argv[4]) if len(sys.argv)>4 else None
-m=synthetic.make_molecules(rs,[16_000_000]*4,B,MEAN,MEAN//5,kind=KIND,lognormal_sigma=SIG)
+PA=float(os.environ.get('POLYA_MEAN','15'))
+m=synthetic.make_molecules(rs,[16_000_000]*4,B,MEAN,MEAN//5,kind=KIND,lognormal_sigma=SIG,polya_mean=PA)
 print('lengths: mean %.0f max %d' % (m['raw_len'].mean(), m['raw_len'].max()), flush=True)
 b=s.batch_from_arrays(m["reads"],m["intervals"],m["mods"],m["literals"],m["literal_pool"],m["ids"],m["id_pool"])
 s.set_timing(True)
