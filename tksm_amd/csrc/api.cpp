@@ -660,7 +660,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_geo.ensure((size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo) + 64));
         HIPCHK(ctx, ctx->f_wsh.ensure(tot_jc * 8 + 64));
         HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 8 + 64));
-        FB.full_rows = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(jcap, 16384), (6ull << 30) / ((uint64_t)(ncap + 16) * 16));   // pool of at most 6 GB
+        // pool of full-width rows: as many as a round can ask for, at most 4 GB (homopolymer-rich batches need many)
+        FB.full_rows = (uint32_t)std::min<uint64_t>(jcap, (4ull << 30) / ((uint64_t)(ncap + 16) * 16));
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * (size_t)(ncap + 16) * 16 + 64));
         HIPCHK(ctx, ctx->f_counters.ensure(256));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
@@ -833,7 +834,12 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             // slowest read (25-45 ms), so they are collected while the rounds are busy and flushed in batches
             // (128 at a time, once more when the rounds become latency-bound; what comes after that waits for the end)
             const bool late = cnt[0] * 16ull < n;
-            if (cnt[2] - n_side >= 128 || (cnt[2] > n_side && late && !late_flushed)) { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
+            // -- and only onto a side stream that has finished its previous launch, unless a lot is waiting: many small
+            // launches in a row on one stream each cost the full latency
+            const uint32_t pending = cnt[2] - n_side;
+            const int k_next = (int)(side_launches % tksmseq_ctx::N_SIDE);
+            const bool stream_idle = !ctx->side_used[k_next] || hipEventQuery(ctx->side_done[k_next]) == hipSuccess;
+            if ((pending >= 128 && (stream_idle || pending >= 2048)) || (pending && late && !late_flushed)) { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
             late_flushed = late_flushed || late;
             if (cnt[0] == 0) {
                 if (cnt[1] == 0 || revived) break;
