@@ -947,7 +947,7 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 //              column) through a small LDS staging area filled with ds_or atomics -- the joined bytes and their
 //              owner array are never materialised;
 //  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
-// Returns the job id (bit 31: the job cannot be represented: a shift > 31 or more than 32 rows within 8 columns).
+// Returns the job id (bit 31: the job cannot be represented: a shift > 31 rows).
 DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
                       int p0, int n, int& m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
     const int lnw = ncap_l / 64 + 2, lshw = ncap_l / 8 + 16;
@@ -1014,7 +1014,6 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             const uint32_t shw = t < nrec ? shn[t] : 0u, shx = t < nrec ? (uint32_t)plb[16 * lnw + t] : 0u;
             const uint32_t x4 = (shw & 0x0f0f0f0fu) + ((shw >> 4) & 0x0f0f0f0fu);
             const int adv = (int)((x4 * 0x01010101u) >> 24) + 16 * __popc(shx);
-            if (adv > 32) fail = true;                            // more rows than one record carries
             const int incl = scan_add_incl(adv, lane);
             const int tk = tcar + incl - adv;                     // window top at the start of block t
             tcar += __shfl(incl, 63, 64);
@@ -1023,7 +1022,9 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
                 const int o = p0 + tk - 1 + 64, w = o >> 6, s2 = o & 63;
                 const uint32_t elo = lo32(funnel128(fp[2 * w], fp[2 * w + 2], s2)), ehi = lo32(funnel128(fp[2 * w + 1], fp[2 * w + 3], s2));
                 uint4 rec;
-                rec.x = shw; rec.y = (uint32_t)plb[t] | ((uint32_t)plb[8 * lnw + t] << 8) | (shx << 16); rec.z = elo; rec.w = ehi;
+                // bit 24: the window moves by more rows in this block than the record carries (a homopolymer that lost most of
+                // its bases): k_aln then takes the window from the read's fragment planes, column by column
+                rec.x = shw; rec.y = (uint32_t)plb[t] | ((uint32_t)plb[8 * lnw + t] << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u); rec.z = elo; rec.w = ehi;
                 jc[t] = rec;
             }
         }
@@ -1458,6 +1459,7 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
 // back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
 struct AlnJob {
     bool act; int p0, n, m, mode;
+    const unsigned long long* fp;    // fragment planes of the read, {lo, hi} word pairs (blocks flagged in their record only)
     const uint4* jc;                 // the job's block records
     const uint4* jc0;                // records of the wave's first job
     int cw;                          // records per job
@@ -1513,6 +1515,8 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
             if (!(act && cb < m)) { rec.x = 0u; rec.y = 0u; rec.z = 0u; rec.w = 0u; }
             const uint32_t shw = rec.x, nbits = rec.y;
             uint32_t EA = rec.z, EB = rec.w;                      // the 32 rows after the window
+            const bool esc = (nbits >> 24) & 1u;                  // ... are not enough in this block (rare)
+            const bool esc_any = __ballot(esc) != 0ull;
             // shift words for the walk, coalesced lines per block: {bits 0-3 of the 8 shifts, bit 4 of the 8 shifts}
             J.wsh0[(size_t)(cb >> 3) * 64 + lane] = make_uint2(shw, (nbits >> 16) & 0xffu);
 #pragma unroll
@@ -1527,6 +1531,15 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
                 Pv &= ~f; Mv |= f;
                 A = mk64(alignbit(EA, hi32(A), sh), alignbit(hi32(A), lo32(A), sh)); EA >>= sh;
                 B = mk64(alignbit(EB, hi32(B), sh), alignbit(hi32(B), lo32(B), sh)); EB >>= sh;
+                if (esc_any) {
+                    if (esc) {
+                        const int o = J.p0 + t - 1, w = o >> 6;
+                        const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w);
+                        const ulonglong2 q1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 2);
+                        A = funnel128(q0.x, q1.x, o & 63); B = funnel128(q0.y, q1.y, o & 63);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this rare path stays in flight (exact waits elsewhere)
+                }
                 const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
                 const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
                 // rows below the fragment (i > n) are not masked: they never feed a row above them
@@ -1686,6 +1699,10 @@ DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long
             Pv &= ~f; Mv |= f;
             A = mk64(alignbit(EA, hi32(A), sh), alignbit(hi32(A), lo32(A), sh)); EA >>= sh;
             B = mk64(alignbit(EB, hi32(B), sh), alignbit(hi32(B), lo32(B), sh)); EB >>= sh;
+            if ((rec.y >> 24) & 1u) {                                 // more entering rows than the record carries
+                const int o = J.p0 + t - 1, w = o >> 6;
+                A = funnel128(J.fp[2 * w], J.fp[2 * w + 2], o & 63); B = funnel128(J.fp[2 * w + 1], J.fp[2 * w + 3], o & 63);
+            }
             const uint32_t cl = 0u - ((rec.y >> (c & 7)) & 1u), ch = 0u - ((rec.y >> (8 + (c & 7))) & 1u);
             const unsigned long long Eq = ~((A ^ mk64(cl, cl)) | (B ^ mk64(ch, ch)));
             const unsigned long long Xv = Eq | Mv;
@@ -1789,6 +1806,7 @@ DEV void load_job(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act, A
     const RangeGeo G = FB.geo_cur[rng];
     const uint32_t rel = job - FB.base_cur[rng];
     J.cw = (int)G.cw;
+    J.fp = FB.st_fplanes + (size_t)r * 2 * FB.fw;
     J.jc = FB.job_cols + G.jc_off + (size_t)rel * G.cw;
     J.win.x = 0ull; J.win.y = 0ull;
     if (act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
