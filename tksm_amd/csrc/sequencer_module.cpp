@@ -58,26 +58,40 @@ void usage(FILE* f) {
             "                [-s SEED] [--devices D] [--batch-bytes B] [--in-flight N] [--verbosity L] [--log-file F]\n");
 }
 
+// one gzip member (RFC 1952) holding d[0..n): members simply follow each other in a .gz file, so batches -- and pieces of
+// a batch -- are compressed independently, on the worker threads, and the writer appends bytes
+bool gzip_member(const uint8_t* d, size_t n, std::vector<uint8_t>& out) {
+    z_stream z{};
+    if (deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&z, (uLong)n) + 64);
+    z.next_in = const_cast<Bytef*>(d); z.avail_in = (uInt)n;
+    z.next_out = out.data(); z.avail_out = (uInt)out.size();
+    const int rc = deflate(&z, Z_FINISH);
+    out.resize(rc == Z_STREAM_END ? z.total_out : 0);
+    deflateEnd(&z);
+    return rc == Z_STREAM_END;
+}
+
 struct Writer {
-    FILE* f = nullptr; gzFile g = nullptr; bool fastq = false;
+    FILE* f = nullptr; bool gz = false, fastq = false, wrote = false;
     bool open(const std::string& path) {                 // get_output_file, py/sequence.py:291-300
         std::string p = path;
-        if (p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0) { g = gzopen(path.c_str(), "wb"); p.resize(p.size() - 3); if (!g) return false; }
-        else { f = fopen(path.c_str(), "wb"); if (!f) return false; }
+        if (p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0) { gz = true; p.resize(p.size() - 3); }
+        f = fopen(path.c_str(), "wb");
+        if (!f) return false;
         auto ends = [&](const char* s) { size_t n = strlen(s); return p.size() >= n && p.compare(p.size() - n, n, s) == 0; };
         fastq = ends(".fastq") || ends(".fq");
         return true;
     }
-    bool write(const uint8_t* d, size_t n) {
-        while (n) {
-            size_t c = n > (1u << 30) ? (1u << 30) : n;
-            if (g) { if (gzwrite(g, d, (unsigned)c) != (int)c) return false; }
-            else if (fwrite(d, 1, c, f) != c) return false;
-            d += c; n -= c;
-        }
-        return true;
+    bool write(const uint8_t* d, size_t n) {             // for .gz outputs the bytes are finished gzip members
+        wrote = wrote || n;
+        return fwrite(d, 1, n, f) == n;
     }
-    void close() { if (g) gzclose(g); if (f) fclose(f); g = nullptr; f = nullptr; }
+    void close() {
+        if (!f) return;
+        if (gz && !wrote) { std::vector<uint8_t> e; if (gzip_member(nullptr, 0, e)) fwrite(e.data(), 1, e.size(), f); }   // a valid empty .gz
+        fclose(f); f = nullptr;
+    }
 };
 
 // reads a batch of MDF text will produce: the depth column of every molecule header (mdf_generator, py/sequence.py:206-213)
@@ -110,6 +124,7 @@ struct ChunkQueue {                                       // bounded, closed by 
 struct Worker {                                           // one batch in flight: context + page-locked record buffers
     tksmseq_ctx* ctx = nullptr;
     uint8_t* host[2] = {nullptr, nullptr}; uint64_t host_cap[2] = {0, 0};
+    std::vector<uint8_t> packed[2];                     // .gz outputs: the batch as gzip members
     std::mutex m; std::condition_variable cv; bool host_busy = false;     // the writer still reads the buffers
     bool reserve(int k, uint64_t bytes) {
         if (bytes <= host_cap[k]) return true;
@@ -302,6 +317,23 @@ public:
                     if (tksmseq_result_download(W.ctx, W.host[k], nullptr)) { set_error(tksmseq_last_error(W.ctx)); return false; }
                     add_clk(2, t_copy);
                     fin.bytes[k] = r.records_bytes;
+                    if ((k == 0 ? wb : wp).gz) {
+                        // 16 MB pieces, compressed side by side (level 1), concatenated in order
+                        const size_t piece = 16u << 20, np = (size_t)((r.records_bytes + piece - 1) / piece);
+                        std::vector<std::vector<uint8_t>> parts(np);
+                        std::vector<char> okp(np, 0);
+                        std::vector<std::thread> zt;
+                        std::atomic<size_t> nextp{0};
+                        auto zwork = [&]() { for (size_t q; (q = nextp++) < np;) okp[q] = gzip_member(W.host[k] + q * piece, (size_t)std::min<uint64_t>(piece, r.records_bytes - q * piece), parts[q]); };
+                        for (size_t q = 0; q < std::min<size_t>(np, 6); q++) zt.emplace_back(zwork);
+                        for (auto& t2 : zt) t2.join();
+                        size_t total = 0;
+                        for (size_t q = 0; q < np; q++) { if (!okp[q]) { set_error("gzip compression failed"); return false; } total += parts[q].size(); }
+                        W.packed[k].resize(total);
+                        size_t at = 0;
+                        for (size_t q = 0; q < np; q++) { memcpy(W.packed[k].data() + at, parts[q].data(), parts[q].size()); at += parts[q].size(); }
+                        fin.bytes[k] = total;
+                    }
                     return true;
                 };
                 if (ok && n) {
@@ -328,8 +360,8 @@ public:
                 Worker& W = *workers[fin.worker];
                 bool ok = true;
                 const auto t_write = now();
-                if (fin.bytes[0]) ok = wb.write(W.host[0], fin.bytes[0]);
-                if (ok && fin.bytes[1]) ok = wp.write(W.host[1], fin.bytes[1]);
+                if (fin.bytes[0]) ok = wb.write(wb.gz ? W.packed[0].data() : W.host[0], fin.bytes[0]);
+                if (ok && fin.bytes[1]) ok = wp.write(wp.gz ? W.packed[1].data() : W.host[1], fin.bytes[1]);
                 add_clk(3, t_write);
                 { std::lock_guard<std::mutex> l(W.m); W.host_busy = false; }
                 W.cv.notify_all();
