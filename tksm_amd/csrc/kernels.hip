@@ -943,7 +943,7 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 }
 
 // Walks the slots of window [p0, p0+n) once, slot per lane, and
-//  build != 0: packs the joined sequence straight into the alignment job (2-bit planes + 4-bit window shift per
+//  build != 0: packs the joined sequence straight into the alignment job (2-bit planes + 5-bit window shift per
 //              column) through a small LDS staging area filled with ds_or atomics -- the joined bytes and their
 //              owner array are never materialised;
 //  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (lane == 0) FB.state[r].stage = 2;
 }
 
-// ---- tail cut: reads still in the error loop when few are left are finished by the wave-wide kernel in one launch
+// ---- tail cut (diagnostic, TKSMSEQ_TAIL_CUT): reads still in the error loop are handed to the wave-wide kernel
 __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
@@ -1452,7 +1452,7 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
 
 // ---- k_aln: bit-parallel (Myers / Hyyro) banded global alignment, one lane per job.
 // Column j of the joined sequence owns fragment rows t_j .. t_j+63 (bit b = row t_j + b); t advances by the
-// 4-bit shift the job carries.  Entering rows take vertical delta +1 (virtual cells below the previous window),
+// 5-bit shift the job carries.  Entering rows take vertical delta +1 (virtual cells below the previous window),
 // the row above the window is unreachable (horizontal delta in = +1), and when the window does not move the
 // top row can only be reached from the left (vertical delta forced to -1).  Per column the resolved predecessor
 // of every cell is stored as 2 bits {w0, w1}: 0 up, 1 left, 2 diagonal mismatch, 3 diagonal match; the walk
@@ -1475,13 +1475,15 @@ constexpr int ST_ROW = 12;          // first stored band row of the 8-byte prede
 
 // ---- the common case: 8 bytes of predecessor codes per column (rows 12..43 of the band; the path practically
 // never leaves them).  Written for the vector ALU and for the memory system:
-//  * every per-column shift is by 0..15, so the 64-bit words are moved with v_alignbit on their halves; the fragment
+//  * every per-column shift is by 0..31, so the 64-bit words are moved with v_alignbit on their halves; the fragment
 //    window slides, fed by the 32 entering rows each block record carries, instead of being re-extracted from the
 //    per-read planes (330 k concurrent jobs each touching its own plane and record lines thrash the L2);
 //  * everything a lane reads or writes in HBM moves as whole 64-byte lines, 4 threads per job, transposed through
 //    LDS: block records one group of 32 columns ahead, predecessor codes per 8 columns;
 //  * the loop body is branch-free and every memory operation is unconditional, so the waits on the prefetches do
-//    not have to drain the trace stores (gfx9 counts loads and stores in one counter, in issue order).
+//    not have to drain the trace stores (gfx9 counts loads and stores in one counter, in issue order); the one
+//    exception, a block whose window moves by more rows than its record carries, is a wave-uniform branch that ends
+//    with nothing in flight.
 // A lane whose walk needs a row outside the stored 32 reports needfull (redone by aln_full).
 DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned long long* tr_lds, uint4* rec_lds, int ablate,
                     uint32_t* devhist) {
