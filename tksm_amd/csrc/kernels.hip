@@ -1351,8 +1351,10 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
     if (S.stage == 0 && want_q && L > FB.defer_len) {
-        // A q-score alignment spans the whole read: on one lane, thousands of columns -- it would set the duration of
-        // this round's k_aln for everybody.  Long reads wait here (stage 3) and align together after the last round.
+        // A q-score alignment spans the whole read: on one lane, up to thousands of columns -- in the round its read
+        // happens to finish in it would set the duration of k_aln for everybody, and the last visit of k_err would be
+        // one more small launch.  Reads wait here (stage 3): all q-score alignments and all last visits run together
+        // after the last regular round, at full occupancy (FB.defer_len = 0; a larger value defers only longer reads).
         if (lane == 0) {
             S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
             S.resume_src = -1; S.pending = 0; S.stage = 3; S.st_draws = st_draws; S.st_aligns = st_aligns;
