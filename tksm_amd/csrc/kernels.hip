@@ -1388,6 +1388,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         wave_sync();
         const int margins = (QM.kmer_size - 1) / 2;
         const uint32_t hmask = (uint32_t)QM.n_slots - 1u;
+#ifdef TKSM_ABLATE
+        if (P.ablate == 30) hi = lo;
+#endif
         for (int i2 = lo + lane; i2 < hi; i2 += 64) {
             int s0 = i2 - margins, e0 = i2 + margins;
             while (s0 < 0 || e0 >= m) { s0++; e0--; }
@@ -1433,6 +1436,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         identity = 1.0 - errors / frag_len;
     }
     int m2 = m;
+#ifdef TKSM_ABLATE
+    if (P.ablate != 31)
+#endif
     (void)join_job(FB, 0, r, 0, 0, frag, nb, 0, L, m2, lds_ncap, aux, out_seq, lo, hi, lane);
     if (P.quirk_perfect) identity = 1.0;
     finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
