@@ -35,8 +35,9 @@ DEV Ph4 philox(uint64_t seed, uint64_t read, uint32_t stream, uint32_t n) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32x32 -> 64 product per word (v_mad_u64_u32) instead of a high and a low multiply
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
