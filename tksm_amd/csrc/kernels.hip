@@ -952,7 +952,7 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
                       int p0, int n, int& m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
     const int lnw = ncap_l / 64 + 2, lshw = ncap_l / 8 + 16;
-    unsigned long long* pl = reinterpret_cast<unsigned long long*>(stage);      // planes: code low, code high, shift bit 4
+    uint32_t* pl32 = reinterpret_cast<uint32_t*>(stage);                        // planes: code low, code high, shift bit 4
     uint32_t* shn = reinterpret_cast<uint32_t*>(stage + 24 * (size_t)lnw);
     uint32_t idx = 0;
     const uint32_t rc = pos / FB.rs;                       // the read's range of the sorted order
@@ -979,12 +979,15 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             const int sh = max(1, p + 1 - 31) - max(1, prevp + 1 - 31);
             if (sh > 31) fail = true;
             atomicOr(&shn[off >> 3], (uint32_t)(sh & 15) << (4 * (off & 7)));
-            if (sh & 16) atomicOr(&pl[2 * lnw + (off >> 6)], 1ull << (off & 63));
+            atomicOr(&pl32[4 * lnw + (off >> 5)], (uint32_t)((sh >> 4) & 1) << (off & 31));
+            // symbol x of a slot: the original base where the marker says so, else the stored 2-bit code
+            const uint32_t oc = (uint32_t)code_of(orig) & 3u;
+            const int mk = code ? (int)((code >> 10) & 3) : 1;
             for (int x2 = 0; x2 < len; x2++) {
                 const int c = off + x2;
-                const int cd = code_of(slot_sym(code, x2, orig));
-                if (cd & 1) atomicOr(&pl[c >> 6], 1ull << (c & 63));
-                if (cd & 2) atomicOr(&pl[lnw + (c >> 6)], 1ull << (c & 63));
+                const uint32_t cd = mk == x2 + 1 ? oc : (code >> (2 * x2)) & 3u;
+                atomicOr(&pl32[c >> 5], (cd & 1u) << (c & 31));
+                atomicOr(&pl32[2 * lnw + (c >> 5)], (cd >> 1) << (c & 31));
             }
         }
         if (out_seq)
