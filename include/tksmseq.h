@@ -73,6 +73,24 @@ int tksmseq_reference_info(const tksmseq_ctx* ctx, uint64_t* n_contigs, uint64_t
  * (colon list, <dir>/badread/<name>.{error,qscore}.gz, py/sequence.py:17-31) or a file path. */
 int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path);
 int tksmseq_load_qscore_model(tksmseq_ctx* ctx, const char* name_or_path);
+/* Tail noise, TAIL_NOISE_MODEL_PY.KDE_noise_generator (py/tksm_badread.py:886-962; sampled at :335, appended to the
+ * fragment before the k-base pads at :336-341).  name_or_path: "no_noise" (the default: nothing is appended), a name
+ * resolved through $TKSM_MODELS (<dir>/badread/<name>.tail.gz) or a JSON[.gz] file in the layout
+ * KDE_noise_generator.save writes (:935-942).  The tail's bases count towards `length=` but not towards
+ * `error_free_length=` (py/sequence.py:253-254).  --perfect output never carries a tail. */
+int tksmseq_load_tail_model(tksmseq_ctx* ctx, const char* name_or_path);
+typedef struct tksmseq_tail_model {
+    uint32_t n_lx, n_ly;
+    const double* lx;      /* [n_lx] tail lengths (Custom2Dist.lx) */
+    const double* ly;      /* [n_ly] fragment-length labels, sorted (Custom2Dist.ly) */
+    const double* grid;    /* [n_ly][n_lx] densities, >= 0, every row with a positive sum */
+    double trans[16];      /* [4][4] transition weights of the base chain (transition_matrix[1]) */
+    double ratio;          /* probability that a read gets a tail */
+    uint8_t bases[4];      /* output byte of each chain state (default "AGTC") */
+    uint8_t pad[4];
+} tksmseq_tail_model;
+/* the same from tables in memory; NULL switches the tail off */
+int tksmseq_set_tail_model(tksmseq_ctx* ctx, const tksmseq_tail_model* model);
 /* Identities.__init__ + beta_parameters, py/tksm_badread.py:703-757 (percent units, as the CLI). */
 int tksmseq_set_identity(tksmseq_ctx* ctx, double mean, double max, double stdev);
 

@@ -18,6 +18,7 @@ loader (tksm_amd/csrc/models.cpp) must reproduce bit for bit.
 """
 import ctypes as C
 import gzip
+import json
 import os
 import re
 import subprocess
@@ -57,6 +58,11 @@ class _IdentModel(C.Structure):
     _fields_ = [("constant", C.c_int32), ("pad", C.c_int32), ("value", C.c_double), ("qtab", C.c_void_p)]
 
 
+class _TailModel(C.Structure):
+    _fields_ = [("n_lx", C.c_int32), ("n_ly", C.c_int32), ("lx", C.c_void_p), ("ly", C.c_void_p), ("grid", C.c_void_p),
+                ("trans", C.c_double * 16), ("ratio", C.c_double), ("bases", C.c_uint8 * 4), ("pad", C.c_uint8 * 4)]
+
+
 class FragStats(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_draws", "n_noop", "n_kmers_applied", "change_count", "n_aligns", "n_random_change",
@@ -81,6 +87,10 @@ _lib.oracle_pct_hundredths.argtypes = [C.c_double]
 _lib.oracle_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
 _lib.oracle_qs_hash.restype = C.c_uint64
 _lib.oracle_qs_hash.argtypes = [C.c_uint64]
+_lib.oracle_tail_length.restype = C.c_int
+_lib.oracle_tail_length.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]
+_lib.oracle_tail_noise.restype = C.c_int
+_lib.oracle_tail_noise.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int]
 
 
 def philox(seed, read, stream, n):
@@ -412,9 +422,42 @@ def perfect_record(fastq, seed, read, seq, molecule_id):      # py/sequence.py:2
     return format_record(fastq, seed, read, seq, b"K" * len(seq), len(seq), 1.0, molecule_id)
 
 
+class TailModel:
+    """KDE_noise_generator.load (py/tksm_badread.py:944-962): JSON[.gz] {lx, ly, grid, begin, trans, ratio, bases}."""
+
+    def __init__(self, path_or_dict):
+        dc = path_or_dict
+        if not isinstance(dc, dict):
+            with _open(path_or_dict) as f:
+                dc = json.load(f)
+        self.lx = np.ascontiguousarray(dc["lx"], dtype=np.float64)
+        self.ly = np.ascontiguousarray(dc["ly"], dtype=np.float64)
+        self.grid = np.ascontiguousarray(dc["grid"], dtype=np.float64)
+        assert self.grid.shape == (len(self.ly), len(self.lx))
+        self.trans = np.ascontiguousarray(dc["trans"], dtype=np.float64)
+        assert self.trans.shape == (4, 4)
+        self.ratio = float(dc["ratio"])
+        self.bases = "".join(dc["bases"]).encode()
+        assert len(self.bases) == 4
+        self._c = _TailModel(len(self.lx), len(self.ly), self.lx.ctypes.data, self.ly.ctypes.data, self.grid.ctypes.data,
+                             (C.c_double * 16)(*self.trans.ravel()), self.ratio, (C.c_uint8 * 4)(*self.bases),
+                             (C.c_uint8 * 4)())
+
+    def length(self, frag_len, seed, read):
+        return _lib.oracle_tail_length(C.byref(self._c), frag_len, seed, read)
+
+    def noise_seq(self, frag_len, seed, read):
+        n = self.length(frag_len, seed, read)
+        buf = C.create_string_buffer(n + 8)
+        got = _lib.oracle_tail_noise(C.byref(self._c), frag_len, seed, read, buf, n)
+        assert got == n
+        return buf.raw[:n]
+
+
 def badread_record(fastq, seed, read, raw, identities, error_model, qscore_model, compute_qual, molecule_id,
-                   use_full=False):                          # py/sequence.py:242-258
+                   use_full=False, tail_model=None):         # py/sequence.py:242-258
     target = identities.get_identity(seed, read)
-    seq, qual, ident, st = sequence_fragment(raw, target, error_model, qscore_model, compute_qual, seed, read,
+    frag = bytes(raw) + (tail_model.noise_seq(len(raw), seed, read) if tail_model is not None else b"")
+    seq, qual, ident, st = sequence_fragment(frag, target, error_model, qscore_model, compute_qual, seed, read,
                                              use_full)
     return format_record(fastq, seed, read, seq, qual, len(raw), ident, molecule_id), st

@@ -337,6 +337,67 @@ double oracle_target_identity(const ident_model* im, uint64_t seed, uint64_t rea
     return im->value * q;
 }
 
+/* ------------------------------------------------------------------ tail noise
+ * TAIL_NOISE_MODEL_PY.KDE_noise_generator.noise_seq (py/tksm_badread.py:919-933), Custom2Dist.__call__ (:1023-1033),
+ * CustomDist (:975-991).  The noise is appended to the fragment before the k-base pads (:334-341); with the
+ * default `no_noise` model it is empty.
+ *   with probability 1 - ratio: nothing;
+ *   row   = np.searchsorted(ly, frag_len) (the :1025-1027 adjustment only moves for unsorted labels), past the
+ *           last label: last row and the quirk factor len(ly) / ly[-1] (:1029);
+ *   x     = int(lx[np.searchsorted(cdf_row, uniform)] * factor), cdf_row[i] = pdf[i] / sum + cdf_row[i-1];
+ *   chain = first state uniform over 4, then x steps of random.choices(range(4), trans[state]) (bisect_right on the
+ *           running sums scaled by their total), emitting bases[state] after each step.
+ * Philox stream ST_TAIL: counter 0 = {ratio draw, length draw, first state, -}; step t uses word t & 3 of counter
+ * 1 + (t >> 2).  Uniforms are word * 2^-32. */
+typedef struct {
+    int32_t n_lx, n_ly;
+    const double* lx;     /* [n_lx] tail lengths */
+    const double* ly;     /* [n_ly] fragment-length labels */
+    const double* grid;   /* [n_ly][n_lx] densities */
+    double trans[16];     /* [4][4] transition weights */
+    double ratio;
+    uint8_t bases[4]; uint8_t pad[4];
+} tail_model;
+
+int oracle_tail_length(const tail_model* tm, int frag_len, uint64_t seed, uint64_t read) {
+    const ph4 w = rng(seed, read, ST_TAIL, 0);
+    const double two32 = 1.0 / 4294967296.0;
+    if ((double)w.v[0] * two32 > tm->ratio) return 0;
+    int pos = 0;
+    while (pos < tm->n_ly && tm->ly[pos] < (double)frag_len) pos++;
+    if (pos < tm->n_ly - 1 && fabs(tm->ly[pos] - (double)frag_len) > fabs(tm->ly[pos + 1] - (double)frag_len)) pos++;
+    double mult = 1.0;
+    if (pos >= tm->n_ly) { mult = (double)pos / tm->ly[tm->n_ly - 1]; pos = tm->n_ly - 1; }
+    const double* pdf = tm->grid + (size_t)pos * tm->n_lx;
+    double sum = 0.0;
+    for (int i = 0; i < tm->n_lx; i++) sum += pdf[i];
+    const double val = (double)w.v[1] * two32;
+    double c = 0.0; int p2 = tm->n_lx - 1;
+    for (int i = 0; i < tm->n_lx; i++) { c = pdf[i] / sum + c; if (c >= val) { p2 = i; break; } }
+    const double x = tm->lx[p2] * mult;
+    if (!(x >= 1.0)) return 0;
+    return x > 1e9 ? 1000000000 : (int)x;
+}
+
+int oracle_tail_noise(const tail_model* tm, int frag_len, uint64_t seed, uint64_t read, uint8_t* out, int cap) {
+    const int x = oracle_tail_length(tm, frag_len, seed, read);
+    if (x > cap) return -1;
+    const double two32 = 1.0 / 4294967296.0;
+    int state = (int)(rng(seed, read, ST_TAIL, 0).v[2] >> 30);
+    double cum[16];
+    for (int s = 0; s < 4; s++) { double c = 0.0; for (int j = 0; j < 4; j++) { c += tm->trans[4 * s + j]; cum[4 * s + j] = c; } }
+    ph4 w = {{0, 0, 0, 0}};
+    for (int t = 0; t < x; t++) {
+        if ((t & 3) == 0) w = rng(seed, read, ST_TAIL, 1u + (uint32_t)(t >> 2));
+        const double v = (double)w.v[t & 3] * two32 * cum[4 * state + 3];
+        int nx = 0;
+        for (int j = 0; j < 3; j++) nx += cum[4 * state + j] <= v;
+        state = nx;
+        out[t] = tm->bases[state];
+    }
+    return x;
+}
+
 /* py/tksm_badread.py:324-451.  raw = error-free sequence (bytes).  Outputs the UNTRIMMED new
  * sequence/quals plus trims, exactly like the reference's locals, then the caller trims.
  * use_full: 1 = unbanded DP everywhere (slow, test only). */
@@ -356,7 +417,7 @@ int oracle_sequence_fragment(const uint8_t* raw, int raw_len, double target_iden
     uint8_t* joined = (uint8_t*)malloc((size_t)L * 6 + 16);
     uint32_t* cen = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)L * 6 + 16));   /* owner of each joined base */
     memset(st, 0, sizeof(*st));
-    /* :334-341 pad with k random bases each side (tail noise: no_noise) */
+    /* :334-341 pad with k random bases each side (the caller has appended the tail noise to raw) */
     ph4 pad = rng(seed, read, ST_PAD, 0);
     for (int j = 0; j < k; j++) {
         s.frag[j] = (uint8_t)BASES[(pad.v[0] >> (2 * j)) & 3];

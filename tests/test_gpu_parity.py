@@ -479,3 +479,86 @@ def test_band_failure_falls_back_to_the_unbanded_alignment(oracle_models, po, mo
         assert res.records()[0] == want
         assert res.stats()[0][0, 7] & 16                    # the run reports that it took the unbanded path
     s.close()
+
+
+TAIL_MODEL = os.path.join(GOLDEN, "tail_model_synth.json")
+
+
+@pytest.mark.parametrize("path", ["fast", "slow"])
+def test_tail_noise_bit_exact_vs_oracle(oracle_models, po, monkeypatch, path):
+    """tail-noise model (KDE_noise_generator, py/tksm_badread.py:886-962; appended at :335-339): whole records against
+    the oracle with the same model; error_free_length excludes the tail; switching the model off (or the seed) on the
+    same batch rebuilds the batch's lengths and order; symbols outside ACGT in `bases` take the wave-wide kernel."""
+    monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
+    if path == "fast":
+        monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0")
+    import json
+    s, ref, rs = _random_genome_seqr()
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    s.load_tail_model(TAIL_MODEL)
+    tm = po.TailModel(TAIL_MODEL)
+    mols = _make_molecules(rs, ref, 96, 700)
+    text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
+    batch = s.batch_from_mdf(text)
+    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    em, qm = oracle_models["em"], oracle_models["qm"]
+
+    def check(seed, tail):
+        recs = s.run(batch, target="badread", fastq=True, compute_qual=True, seed=seed, first_read_index=500, stride=2).records()
+        n_tail = 0
+        for i, (mid, ivs) in enumerate(mols):
+            raw = po.splice(ref, ivs)
+            want, st = po.badread_record(True, seed, 500 + 2 * i, raw, ident, em, qm, True, mid, tail_model=tail)
+            assert st.band_fail == 0
+            assert recs[i] == want, (i, mid)
+            n_tail += st.frag_len != len(raw) + 2 * em.k
+            assert f" error_free_length={len(raw)} ".encode() in recs[i]
+        return n_tail
+
+    assert check(SEED, tm) > 15                                # ratio 0.35 of 96 reads
+    assert check(SEED + 1, tm) > 15                            # other seed, other tails: lengths rebuilt
+    s.load_tail_model("no_noise")
+    assert check(SEED, None) == 0
+    # every read with a tail, and a state that emits 'N' (not a base the bit-parallel path can hold)
+    dc = json.load(open(TAIL_MODEL))
+    s.set_tail_model(dc["lx"], dc["ly"], dc["grid"], dc["trans"], 1.0, "AGTN")
+    dc["ratio"] = 1.0; dc["bases"] = list("AGTN")
+    assert check(SEED, po.TailModel(dc)) > 60
+    # perfect output never carries a tail
+    recs = s.run(batch, target="perfect", fastq=True, seed=SEED).records()
+    for i, (mid, ivs) in enumerate(mols[:8]):
+        assert recs[i] == po.perfect_record(True, SEED, i, po.splice(ref, ivs), mid)
+    s.close()
+
+
+def test_cli_tail_model_flag(tmp_path, po, oracle_models):
+    """--badread-tail-model through the module boundary (py/sequence.py:109-113, :343-345), and its error path."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    d = os.path.join(GOLDEN, "splice_corpus")
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    out = tmp_path / "tail.fastq"
+    r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", str(out), "-s", "9",
+                        "--badread-tail-model", TAIL_MODEL, "--batch-bytes", "4096"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    ref = po.get_reference_seqs([os.path.join(d, "ref.fa")])
+    from tksm_amd.sequence import Sequencer
+    s = Sequencer(0)
+    s.set_identity(84.0, 99.0, 5.5)
+    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    s.close()
+    tm = po.TailModel(TAIL_MODEL)
+    want = []
+    with open(os.path.join(d, "mols.mdf")) as f:
+        for i, (mid, ivs) in enumerate(po.mdf_generator(f)):
+            want.append(po.badread_record(True, 9, i, po.splice(ref, ivs), ident, oracle_models["em"], oracle_models["qm"], True, mid,
+                                          tail_model=tm)[0])
+    assert out.read_bytes() == b"".join(want)
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"lx": [1, 2], "ly": [5], "grid": [[0, 0]], "trans": [[1,1,1,1]], "ratio": 0.5, "bases": ["A","G","T","C"], "begin": []}')
+    r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", str(tmp_path / "x.fastq"),
+                        "--badread-tail-model", str(bad)], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "tail model" in r.stderr

@@ -196,3 +196,50 @@ def test_quirks_and_edge_cases(po, oracle_models):
     # non-ACGT k-mers fall back to a random change (py/tksm_badread.py:127-128)
     seq, qual, idt, st = po.sequence_fragment(b"N" * 200, 0.9, em, qm, False, 3, 8)
     assert st.n_random_change >= st.n_draws - 3 and qual == b"K" * len(seq)   # only flank-only k-mers are valid
+
+
+def test_tail_noise_matches_reference_distributions(po):
+    """oracle tail noise vs KDE_noise_generator.noise_seq run in the reference itself on the same synthetic model
+    (tests/golden/make_tail_golden.py): share of reads with a tail, tail-length histogram, first base, base transitions;
+    the fragment length past the last label reproduces the reference's len(ly) / ly[-1] factor (always empty here)."""
+    from scipy.stats import chi2
+    g = np.load(os.path.join(GOLDEN, "tail_reference_stats.npz"))
+    tm = po.TailModel(os.path.join(GOLDEN, "tail_model_synth.json"))
+    n_ref = int(g["n"])
+    n = 20000
+    code = np.full(256, -1); code[np.frombuffer(b"ACGT", np.uint8)] = np.arange(4)
+
+    def chi2_two_sample(a, b):
+        """two-sample chi-square on counts a (n_a draws) and b (n_b draws); returns the p-value"""
+        a = np.asarray(a, float); b = np.asarray(b, float)
+        keep = (a + b) >= 10
+        a = np.append(a[keep], a[~keep].sum()); b = np.append(b[keep], b[~keep].sum())
+        keep = (a + b) > 0
+        a, b = a[keep], b[keep]
+        k1, k2 = np.sqrt(b.sum() / a.sum()), np.sqrt(a.sum() / b.sum())
+        stat = (((k1 * a - k2 * b) ** 2) / (a + b)).sum()
+        return chi2.sf(stat, len(a) - 1)
+
+    for fi, fl in enumerate(g["frag_lens"]):
+        fl = int(fl)
+        lens = np.zeros(n, np.int64); first = np.zeros(4); trans = np.zeros((4, 4))
+        for r in range(n):
+            sq = tm.noise_seq(fl, 99 + fi, r)
+            lens[r] = len(sq)
+            if sq:
+                c = code[np.frombuffer(sq, np.uint8)]
+                assert (c >= 0).all()
+                first[c[0]] += 1
+                np.add.at(trans, (c[:-1], c[1:]), 1)
+        vals = g[f"len_values_{fl}"]; cnt = g[f"len_counts_{fl}"]
+        if fl > 4000:
+            assert vals.tolist() == [0] and (lens == 0).all()
+            continue
+        assert set(np.unique(lens)) <= set(vals.tolist()) | set(np.arange(0, 408, 8).tolist())
+        allv = np.union1d(vals, np.unique(lens))
+        a = np.array([cnt[vals == v].sum() for v in allv]); b = np.array([(lens == v).sum() for v in allv])
+        assert chi2_two_sample(a, b) > 1e-3, (fl, "length")
+        assert abs((lens == 0).mean() - cnt[vals == 0].sum() / n_ref) < 0.015
+        assert chi2_two_sample(g[f"first_{fl}"], first) > 1e-3, (fl, "first base")
+        for srow in range(4):
+            assert chi2_two_sample(g[f"trans_{fl}"][srow], trans[srow]) > 1e-3, (fl, "transitions from", srow)

@@ -32,6 +32,11 @@ class Result(C.Structure):
                 ("kernel_ms", C.c_float * 8)]
 
 
+class TailModelDesc(C.Structure):            # tksmseq_tail_model
+    _fields_ = [("n_lx", C.c_uint32), ("n_ly", C.c_uint32), ("lx", C.c_void_p), ("ly", C.c_void_p), ("grid", C.c_void_p),
+                ("trans", C.c_double * 16), ("ratio", C.c_double), ("bases", C.c_uint8 * 4), ("pad", C.c_uint8 * 4)]
+
+
 # every symbol include/tksmseq.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = [
     "tksmseq_create", "tksmseq_destroy", "tksmseq_last_error", "tksmseq_version", "tksmseq_set_stream",
@@ -41,7 +46,7 @@ SYMBOLS = [
     "tksmseq_get_identity", "tksmseq_batch_create", "tksmseq_batch_from_mdf_text", "tksmseq_batch_info",
     "tksmseq_batch_free", "tksmseq_run", "tksmseq_set_output_buffer", "tksmseq_set_timing",
     "tksmseq_result_download", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
-    "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free",
+    "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
 ]
 
 _lib = None
@@ -74,6 +79,8 @@ def load():
         "tksmseq_reference_info": (C.c_int, [vp, P(u64), P(u64), P(u64)]),
         "tksmseq_load_error_model": (C.c_int, [vp, C.c_char_p]),
         "tksmseq_load_qscore_model": (C.c_int, [vp, C.c_char_p]),
+        "tksmseq_load_tail_model": (C.c_int, [vp, C.c_char_p]),
+        "tksmseq_set_tail_model": (C.c_int, [vp, vp]),
         "tksmseq_set_identity": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "tksmseq_get_error_model": (C.c_int, [vp, P(i32), P(i32), P(i32), vp, vp, vp]),
         "tksmseq_get_qscore_model": (C.c_int, [vp, P(i32), P(i32), P(u64), vp, vp, vp, vp, vp]),

@@ -67,6 +67,11 @@ struct tksmseq_batch {
     DevBuf d_order;
     uint32_t max_raw = 0;
     uint64_t total_raw = 0;
+    // tail noise: raw_len / max_raw / order describe splice + tail while a tail model applies to the run
+    std::vector<uint32_t> splice_len;    // the spliced lengths (filled the first time a tail is added)
+    DevBuf d_tail;                       // [n_reads] tail lengths of the run keyed below
+    bool tail_on = false;
+    uint64_t tail_key[4] = {};           // seed, first read index, stride, model version
     // cached scratch sizing, keyed by (k, cap_num, cap_den, cap_add)
     int cache_k = -1, cache_num = 0, cache_den = 0, cache_add = 0;
     uint64_t cache_scratch = 0;
@@ -97,6 +102,8 @@ struct tksmseq_ctx : ContigLookup {
     // models
     ErrorModelHost em; QScoreModelHost qm; IdentityHost idm;
     bool em_uniform = false, em_alt0 = false;
+    TailModelHost tail; uint64_t tail_version = 0;
+    DevBuf d_tail_lx, d_tail_ly, d_tail_cdf, d_tail_chain;
     DevBuf d_pself, d_cdf32, d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
 
     // per-run work buffers
@@ -179,6 +186,8 @@ int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out) {
     c->d_nalts.borrow(src->d_nalts); c->d_qkeys.borrow(src->d_qkeys); c->d_qoff.borrow(src->d_qoff); c->d_qcnt.borrow(src->d_qcnt);
     c->d_qcdf.borrow(src->d_qcdf); c->d_qq.borrow(src->d_qq); c->d_qtab.borrow(src->d_qtab); c->d_qent.borrow(src->d_qent);
     c->d_qpairs.borrow(src->d_qpairs); c->d_qguide.borrow(src->d_qguide);
+    c->tail = src->tail; c->tail_version = src->tail_version;
+    c->d_tail_lx.borrow(src->d_tail_lx); c->d_tail_ly.borrow(src->d_tail_ly); c->d_tail_cdf.borrow(src->d_tail_cdf); c->d_tail_chain.borrow(src->d_tail_chain);
     return TKSMSEQ_OK;
 }
 
@@ -368,6 +377,40 @@ int tksmseq_load_qscore_model(tksmseq_ctx* ctx, const char* name_or_path) {
     }
 }
 
+static int install_tail_model(tksmseq_ctx* ctx, TailModelHost&& m) {
+    ctx->tail = std::move(m);
+    ctx->tail_version++;
+    if (!ctx->tail.enabled) return TKSMSEQ_OK;
+    int rc;
+    if ((rc = upload(ctx, ctx->d_tail_lx, ctx->tail.lx))) return rc;
+    if ((rc = upload(ctx, ctx->d_tail_ly, ctx->tail.ly))) return rc;
+    if ((rc = upload(ctx, ctx->d_tail_cdf, ctx->tail.cdf))) return rc;
+    std::vector<tk::TailChain> ch(1);
+    memcpy(ch[0].cum, ctx->tail.cum, sizeof(ch[0].cum));
+    ch[0].bases = (uint32_t)ctx->tail.bases[0] | ((uint32_t)ctx->tail.bases[1] << 8) | ((uint32_t)ctx->tail.bases[2] << 16) | ((uint32_t)ctx->tail.bases[3] << 24);
+    ch[0].pad = 0;
+    return upload(ctx, ctx->d_tail_chain, ch);
+}
+
+int tksmseq_load_tail_model(tksmseq_ctx* ctx, const char* name_or_path) {
+    if (!ctx || !name_or_path) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TailModelHost m;
+    if (!load_tail_model(name_or_path, m, ctx->err)) return TKSMSEQ_EINVAL;
+    return install_tail_model(ctx, std::move(m));
+}
+
+int tksmseq_set_tail_model(tksmseq_ctx* ctx, const tksmseq_tail_model* t) {
+    if (!ctx) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TailModelHost m;
+    if (t) {
+        if (!t->lx || !t->ly || !t->grid) { ctx->err = "tail model: null table"; return TKSMSEQ_EINVAL; }
+        if (!make_tail_model(t->lx, t->n_lx, t->ly, t->n_ly, t->grid, t->trans, t->ratio, t->bases, m, ctx->err)) return TKSMSEQ_EINVAL;
+    }
+    return install_tail_model(ctx, std::move(m));
+}
+
 int tksmseq_set_identity(tksmseq_ctx* ctx, double mean, double max, double stdev) {
     if (!ctx) return TKSMSEQ_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -526,6 +569,50 @@ int tksmseq_set_output_buffer(tksmseq_ctx* ctx, void* p, uint64_t cap) {
     return TKSMSEQ_OK;
 }
 
+static tk::BatchView batch_view(const tksmseq_batch* b) {
+    return tk::BatchView{b->reads.as<uint32_t>(), b->intervals.as<uint32_t>(), b->mods.as<uint32_t>(), b->literals.as<uint64_t>(),
+                         b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), b->n_reads, (uint32_t)b->n_literals};
+}
+static tk::RefView ref_view(const tksmseq_ctx* ctx) {
+    return tk::RefView{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
+                       ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
+}
+
+// Tail noise (py/tksm_badread.py:335-339) lengthens the fragment before the error loop, and everything that is sized or
+// ordered by length on the host follows: the lengths are drawn on the device (they depend on the run's seed and read
+// indices only), read back, and the batch's lengths, maximum and sorted order are rebuilt for this run.
+static int apply_tail(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params* p) {
+    const bool want = p->mode == TKSMSEQ_MODE_BADREAD && ctx->tail.enabled && b->n_reads > 0;
+    const uint64_t key[4] = {p->seed, p->first_read_index, p->read_index_stride ? p->read_index_stride : 1, ctx->tail_version};
+    if (want == b->tail_on && (!want || !memcmp(key, b->tail_key, sizeof(key)))) return TKSMSEQ_OK;
+    if (b->splice_len.empty()) b->splice_len = b->raw_len;
+    const uint64_t n = b->n_reads;
+    if (want) {
+        HIPCHK(ctx, b->d_tail.ensure(n * 4 + 16));
+        tk::TailView T{(int)ctx->tail.lx.size(), (int)ctx->tail.ly.size(), ctx->tail.ratio, ctx->d_tail_lx.as<double>(),
+                       ctx->d_tail_ly.as<double>(), ctx->d_tail_cdf.as<double>()};
+        HIPCHK(ctx, tk::launch_tail_lengths(batch_view(b), ref_view(ctx), T, key[0], key[1], key[2], b->d_tail.as<uint32_t>(), ctx->stream));
+        std::vector<uint32_t> tl(n);
+        HIPCHK(ctx, hipMemcpyAsync(tl.data(), b->d_tail.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint64_t r = 0; r < n; r++) {
+            const uint64_t t = (uint64_t)b->splice_len[r] + tl[r];
+            if (t > 0x7fffff00ull) { ctx->err = "molecule plus tail noise longer than 2^31 bases"; return TKSMSEQ_ELIMIT; }
+            b->raw_len[r] = (uint32_t)t;
+        }
+    } else b->raw_len = b->splice_len;
+    b->max_raw = 0;
+    for (uint32_t v : b->raw_len) b->max_raw = std::max(b->max_raw, v);
+    for (uint64_t r = 0; r < n; r++) b->order[r] = (uint32_t)r;
+    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) { return b->raw_len[x] < b->raw_len[y]; });
+    HIPCHK(ctx, hipMemcpyAsync(b->d_order.p, b->order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    b->cache_k = -1;                      // the cached scratch size was for the old lengths
+    b->tail_on = want;
+    memcpy(b->tail_key, key, sizeof(key));
+    return TKSMSEQ_OK;
+}
+
 static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params* p, int cap_num, int cap_den, int cap_add,
                     tksmseq_result* res, bool* overflow) {
     *overflow = false;
@@ -584,10 +671,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, hipMemsetAsync(ctx->w_dstats.p, 0, n * 16, s));
     }
 
-    tk::BatchView B{b->reads.as<uint32_t>(), b->intervals.as<uint32_t>(), b->mods.as<uint32_t>(), b->literals.as<uint64_t>(),
-                    b->litpool.as<uint8_t>(), b->ids.as<uint32_t>(), b->idpool.as<uint8_t>(), n, (uint32_t)b->n_literals};
-    tk::RefView R{ctx->d_packed.as<uint32_t>(), ctx->d_blocktab.as<uint32_t>(), ctx->d_pool.as<uint8_t>(),
-                  ctx->d_contigs.as<uint64_t>(), (uint32_t)ctx->contig_names.size()};
+    const tk::BatchView B = batch_view(b);
+    const tk::RefView R = ref_view(ctx);
     tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
@@ -605,6 +690,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     O.out_len = ctx->w_outlen.as<uint32_t>(); O.identity = ctx->w_ident.as<double>(); O.rec_len = ctx->w_reclen.as<uint64_t>();
     O.status = ctx->w_status.as<uint32_t>(); O.trace = ctx->w_trace.as<uint32_t>();
     O.work_counter = ctx->w_counter.as<unsigned long long>();
+    O.tail_len = (badread && b->tail_on) ? b->d_tail.as<uint32_t>() : nullptr;
+    O.tail_chain = ctx->d_tail_chain.as<tk::TailChain>();
     if (badread) {
         // memory for the unbanded alignments of the wave-wide kernel (rare: kernels.hip, full_align_wave)
         HIPCHK(ctx, ctx->w_fullpool.ensure(ctx->full_pool_bytes));
@@ -619,7 +706,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     float ms_err = 0, ms_aln = 0, ms_other = 0;
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
     HIPCHK(ctx, hipMemsetAsync(ctx->w_counter.p, 0, 8192, s));
-    HIPCHK(ctx, tk::launch_read_lengths(B, R, k, cap_num, cap_den, cap_add, ctx->w_rawlen.as<uint32_t>(), ctx->w_slotcap.as<uint64_t>(),
+    HIPCHK(ctx, tk::launch_read_lengths(B, R, k, cap_num, cap_den, cap_add, O.tail_len, ctx->w_rawlen.as<uint32_t>(), ctx->w_slotcap.as<uint64_t>(),
                                         ctx->w_status.as<uint32_t>(), s));
     HIPCHK(ctx, tk::launch_scan(ctx->w_slotcap.as<uint64_t>(), ctx->w_slotoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
@@ -988,7 +1075,9 @@ int tksmseq_run(tksmseq_ctx* ctx, const tksmseq_batch* batch, const tksmseq_run_
     }
     tksmseq_batch* b = const_cast<tksmseq_batch*>(batch);
     bool overflow = false;
-    int rc = run_once(ctx, b, p, 3, 2, 64, result, &overflow);
+    int rc = apply_tail(ctx, b, p);
+    if (rc != TKSMSEQ_OK) return rc;
+    rc = run_once(ctx, b, p, 3, 2, 64, result, &overflow);
     if (rc == TKSMSEQ_OK && overflow) {
         // insertion-heavy reads outgrew the default 1.5x slot: rerun with the worst-case factor
         rc = run_once(ctx, b, p, 6, 1, 64, result, &overflow);

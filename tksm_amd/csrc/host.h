@@ -39,11 +39,25 @@ struct BatchHost {
     std::vector<uint8_t> id_pool;
 };
 
+// tail-noise model (KDE_noise_generator, py/tksm_badread.py:886-962): the length sampler's grid and the base chain
+struct TailModelHost {
+    bool enabled = false;
+    std::vector<double> lx, ly;        // tail lengths; fragment-length labels (non-decreasing)
+    std::vector<double> cdf;           // [ly][lx] running sums of the normalised grid rows (CustomDist.__init__, :980-986)
+    double cum[16] = {};               // running sums of the 4 transition rows (random.choices)
+    double ratio = 0.0;
+    uint8_t bases[4] = {'A', 'G', 'T', 'C'};
+};
+
 bool read_text_file(const std::string& path, std::string& out, std::string& err);
 std::string resolve_model(const std::string& name, const char* kind);
 void cdf_thresholds(const std::vector<double>& probs, bool residual_to_one, std::vector<uint32_t>& out);
 bool load_error_model(const std::string& name_or_path, ErrorModelHost& m, std::string& err);
 bool load_qscore_model(const std::string& name_or_path, QScoreModelHost& m, std::string& err);
+// name_or_path "no_noise" disables the model
+bool load_tail_model(const std::string& name_or_path, TailModelHost& m, std::string& err);
+bool make_tail_model(const double* lx, size_t n_lx, const double* ly, size_t n_ly, const double* grid, const double* trans16,
+                     double ratio, const uint8_t* bases4, TailModelHost& m, std::string& err);
 bool make_identity(double mean, double max, double stdev, IdentityHost& id, std::string& err);
 
 // FASTA (py/sequence.py:168-186): calls sink(name, sequence) per record, in file order

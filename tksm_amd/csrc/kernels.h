@@ -60,6 +60,20 @@ struct IdentView {
     const double* qtab;
 };
 
+// tail noise (TAIL_NOISE_MODEL_PY.KDE_noise_generator, py/tksm_badread.py:886-1050): length sampler tables and the base chain
+struct TailView {
+    int n_lx, n_ly;
+    double ratio;
+    const double* lx;    // [n_lx] tail lengths
+    const double* ly;    // [n_ly] fragment-length labels
+    const double* cdf;   // [n_ly][n_lx] running sums of the normalised rows
+};
+struct TailChain {
+    double cum[16];      // running sums of the 4 transition rows
+    uint32_t bases;      // the 4 output bytes, state 0 in the low byte
+    uint32_t pad;
+};
+
 struct SimParams {
     uint64_t seed, first_read, stride;
     int mode, compute_q, fastq, quirk_perfect;
@@ -85,6 +99,8 @@ struct SimBuffers {
     double* dstats;              // optional [n_reads][2]
     // k_simulate only: memory for the unbanded alignment of the rare window the guided band cannot hold (bump allocator)
     uint8_t* full_pool; unsigned long long full_pool_bytes; unsigned long long* full_pool_used;
+    const uint32_t* tail_len;    // optional [n_reads]: tail-noise bases at the end of the read's raw_len (else none)
+    const TailChain* tail_chain;
     const uint32_t* read_list;   // k_simulate only: optional list of reads to process (slow path), else all
     uint64_t n_work;             // k_simulate only: number of work items (list length or n_reads)
 };
@@ -158,7 +174,9 @@ hipError_t launch_pack(const uint8_t* ascii, uint64_t n, uint64_t gstart, uint32
 hipError_t launch_fill_pool(const uint8_t* ascii, uint64_t n, uint64_t gstart, const uint32_t* blocktab,
                             uint8_t* pool, hipStream_t s);
 hipError_t launch_read_lengths(const BatchView& b, const RefView& r, int k, int cap_num, int cap_den, int cap_add,
-                               uint32_t* raw_len, uint64_t* slot_cap, uint32_t* status, hipStream_t s);
+                               const uint32_t* tail_len, uint32_t* raw_len, uint64_t* slot_cap, uint32_t* status, hipStream_t s);
+hipError_t launch_tail_lengths(const BatchView& B, const RefView& R, const TailView& T, uint64_t seed, uint64_t first_read,
+                               uint64_t stride, uint32_t* tail_len, hipStream_t s);
 hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
                            const IdentView& im, const SimParams& p, const SimBuffers& o, int n_wgs,
                            int waves_per_wg, hipStream_t s);

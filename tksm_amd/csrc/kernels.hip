@@ -197,13 +197,83 @@ DEV Ivl load_interval(const BatchView& B, const RefView& R, uint32_t idx) {
     return iv;
 }
 
+// tail noise length of one read (KDE_noise_generator.noise_seq / Custom2Dist.__call__ / CustomDist.__call__,
+// py/tksm_badread.py:919-926, :1023-1033, :988-991): nothing with probability 1 - ratio; else the row of the first label
+// >= the fragment length (past the last label: the last row and the factor len(ly) / ly[-1], as the reference has it),
+// inverse-CDF pick of a length, truncated product.  The host reads the lengths back to size the batch.
+__global__ void k_tail_lengths(BatchView B, RefView R, TailView T, uint64_t seed, uint64_t first_read, uint64_t stride,
+                               uint32_t* __restrict__ tail_len) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B.n_reads) return;
+    const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < ic; i++) total += load_interval(B, R, ib + i).len;
+    const Ph4 w = philox(seed, first_read + r * stride, ST_TAIL, 0);
+    const double two32 = 1.0 / 4294967296.0;
+    uint32_t x = 0;
+    if (!((double)w.x * two32 > T.ratio)) {
+        const double y = (double)total;
+        int lo = 0, hi = T.n_ly;                        // np.searchsorted(ly, y), side left
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (T.ly[mid] < y) lo = mid + 1; else hi = mid; }
+        int pos = lo;
+        if (pos < T.n_ly - 1 && fabs(T.ly[pos] - y) > fabs(T.ly[pos + 1] - y)) pos++;
+        double mult = 1.0;
+        if (pos >= T.n_ly) { mult = (double)pos / T.ly[T.n_ly - 1]; pos = T.n_ly - 1; }
+        const double* cdf = T.cdf + (size_t)pos * T.n_lx;
+        const double val = (double)w.y * two32;
+        lo = 0; hi = T.n_lx - 1;                        // first entry >= val (the last one if rounding left none)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] >= val) hi = mid; else lo = mid + 1; }
+        const double v = T.lx[lo] * mult;
+        if (v >= 1.0) x = v > 1e9 ? 1000000000u : (uint32_t)v;
+    }
+    tail_len[r] = x;
+}
+
+// the tail's bases (noise_seq, py/tksm_badread.py:927-933): a 4-state chain, first state uniform, one weighted step per
+// base.  Each lane turns its step's uniform into the map state -> next state; a wave scan composes the maps.
+DEV void tail_fill(const TailChain* TC, uint64_t seed, uint64_t g, uint8_t* dst, int x, int lane) {
+    if (x <= 0) return;
+    const double two32 = 1.0 / 4294967296.0;
+    int state = (int)(philox(seed, g, ST_TAIL, 0).z >> 30);
+    const uint32_t bases = TC->bases;
+    for (int t0 = 0; t0 < x; t0 += 64) {
+        const int t = t0 + lane;
+        uint32_t map = 0xE4u;                           // identity for the lanes past the end
+        if (t < x) {
+            const Ph4 w = philox(seed, g, ST_TAIL, 1u + (uint32_t)(t >> 2));
+            const uint32_t u = (t & 3) == 0 ? w.x : (t & 3) == 1 ? w.y : (t & 3) == 2 ? w.z : w.w;
+            map = 0u;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const double v = (double)u * two32 * TC->cum[4 * s + 3];
+                const uint32_t nx = (uint32_t)(TC->cum[4 * s] <= v) + (uint32_t)(TC->cum[4 * s + 1] <= v) + (uint32_t)(TC->cum[4 * s + 2] <= v);
+                map |= nx << (2 * s);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)map, o, 64);      // the earlier steps
+            if (lane >= o) {
+                uint32_t c = 0u;
+#pragma unroll
+                for (int s = 0; s < 4; s++) c |= ((map >> (2 * ((y >> (2 * s)) & 3u))) & 3u) << (2 * s);
+                map = c;
+            }
+        }
+        const int mine = (int)((map >> (2 * state)) & 3u);
+        if (t < x) dst[t] = (uint8_t)(bases >> (8 * mine));
+        state = __shfl(mine, 63, 64);
+    }
+}
+
 __global__ void k_read_lengths(BatchView B, RefView R, int k, int cap_num, int cap_den, int cap_add,
+                               const uint32_t* __restrict__ tail_len,
                                uint32_t* __restrict__ raw_len, uint64_t* __restrict__ slot_cap,
                                uint32_t* __restrict__ status) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= B.n_reads) return;
     uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
-    uint64_t total = 0;
+    uint64_t total = tail_len ? tail_len[r] : 0;
     for (uint32_t i = 0; i < ic; i++) total += load_interval(B, R, ib + i).len;
     raw_len[r] = (uint32_t)total;
     uint64_t cap = (total + 2 * (uint64_t)k) * cap_num / cap_den + cap_add;
@@ -428,7 +498,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
         if (rr >= O.n_work) break;                // every wave reaches this exit
         const uint64_t r = O.read_list ? (uint64_t)O.read_list[rr] : rr;
         const uint64_t g = P.first_read + r * P.stride;
-        const int raw_len = (int)O.raw_len[r];
+        const int raw_len = (int)O.raw_len[r];             // spliced bases + tail noise
+        const int tail = O.tail_len ? (int)O.tail_len[r] : 0;
         const int L = raw_len + 2 * k;
         const uint64_t slot = O.slot_off[r];
         const int cap = (int)((O.slot_off[r + 1] - slot) >> 1);
@@ -464,6 +535,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                 }
                 o += len;
             }
+            if (tail) tail_fill(O.tail_chain, P.seed, g, frag + o, tail, lane);     // py/tksm_badread.py:335-339
         }
         double identity = 1.0;
         int out_len = 0;
@@ -716,7 +788,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
         // ---- per-read results; record length of py/sequence.py:252-288
         if (P.quirk_perfect) identity = 1.0;
         if (lane == 0) {
-            const int efl = P.quirk_perfect ? out_len : raw_len;
+            const int efl = P.quirk_perfect ? out_len : raw_len - tail;
             const long long h = pct_hundredths(identity);
             const uint32_t idl = B.ids[2 * r + 1];
             // '@' uuid(36) ' length=' n ' error_free_length=' n ' read_identity=' x.xx '% molecule_id=' id '\n'
@@ -815,6 +887,7 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
             }
             o += len;
         }
+        if (O.tail_len && O.tail_len[r]) tail_fill(O.tail_chain, P.seed, g, frag + o, (int)O.tail_len[r], lane);
     }
     {
         const Ph4 pad = philox(P.seed, g, ST_PAD, 0);
@@ -863,6 +936,7 @@ DEV void finish_read(const BatchView& B, const SimParams& P, const SimBuffers& O
                      double identity, uint32_t status, int st_draws, int st_changes, int st_aligns, int L, int st_newlen,
                      int st_strim, int st_etrim, double errors, double target, int lane) {
     if (lane != 0) return;
+    if (O.tail_len && !P.quirk_perfect) raw_len -= (int)O.tail_len[r];      // error_free_length = len(raw_seq), py/sequence.py:254
     const long long h = pct_hundredths(identity);
     const uint32_t idl = B.ids[2 * r + 1];
     uint64_t rec = 1 + 36 + 8 + ndigits((unsigned)out_len) + 19 + ndigits((unsigned)raw_len) + 15 +
@@ -1939,7 +2013,7 @@ __global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffe
     if (r >= B.n_reads) return;
     uint8_t* hdr = hdr_all[wave];
     const uint64_t g = P.first_read + r * P.stride;
-    const uint32_t out_len = O.out_len[r], raw_len = P.quirk_perfect ? O.out_len[r] : O.raw_len[r];
+    const uint32_t out_len = O.out_len[r], raw_len = P.quirk_perfect ? O.out_len[r] : O.raw_len[r] - (O.tail_len ? O.tail_len[r] : 0u);
     int hl = 0;
     if (lane == 0) hl = format_header(hdr, P, g, out_len, raw_len, O.identity[r]);
     hl = __shfl(hl, 0, 64);
@@ -2131,10 +2205,17 @@ hipError_t launch_fill_pool(const uint8_t* ascii, uint64_t n, uint64_t gstart, c
     return hipGetLastError();
 }
 hipError_t launch_read_lengths(const BatchView& b, const RefView& r, int k, int cap_num, int cap_den, int cap_add,
-                               uint32_t* raw_len, uint64_t* slot_cap, uint32_t* status, hipStream_t s) {
+                               const uint32_t* tail_len, uint32_t* raw_len, uint64_t* slot_cap, uint32_t* status, hipStream_t s) {
     if (!b.n_reads) return hipSuccess;
     hipLaunchKernelGGL(k_read_lengths, dim3((unsigned)((b.n_reads + 255) / 256)), dim3(256), 0, s, b, r, k, cap_num, cap_den,
-                       cap_add, raw_len, slot_cap, status);
+                       cap_add, tail_len, raw_len, slot_cap, status);
+    return hipGetLastError();
+}
+hipError_t launch_tail_lengths(const BatchView& b, const RefView& r, const TailView& t, uint64_t seed, uint64_t first_read,
+                               uint64_t stride, uint32_t* tail_len, hipStream_t s) {
+    if (!b.n_reads) return hipSuccess;
+    hipLaunchKernelGGL(k_tail_lengths, dim3((unsigned)((b.n_reads + 255) / 256)), dim3(256), 0, s, b, r, t, seed, first_read, stride,
+                       tail_len);
     return hipGetLastError();
 }
 int simulate_lds_bytes(int lcap, int ncap, int wpw) { return wpw * (lcap * 3 + ncap * 4); }

@@ -6,6 +6,7 @@
 //                                        path; traceback prefers query-only, target-only, diagonal)
 //   QScoreModel.load_from_file/random/ideal   py/tksm_badread.py:487-582
 //   Identities / beta_parameters         py/tksm_badread.py:703-757
+//   KDE_noise_generator.load, Custom2Dist / CustomDist tables   py/tksm_badread.py:944-962, :975-1021
 //   model-name lookup through $TKSM_MODELS    py/sequence.py:17-31, src/sequence.cpp:38-52
 // and produces the packed device layouts described in DESIGN.md (identical, bit for bit, to the
 // tables oracle/pyoracle.py builds independently).
@@ -299,6 +300,159 @@ bool load_qscore_model(const std::string& name_or_path, QScoreModelHost& m, std:
         for (int q : r.scores) m.q_pool.push_back((uint8_t)q);
     }
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail-noise model: JSON {lx, ly, grid, begin, trans, ratio, bases} as KDE_noise_generator.save writes it
+// (py/tksm_badread.py:935-942); `begin` is read by the reference and never used (:912, :927)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct JVal {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    double num = 0.0; bool b = false; std::string str;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal* get(const char* key) const { for (auto& kv : obj) if (kv.first == key) return &kv.second; return nullptr; }
+};
+struct JParser {
+    const char* p; const char* e; std::string err;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    bool fail(const char* m) { if (err.empty()) err = m; return false; }
+    bool str(std::string& out) {
+        if (p >= e || *p != '"') return fail("expected a string");
+        p++; out.clear();
+        while (p < e && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= e) return fail("bad escape");
+                switch (*p) { case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                              case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                              case 'u': if (e - p < 5) return fail("bad escape"); out += (char)strtol(std::string(p + 1, 4).c_str(), nullptr, 16); p += 4; break;
+                              default: out += *p; }
+                p++;
+            } else out += *p++;
+        }
+        if (p >= e) return fail("unterminated string");
+        p++;
+        return true;
+    }
+    bool value(JVal& v, int depth) {
+        if (depth > 32) return fail("nesting too deep");
+        ws();
+        if (p >= e) return fail("unexpected end");
+        if (*p == '{') {
+            v.kind = JVal::Obj; p++; ws();
+            if (p < e && *p == '}') { p++; return true; }
+            for (;;) {
+                ws(); std::string k; if (!str(k)) return false;
+                ws(); if (p >= e || *p != ':') return fail("expected ':'");
+                p++;
+                v.obj.emplace_back(k, JVal());
+                if (!value(v.obj.back().second, depth + 1)) return false;
+                ws(); if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == '}') { p++; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (*p == '[') {
+            v.kind = JVal::Arr; p++; ws();
+            if (p < e && *p == ']') { p++; return true; }
+            for (;;) {
+                v.arr.emplace_back();
+                if (!value(v.arr.back(), depth + 1)) return false;
+                ws(); if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == ']') { p++; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (*p == '"') { v.kind = JVal::Str; return str(v.str); }
+        if (e - p >= 4 && !strncmp(p, "true", 4)) { v.kind = JVal::Bool; v.b = true; p += 4; return true; }
+        if (e - p >= 5 && !strncmp(p, "false", 5)) { v.kind = JVal::Bool; p += 5; return true; }
+        if (e - p >= 4 && !strncmp(p, "null", 4)) { p += 4; return true; }
+        if (e - p >= 3 && !strncmp(p, "NaN", 3)) { v.kind = JVal::Num; v.num = NAN; p += 3; return true; }
+        char* end = nullptr;
+        v.num = strtod(p, &end);                       // the text is NUL-terminated (std::string)
+        if (end == p) return fail("unexpected character");
+        v.kind = JVal::Num; p = end;
+        return true;
+    }
+};
+bool num_list(const JVal* v, std::vector<double>& out) {
+    if (!v || v->kind != JVal::Arr) return false;
+    for (auto& x : v->arr) { if (x.kind != JVal::Num) return false; out.push_back(x.num); }
+    return true;
+}
+}  // namespace
+
+bool make_tail_model(const double* lx, size_t n_lx, const double* ly, size_t n_ly, const double* grid, const double* trans16,
+                     double ratio, const uint8_t* bases4, TailModelHost& m, std::string& err) {
+    if (!n_lx || !n_ly) { err = "tail model: empty lx or ly"; return false; }
+    if (n_lx > (1u << 24) || n_ly > (1u << 24)) { err = "tail model: grid too large"; return false; }
+    m = TailModelHost();
+    m.lx.assign(lx, lx + n_lx); m.ly.assign(ly, ly + n_ly);
+    for (size_t i = 0; i < n_lx; i++) if (!std::isfinite(lx[i])) { err = "tail model: lx is not finite"; return false; }
+    for (size_t i = 0; i < n_ly; i++)
+        if (!std::isfinite(ly[i]) || (i && ly[i] < ly[i - 1])) { err = "tail model: ly must be finite and sorted (np.searchsorted)"; return false; }
+    if (!(ly[n_ly - 1] != 0.0)) { err = "tail model: last ly label is zero"; return false; }
+    m.cdf.resize(n_lx * n_ly);
+    for (size_t r = 0; r < n_ly; r++) {
+        const double* pdf = grid + r * n_lx;
+        double sum = 0.0;
+        for (size_t i = 0; i < n_lx; i++) {
+            if (!(pdf[i] >= 0.0) || !std::isfinite(pdf[i])) { err = "tail model: grid entries must be finite and >= 0"; return false; }
+            sum += pdf[i];
+        }
+        if (!(sum > 0.0)) { err = "tail model: a grid row sums to zero"; return false; }
+        double c = 0.0;
+        for (size_t i = 0; i < n_lx; i++) { c = pdf[i] / sum + c; m.cdf[r * n_lx + i] = c; }
+    }
+    for (int s = 0; s < 4; s++) {
+        double c = 0.0;
+        for (int j = 0; j < 4; j++) {
+            const double w = trans16[4 * s + j];
+            if (!(w >= 0.0) || !std::isfinite(w)) { err = "tail model: transition weights must be finite and >= 0"; return false; }
+            c += w; m.cum[4 * s + j] = c;
+        }
+        if (!(c > 0.0)) { err = "tail model: Total of weights must be greater than zero"; return false; }   // random.choices
+    }
+    if (!std::isfinite(ratio)) { err = "tail model: ratio is not finite"; return false; }
+    m.ratio = ratio;
+    memcpy(m.bases, bases4, 4);
+    m.enabled = true;
+    return true;
+}
+
+bool load_tail_model(const std::string& name_or_path, TailModelHost& m, std::string& err) {
+    if (name_or_path == "no_noise") { m = TailModelHost(); return true; }      // Mock_noise_generator, :964-972
+    std::string text;
+    if (!read_text_file(resolve_model(name_or_path, "tail"), text, err)) return false;
+    JParser jp{text.c_str(), text.c_str() + text.size(), {}};
+    JVal root;
+    if (!jp.value(root, 0) || root.kind != JVal::Obj) { err = "tail model: not a JSON object" + (jp.err.empty() ? std::string() : " (" + jp.err + ")"); return false; }
+    std::vector<double> lx, ly, grid, trans;
+    if (!num_list(root.get("lx"), lx) || !num_list(root.get("ly"), ly)) { err = "tail model: lx / ly missing or not numeric lists"; return false; }
+    const JVal* g = root.get("grid");
+    if (!g || g->kind != JVal::Arr || g->arr.size() != ly.size()) { err = "tail model: grid must hold one row per ly label"; return false; }
+    for (auto& row : g->arr) {
+        const size_t before = grid.size();
+        if (!num_list(&row, grid) || grid.size() - before != lx.size()) { err = "tail model: grid rows must hold one number per lx entry"; return false; }
+    }
+    const JVal* t = root.get("trans");
+    if (!t || t->kind != JVal::Arr || t->arr.size() != 4) { err = "tail model: trans must be 4 x 4"; return false; }
+    for (auto& row : t->arr) {
+        const size_t before = trans.size();
+        if (!num_list(&row, trans) || trans.size() - before != 4) { err = "tail model: trans must be 4 x 4"; return false; }
+    }
+    const JVal* r = root.get("ratio");
+    if (!r || r->kind != JVal::Num) { err = "tail model: ratio missing"; return false; }
+    const JVal* bs = root.get("bases");
+    uint8_t bases[4];
+    if (!bs || bs->kind != JVal::Arr || bs->arr.size() != 4) { err = "tail model: bases must list 4 symbols"; return false; }
+    for (int i = 0; i < 4; i++) {
+        if (bs->arr[i].kind != JVal::Str || bs->arr[i].str.size() != 1) { err = "tail model: bases must be single characters"; return false; }
+        bases[i] = (uint8_t)bs->arr[i].str[0];
+    }
+    if (!root.get("begin")) { err = "tail model: begin missing"; return false; }               // KeyError in the reference (:958)
+    return make_tail_model(lx.data(), lx.size(), ly.data(), ly.size(), grid.data(), trans.data(), r->num, bases, m, err);
 }
 
 // ---------------------------------------------------------------------------------------------

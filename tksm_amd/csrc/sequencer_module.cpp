@@ -217,7 +217,6 @@ public:
         if (mean > maxi) { char b[200]; snprintf(b, sizeof b, "Error: mean identity (%g) cannot be larger than max identity (%g)", mean, maxi); return die(b); }
         if (sd < 0.0) return die("Error: read identity stdev cannot be negative");
         if (a.badread.empty() && a.perfect.empty()) { usage(stderr); fprintf(stderr, "sequence: error: Must specify either --output or --perfect.\n"); return 2; }
-        if (a.tail_model != "no_noise") return die("Error: tail-noise models other than no_noise are not supported by this build yet");
 
         const auto t_begin = std::chrono::steady_clock::now();
         tksmseq_ctx* ctx = nullptr;
@@ -239,6 +238,7 @@ public:
                 fprintf(stderr, "\nLoading qscore model from %s\n", a.qscore_model.c_str());
                 if (tksmseq_load_qscore_model(ctx, a.qscore_model.c_str())) return fail("qscore model");
             }
+            if (tksmseq_load_tail_model(ctx, a.tail_model.c_str())) return fail("tail model");     // py/sequence.py:343-345
         }
         if (!a.perfect.empty() && !wp.open(a.perfect)) { tksmseq_destroy(ctx); return die("Error: cannot open " + a.perfect); }
         if (!a.badread.empty() && !a.perfect.empty())

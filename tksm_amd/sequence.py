@@ -146,6 +146,21 @@ class Sequencer:
     def load_qscore_model(self, name_or_path):
         self._chk(self._lib.tksmseq_load_qscore_model(self._ctx, str(name_or_path).encode()))
 
+    def load_tail_model(self, name_or_path="no_noise"):
+        """KDE_noise_generator.load (py/tksm_badread.py:944-962); "no_noise" switches the tail off."""
+        self._chk(self._lib.tksmseq_load_tail_model(self._ctx, str(name_or_path).encode()))
+
+    def set_tail_model(self, lx, ly, grid, trans, ratio, bases="AGTC"):
+        """The same from arrays (KDE_noise_generator.__init__, py/tksm_badread.py:905-917)."""
+        lx = np.ascontiguousarray(lx, np.float64); ly = np.ascontiguousarray(ly, np.float64)
+        grid = np.ascontiguousarray(grid, np.float64); trans = np.ascontiguousarray(trans, np.float64)
+        if grid.shape != (len(ly), len(lx)) or trans.shape != (4, 4) or len(bases) != 4:
+            raise ValueError("tail model: grid must be len(ly) x len(lx), trans 4 x 4, bases 4 symbols")
+        b = bases.encode() if isinstance(bases, str) else bytes(bases)
+        d = L.TailModelDesc(len(lx), len(ly), lx.ctypes.data, ly.ctypes.data, grid.ctypes.data, (C.c_double * 16)(*trans.ravel()),
+                          float(ratio), (C.c_uint8 * 4)(*b), (C.c_uint8 * 4)())
+        self._chk(self._lib.tksmseq_set_tail_model(self._ctx, C.byref(d)))
+
     def set_identity(self, mean=84.0, max_identity=99.0, stdev=5.5):
         self._chk(self._lib.tksmseq_set_identity(self._ctx, mean, max_identity, stdev))
 
