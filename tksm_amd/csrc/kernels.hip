@@ -1154,7 +1154,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     uint8_t* frag = STATE_IN_HBM ? FB.st_frag + r * (size_t)P.lcap : lds_wave;
     uint16_t* nb = STATE_IN_HBM ? gnb : reinterpret_cast<uint16_t*>(lds_wave + lds_lcap);
     uint8_t* aux = STATE_IN_HBM ? lds_wave : lds_wave + 3 * (size_t)lds_lcap;
-    uint8_t* popd = aux;
     const int k = EM.k;
     const uint64_t g = P.first_read + r * P.stride;
     const int raw_len = __builtin_amdgcn_readfirstlane(S.raw_len);
@@ -1462,6 +1461,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const uint32_t rc1 = pos / FB.rs;
         const uint8_t* gp = FB.prev_popd + FB.geo_prev[rc1].popd_off + (size_t)(S.job - FB.base_prev[rc1]) * FB.geo_prev[rc1].ncap;
         wave_sync();
+        uint8_t* popd = aux + 16;               // 16 bytes in front, 12 behind: the 9-byte windows are read as whole words
         for (int t = lane; t < m; t += 64) popd[t] = gp[t];
         wave_sync();
         const int margins = (QM.kmer_size - 1) / 2;
@@ -1470,33 +1470,65 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         if (P.ablate == 30) hi = lo;
 #endif
         for (int i2 = lo + lane; i2 < hi; i2 += 64) {
-            int s0 = i2 - margins, e0 = i2 + margins;
-            while (s0 < 0 || e0 >= m) { s0++; e0--; }
+            const int d = max(0, max(margins - i2, i2 + margins - (m - 1)));     // window shrunk symmetrically at the ends
             int row = -1; uint32_t roff = 0, rcnt = 0;
-            for (;;) {
-                uint64_t key = 0; int len = 0; bool ok = true;
-                for (int x2 = s0; x2 <= e0; x2++) {
-                    if (x2 > s0) {
-                        const int dd = popd[x2 - 1] >> 2;
-                        if (len + dd > 29) { ok = false; break; }
-                        key |= ((1ull << (2 * dd)) - 1ull) << (2 * len); len += dd;
-                    }
-                    if (len >= 29) { ok = false; break; }
-                    key |= (uint64_t)(popd[x2] & 3) << (2 * len); len++;
+            auto probe = [&](uint64_t key) {
+                uint32_t sl = (uint32_t)qs_hash(key) & hmask;
+                for (;;) {
+                    const uint4 e = QM.ent[sl];                   // {key lo, key hi, row offset, row count}
+                    const uint64_t kk = ((uint64_t)e.y << 32) | e.x;
+                    if (kk == key) { row = (int)sl; roff = e.z; rcnt = e.w; break; }
+                    if (kk == 0) break;
+                    sl = (sl + 1) & hmask;
                 }
-                if (ok) {
-                    key |= (uint64_t)len << 58;
-                    uint32_t s = (uint32_t)qs_hash(key) & hmask;
-                    for (;;) {
-                        const uint4 e = QM.ent[s];               // {key lo, key hi, row offset, row count}
-                        const uint64_t kk = ((uint64_t)e.y << 32) | e.x;
-                        if (kk == key) { row = (int)s; roff = e.z; rcnt = e.w; break; }
-                        if (kk == 0) break;
-                        s = (s + 1) & hmask;
-                    }
+            };
+            if (margins <= 4) {
+                // the windows [i2 - h, i2 + h], h = 0 .. 4, nest: their keys are built from the centre outwards in one
+                // pass over the 9 bytes around i2 (three aligned LDS words), then tried from the widest one down
+                // (a miss strips one symbol each side, get_qscore, py/tksm_badread.py:596-597)
+                const int ob = 16 + i2 - 4, sh = ob & 3;
+                const uint32_t* aw = reinterpret_cast<const uint32_t*>(aux) + (ob >> 2);
+                const uint32_t w0 = aw[0], w1 = aw[1], w2 = aw[2];
+                const uint32_t b0 = __builtin_amdgcn_alignbyte(w1, w0, sh), b1 = __builtin_amdgcn_alignbyte(w2, w1, sh), b2 = w2 >> (8 * sh);
+                auto byte_at = [&](int j) -> uint32_t { return j < 4 ? (b0 >> (8 * j)) & 255u : j < 8 ? (b1 >> (8 * (j - 4))) & 255u : b2 & 255u; };
+                uint64_t K[5]; int ln[5];
+                K[0] = byte_at(4) & 3u; ln[0] = 1;
+#pragma unroll
+                for (int h = 1; h <= 4; h++) {
+                    const uint32_t bl = byte_at(4 - h);
+                    const int ddl = (int)(bl >> 2), ddr = (int)(byte_at(3 + h) >> 2);
+                    ln[h] = ln[h - 1] + 2 + ddl + ddr;
+                    const bool fits = ln[h] <= 29;                 // longer keys do not exist (and would not fit 58 bits)
+                    const int sl_ = fits ? 2 * (1 + ddl) : 0, sr_ = fits ? 2 * (1 + ddl + ln[h - 1]) : 0, so_ = fits ? 2 * (ln[h] - 1) : 0;
+                    const int dl2 = fits ? 2 * ddl : 0, dr2 = fits ? 2 * ddr : 0;
+                    K[h] = (uint64_t)(bl & 3u) | (((1ull << dl2) - 1ull) << 2) | (K[h - 1] << sl_) | (((1ull << dr2) - 1ull) << sr_) |
+                           ((uint64_t)(byte_at(4 + h) & 3u) << so_);
                 }
-                if (row >= 0 || s0 == e0) break;
-                s0++; e0--;
+                const int hmax = margins - d;
+                bool pend = true;
+#pragma unroll
+                for (int h = 4; h >= 0; h--) {
+                    const bool tryit = pend && h <= hmax;
+                    if (__ballot(tryit) == 0ull) continue;
+                    if (tryit && ln[h] <= 29) { probe(K[h] | ((uint64_t)ln[h] << 58)); pend = row < 0; }
+                }
+            } else {
+                int s0 = i2 - margins + d, e0 = i2 + margins - d;
+                for (;;) {
+                    uint64_t key = 0; int len = 0; bool ok = true;
+                    for (int x2 = s0; x2 <= e0; x2++) {
+                        if (x2 > s0) {
+                            const int dd = popd[x2 - 1] >> 2;
+                            if (len + dd > 29) { ok = false; break; }
+                            key |= ((1ull << (2 * dd)) - 1ull) << (2 * len); len += dd;
+                        }
+                        if (len >= 29) { ok = false; break; }
+                        key |= (uint64_t)(popd[x2] & 3) << (2 * len); len++;
+                    }
+                    if (ok) probe(key | ((uint64_t)len << 58));
+                    if (row >= 0 || s0 == e0) break;
+                    s0++; e0--;
+                }
             }
             uint8_t q = 0;
             if (row >= 0) {
