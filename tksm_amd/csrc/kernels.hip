@@ -2099,49 +2099,195 @@ __global__ void k_perfect_lengths(BatchView B, RefView R, SimParams P, SimBuffer
     O.out_len[r] = L; O.identity[r] = 1.0; O.rec_len[r] = rec;
 }
 
+// One record, byte by byte (any length; also what the image path below falls back to when a record does not fit).
+DEV void perfect_record_bytewise(const BatchView& B, const RefView& R, const SimParams& P, uint64_t r, uint32_t L, uint8_t* hdr,
+                                 uint8_t* dst, int lane) {
+    int hl = 0;
+    wave_sync();
+    if (lane == 0) hl = format_header(hdr, P, P.first_read + r * P.stride, L, L, 1.0);
+    hl = __shfl(hl, 0, 64);
+    wave_sync();
+    for (int t = lane; t < hl; t += 64) dst[t] = hdr[t];
+    dst += hl;
+    const uint32_t ido = B.ids[2 * r], idl = B.ids[2 * r + 1];
+    for (uint32_t t = lane; t < idl; t += 64) dst[t] = B.idpool[ido + t];
+    dst += idl;
+    if (lane == 0) dst[0] = '\n';
+    dst += 1;
+    // splice: slices of the contigs / literals, substitutions applied before the strand flip, later ones win
+    const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+    for (uint32_t ii = 0; ii < ic; ii++) {
+        const Ivl iv = load_interval(B, R, ib + ii);
+        const uint32_t len = iv.len;
+        for (uint32_t t = lane; t < len; t += 64) {
+            const uint32_t src = iv.minus ? len - 1 - t : t;             // position in the slice
+            uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + iv.s + src]) : ref_base(R, iv.gbase + iv.s + src);
+            for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++)
+                if (B.mods[2ull * mi] == src) b = (uint8_t)B.mods[2ull * mi + 1];
+            dst[t] = iv.minus ? comp(b) : b;
+        }
+        dst += len;
+    }
+    if (lane == 0) dst[0] = '\n';
+    dst += 1;
+    if (P.fastq) {
+        if (lane == 0) { dst[0] = '+'; dst[1] = '\n'; }
+        dst += 2;
+        for (uint32_t t = lane; t < L; t += 64) dst[t] = (uint8_t)'K';
+        dst += L;
+        if (lane == 0) dst[0] = '\n';
+    }
+}
+
+// four 2-bit base codes (bits 0..7 of v) -> four ASCII bytes "ACGT"[code], first code in the low byte
+DEV uint32_t ascii4(uint32_t v) {
+    v &= 0xffu;
+    uint32_t t = (v | (v << 12)) & 0x000f000fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    const uint32_t b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u;
+    return 0x41414141u + 2u * b0 + 6u * b1 + 11u * (b0 & b1);     // A 0x41, C +2, G +6, T +2+6+11
+}
+
+__constant__ char PERFECT_TEXT[] = " length= error_free_length= read_identity=100.00% molecule_id=";
+constexpr int PT_LEN = 8, PT_EFL = 19, PT_REST = 35;
+constexpr int PERFECT_IMG = 8192;        // bytes of LDS per wave: records up to this size (minus alignment slack) are assembled there
+
+// --perfect records at memory speed.  A wave assembles its record as an image in LDS whose origin has the alignment of
+// the record's place in the output (mod 16), then copies it out in whole aligned 16-byte pieces: 1 KB per store
+// instruction, only the first and last piece of a record (shared with its neighbours) go out byte by byte.  The bases
+// come 16 at a time from the packed reference: two words, a funnel shift, for the minus strand a bit reversal and
+// complement, then four codes -> four ASCII bytes by byte-parallel arithmetic.  Literal segments and reference blocks that
+// hold other symbols than ACGT are copied bytewise; substitutions are written over the image afterwards, in order.
 __global__ __launch_bounds__(256) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
                                                   uint8_t* __restrict__ records) {
+    __shared__ __attribute__((aligned(16))) uint8_t img_all[WAVES_PER_WG][PERFECT_IMG + 32];
     __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* hdr = hdr_all[wave];
+    uint8_t* img = img_all[wave];
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_PER_WG;
     for (uint64_t r = (uint64_t)blockIdx.x * WAVES_PER_WG + wave; r < B.n_reads; r += n_waves) {
         const uint32_t L = O.raw_len[r];
-        int hl = 0;
-        wave_sync();
-        if (lane == 0) hl = format_header(hdr, P, P.first_read + r * P.stride, L, L, 1.0);
-        hl = __shfl(hl, 0, 64);
-        wave_sync();
-        uint8_t* dst = records + rec_off[r];
-        for (int t = lane; t < hl; t += 64) dst[t] = hdr[t];
-        dst += hl;
+        const uint64_t off = rec_off[r], rec_len = rec_off[r + 1] - off;
+        const int a = (int)(reinterpret_cast<uintptr_t>(records + off) & 15);
+        if (rec_len + (uint64_t)a > (uint64_t)PERFECT_IMG) { perfect_record_bytewise(B, R, P, r, L, hdr_all[wave], records + off, lane); continue; }
+        wave_sync();                                      // the previous record's image has been read
+        // ---- header (format_header, one character per lane), molecule id, newline
+        int nd = 1;
+        for (uint32_t v = L; v >= 10; v /= 10) nd++;
+        const int hl = 1 + 36 + PT_LEN + nd + PT_EFL + nd + PT_REST;
         const uint32_t ido = B.ids[2 * r], idl = B.ids[2 * r + 1];
-        for (uint32_t t = lane; t < idl; t += 64) dst[t] = B.idpool[ido + t];
-        dst += idl;
-        if (lane == 0) dst[0] = '\n';
-        dst += 1;
-        // splice: slices of the contigs / literals, substitutions applied before the strand flip, later ones win
+        {
+            const Ph4 id = philox(P.seed, P.first_read + r * P.stride, ST_ID, 0);
+            for (int t = lane; t < hl; t += 64) {
+                uint32_t ch;
+                if (t == 0) ch = P.fastq ? '@' : '>';
+                else if (t <= 36) {
+                    const int u = t - 1;
+                    if (u == 8 || u == 13 || u == 18 || u == 23) ch = '-';
+                    else {
+                        const int nb = u - (u > 8) - (u > 13) - (u > 18) - (u > 23);
+                        const uint32_t w = (nb >> 3) == 0 ? id.x : (nb >> 3) == 1 ? id.y : (nb >> 3) == 2 ? id.z : id.w;
+                        const uint32_t v = (w >> (4 * (7 - (nb & 7)))) & 15u;
+                        ch = v < 10 ? '0' + v : 'a' + v - 10;
+                    }
+                } else {
+                    int u = t - 37;
+                    int dg = -1;                           // >= 0: this position is digit dg (from the left) of L
+                    if (u < PT_LEN) ch = (uint8_t)PERFECT_TEXT[u];
+                    else if (u < PT_LEN + nd) { dg = u - PT_LEN; ch = 0; }
+                    else if (u < PT_LEN + nd + PT_EFL) ch = (uint8_t)PERFECT_TEXT[u - nd];
+                    else if (u < PT_LEN + nd + PT_EFL + nd) { dg = u - (PT_LEN + nd + PT_EFL); ch = 0; }
+                    else ch = (uint8_t)PERFECT_TEXT[u - 2 * nd];
+                    if (dg >= 0) {
+                        uint32_t v = L;
+                        for (int q = nd - 1 - dg; q > 0; q--) v /= 10;
+                        ch = '0' + v % 10;
+                    }
+                }
+                img[a + t] = (uint8_t)ch;
+            }
+            for (uint32_t t = lane; t < idl; t += 64) img[a + hl + t] = B.idpool[ido + t];
+            if (lane == 0) img[a + hl + idl] = '\n';
+        }
+        // ---- bases
+        uint8_t* bimg = img + a + hl + idl + 1;
         const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
+        uint32_t o = 0;
         for (uint32_t ii = 0; ii < ic; ii++) {
             const Ivl iv = load_interval(B, R, ib + ii);
             const uint32_t len = iv.len;
-            for (uint32_t t = lane; t < len; t += 64) {
-                const uint32_t src = iv.minus ? len - 1 - t : t;             // position in the slice
-                uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + iv.s + src]) : ref_base(R, iv.gbase + iv.s + src);
-                for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++)
-                    if (B.mods[2ull * mi] == src) b = (uint8_t)B.mods[2ull * mi + 1];
-                dst[t] = iv.minus ? comp(b) : b;
+            wave_sync();                                  // pieces of 16 may run over the end of the previous interval's bytes
+            for (uint32_t t0 = 16u * lane; t0 < len; t0 += 1024u) {
+                const uint32_t n = min(16u, len - t0);
+                // forward reference positions of this piece: [g0, g0 + n)
+                const uint64_t g0 = iv.gbase + iv.s + (iv.minus ? len - t0 - n : t0);
+                uint32_t d[4];
+                bool fast = !iv.literal;
+                if (fast) fast = R.blocktab[g0 >> BLOCK_SHIFT] == NO_BLOCK && R.blocktab[(g0 + n - 1) >> BLOCK_SHIFT] == NO_BLOCK;
+                if (fast) {
+                    const uint32_t w0 = R.packed[g0 >> 4], w1 = (g0 & 15) ? R.packed[(g0 >> 4) + 1] : 0u;
+                    uint32_t x = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> (2 * (g0 & 15)));      // n codes, first at bit 0
+                    if (iv.minus) {
+                        // last base first, complemented (complement = both bits inverted); the n codes sit at the top
+                        // after the reversal
+                        x = __builtin_bitreverse32(~x);
+                        x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+                        x >>= 2 * (16 - n);
+                    }
+                    d[0] = ascii4(x); d[1] = ascii4(x >> 8); d[2] = ascii4(x >> 16); d[3] = ascii4(x >> 24);
+                } else {
+                    d[0] = d[1] = d[2] = d[3] = 0u;
+                    for (uint32_t j = 0; j < n; j++) {
+                        const uint32_t src = iv.minus ? len - 1 - (t0 + j) : t0 + j;
+                        uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + iv.s + src]) : ref_base(R, iv.gbase + iv.s + src);
+                        b = iv.minus ? comp(b) : b;
+                        d[j >> 2] |= (uint32_t)b << (8 * (j & 3));
+                    }
+                }
+                __builtin_memcpy(bimg + o + t0, d, 16);
             }
-            dst += len;
+            if (iv.mod_end > iv.mod_begin) {
+                wave_sync();
+                if (lane == 0)
+                    for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++) {
+                        const uint32_t mp = B.mods[2ull * mi], mc = B.mods[2ull * mi + 1];
+                        if (mp < len) bimg[o + (iv.minus ? len - 1 - mp : mp)] = iv.minus ? comp((uint8_t)mc) : (uint8_t)mc;
+                    }
+            }
+            o += len;
         }
-        if (lane == 0) dst[0] = '\n';
-        dst += 1;
+        wave_sync();
+        // ---- separator and quality line
+        if (lane == 0) {
+            bimg[L] = '\n';
+            if (P.fastq) { bimg[L + 1] = '+'; bimg[L + 2] = '\n'; bimg[L + 3 + L] = '\n'; }
+        }
         if (P.fastq) {
-            if (lane == 0) { dst[0] = '+'; dst[1] = '\n'; }
-            dst += 2;
-            for (uint32_t t = lane; t < L; t += 64) dst[t] = (uint8_t)'K';
-            dst += L;
-            if (lane == 0) dst[0] = '\n';
+            uint8_t* kq = bimg + L + 3;
+            // whole words of 'K' between the unaligned ends
+            const uint32_t head = (uint32_t)((16 - ((uintptr_t)kq & 15)) & 15);
+            for (uint32_t t = lane; t < min(head, L); t += 64) kq[t] = 'K';
+            if (L > head) {
+                const uint32_t body = (L - head) & ~15u;
+                for (uint32_t t = 16u * lane; t < body; t += 1024u)
+                    *reinterpret_cast<uint4*>(kq + head + t) = make_uint4(0x4b4b4b4bu, 0x4b4b4b4bu, 0x4b4b4b4bu, 0x4b4b4b4bu);
+                for (uint32_t t = head + body + lane; t < L; t += 64) kq[t] = 'K';
+            }
+        }
+        wave_sync();
+        // ---- out: image bytes [a, a + rec_len) -> records[off ..)
+        uint8_t* gbase = records + (off - (uint64_t)a);
+        const uint32_t end = (uint32_t)a + (uint32_t)rec_len, n_pieces = (end + 15) >> 4;
+        for (uint32_t c = lane; c < n_pieces; c += 64) {
+            const uint4 v = *reinterpret_cast<const uint4*>(img + 16u * c);
+            const uint32_t lo = 16u * c, hi = lo + 16u;
+            if (lo >= (uint32_t)a && hi <= end) *reinterpret_cast<uint4*>(gbase + lo) = v;
+            else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++)
+                    if (lo + j >= (uint32_t)a && lo + j < end) gbase[lo + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+            }
         }
     }
 }
@@ -2313,7 +2459,7 @@ hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams&
                           int n_cus, hipStream_t s) {
     if (!b.n_reads) return hipSuccess;
     const uint64_t want = (b.n_reads + WAVES_PER_WG - 1) / WAVES_PER_WG;
-    hipLaunchKernelGGL(k_perfect, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)n_cus * 8)), dim3(64 * WAVES_PER_WG), 0, s, b, r, p, o, rec_off, records);
+    hipLaunchKernelGGL(k_perfect, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)n_cus * 4)), dim3(64 * WAVES_PER_WG), 0, s, b, r, p, o, rec_off, records);   // 4 workgroups of 33 KB LDS per CU
     return hipGetLastError();
 }
 hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank, uint64_t n_total,
