@@ -1049,7 +1049,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->w_records.ensure(total + 64));
         records = ctx->w_records.as<uint8_t>();
     }
-    if (direct) HIPCHK(ctx, tk::launch_perfect(B, R, P, O, ctx->w_recoff.as<uint64_t>(), records, ctx->n_cus, s));
+    if (direct) HIPCHK(ctx, tk::launch_perfect(B, R, P, O, ctx->w_recoff.as<uint64_t>(), records, b->max_raw, ctx->n_cus, s));
     else HIPCHK(ctx, tk::launch_emit(B, P, O, ctx->w_recoff.as<uint64_t>(), records, s));
     if (T) {
         HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));

@@ -189,8 +189,8 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, hipStream_t s);
 hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s);
-hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off,
-                          uint8_t* records, int n_cus, hipStream_t s);
+hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,
+                          uint32_t max_raw, int n_cus, hipStream_t s);
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off,
                        uint8_t* records, hipStream_t s);
 hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank,

@@ -2150,32 +2150,56 @@ DEV uint32_t ascii4(uint32_t v) {
 
 __constant__ char PERFECT_TEXT[] = " length= error_free_length= read_identity=100.00% molecule_id=";
 constexpr int PT_LEN = 8, PT_EFL = 19, PT_REST = 35;
-constexpr int PERFECT_IMG = 8192;        // bytes of LDS per wave: records up to this size (minus alignment slack) are assembled there
+constexpr int PERFECT_IMG_MAX = 8192;    // largest LDS image of a record (bytes); longer records are written bytewise
+constexpr int PERFECT_IVLS = 32;         // intervals of a read held in the wave's LDS table; reads with more are written bytewise
+struct PIvl { unsigned long long g; uint32_t len, o, pc, flags, mod_begin, mod_end; };   // flags: bit 0 literal, bit 1 minus
+int perfect_lds_bytes(int img_bytes) { return WAVES_PER_WG * (img_bytes + 32 + PERFECT_IVLS * (int)sizeof(PIvl) + 160); }
 
 // --perfect records at memory speed.  A wave assembles its record as an image in LDS whose origin has the alignment of
 // the record's place in the output (mod 16), then copies it out in whole aligned 16-byte pieces: 1 KB per store
-// instruction, only the first and last piece of a record (shared with its neighbours) go out byte by byte.  The bases
-// come 16 at a time from the packed reference: two words, a funnel shift, for the minus strand a bit reversal and
+// instruction, only the first and last piece of a record (shared with its neighbours) go out byte by byte.  The read's
+// intervals are loaded by one lane each; then every lane takes pieces of 16 bases of any interval, so that all reference
+// reads of a record are in flight together: two packed words, a funnel shift, for the minus strand a bit reversal and
 // complement, then four codes -> four ASCII bytes by byte-parallel arithmetic.  Literal segments and reference blocks that
 // hold other symbols than ACGT are copied bytewise; substitutions are written over the image afterwards, in order.
-__global__ __launch_bounds__(256) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
-                                                  uint8_t* __restrict__ records) {
-    __shared__ __attribute__((aligned(16))) uint8_t img_all[WAVES_PER_WG][PERFECT_IMG + 32];
-    __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
+__global__ __launch_bounds__(256, 6) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
+                                                     uint8_t* __restrict__ records, int img_bytes) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* img = img_all[wave];
+    const int per_wave = img_bytes + 32 + PERFECT_IVLS * (int)sizeof(PIvl) + 160;
+    uint8_t* img = lds_raw + (size_t)wave * per_wave;
+    PIvl* tab = reinterpret_cast<PIvl*>(img + img_bytes + 32);
+    uint8_t* hdr = img + img_bytes + 32 + PERFECT_IVLS * sizeof(PIvl);
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_PER_WG;
     for (uint64_t r = (uint64_t)blockIdx.x * WAVES_PER_WG + wave; r < B.n_reads; r += n_waves) {
         const uint32_t L = O.raw_len[r];
         const uint64_t off = rec_off[r], rec_len = rec_off[r + 1] - off;
-        const int a = (int)(reinterpret_cast<uintptr_t>(records + off) & 15);
-        if (rec_len + (uint64_t)a > (uint64_t)PERFECT_IMG) { perfect_record_bytewise(B, R, P, r, L, hdr_all[wave], records + off, lane); continue; }
-        wave_sync();                                      // the previous record's image has been read
-        // ---- header (format_header, one character per lane), molecule id, newline
-        int nd = 1;
-        for (uint32_t v = L; v >= 10; v /= 10) nd++;
-        const int hl = 1 + 36 + PT_LEN + nd + PT_EFL + nd + PT_REST;
+        const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
         const uint32_t ido = B.ids[2 * r], idl = B.ids[2 * r + 1];
+        const int a = (int)(reinterpret_cast<uintptr_t>(records + off) & 15);
+        if (rec_len + (uint64_t)a > (uint64_t)img_bytes || ic > (uint32_t)PERFECT_IVLS) {
+            perfect_record_bytewise(B, R, P, r, L, hdr, records + off, lane);
+            continue;
+        }
+        wave_sync();                                      // the previous record's image and table have been read
+        // ---- the read's intervals, one per lane: offsets of their bases and of their 16-base pieces
+        uint32_t total_pieces;
+        {
+            Ivl iv{}; uint32_t len_i = 0, np_i = 0;
+            if ((uint32_t)lane < ic) { iv = load_interval(B, R, ib + lane); len_i = iv.len; np_i = (len_i + 15) >> 4; }
+            const uint32_t o_incl = (uint32_t)scan_add_incl((int)len_i, lane), pc_incl = (uint32_t)scan_add_incl((int)np_i, lane);
+            total_pieces = (uint32_t)__shfl((int)pc_incl, 63, 64);
+            if ((uint32_t)lane < ic) {
+                PIvl e;
+                e.g = iv.gbase + iv.s; e.len = len_i; e.o = o_incl - len_i; e.pc = pc_incl - np_i;
+                e.flags = (iv.literal ? 1u : 0u) | (iv.minus ? 2u : 0u); e.mod_begin = iv.mod_begin; e.mod_end = iv.mod_end;
+                tab[lane] = e;
+            }
+        }
+        // ---- header (format_header, one character per lane), molecule id, newline
+        // the digits of L, first one in the low byte (a record that fits the image has at most 4)
+        int nd = 0; uint32_t dpack = 0;
+        for (uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)L);; v /= 10) { dpack = (dpack << 8) | ('0' + v % 10); nd++; if (v < 10) break; }
+        const int hl = 1 + 36 + PT_LEN + nd + PT_EFL + nd + PT_REST;
         {
             const Ph4 id = philox(P.seed, P.first_read + r * P.stride, ST_ID, 0);
             for (int t = lane; t < hl; t += 64) {
@@ -2191,72 +2215,67 @@ __global__ __launch_bounds__(256) void k_perfect(BatchView B, RefView R, SimPara
                         ch = v < 10 ? '0' + v : 'a' + v - 10;
                     }
                 } else {
-                    int u = t - 37;
+                    const int u = t - 37;
                     int dg = -1;                           // >= 0: this position is digit dg (from the left) of L
                     if (u < PT_LEN) ch = (uint8_t)PERFECT_TEXT[u];
                     else if (u < PT_LEN + nd) { dg = u - PT_LEN; ch = 0; }
                     else if (u < PT_LEN + nd + PT_EFL) ch = (uint8_t)PERFECT_TEXT[u - nd];
                     else if (u < PT_LEN + nd + PT_EFL + nd) { dg = u - (PT_LEN + nd + PT_EFL); ch = 0; }
                     else ch = (uint8_t)PERFECT_TEXT[u - 2 * nd];
-                    if (dg >= 0) {
-                        uint32_t v = L;
-                        for (int q = nd - 1 - dg; q > 0; q--) v /= 10;
-                        ch = '0' + v % 10;
-                    }
+                    if (dg >= 0) ch = (dpack >> (8 * dg)) & 255u;
                 }
                 img[a + t] = (uint8_t)ch;
             }
             for (uint32_t t = lane; t < idl; t += 64) img[a + hl + t] = B.idpool[ido + t];
             if (lane == 0) img[a + hl + idl] = '\n';
         }
-        // ---- bases
+        wave_sync();
+        // ---- bases: piece w of the read = piece w - pc of the last interval whose first piece is <= w
         uint8_t* bimg = img + a + hl + idl + 1;
-        const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
-        uint32_t o = 0;
-        for (uint32_t ii = 0; ii < ic; ii++) {
-            const Ivl iv = load_interval(B, R, ib + ii);
-            const uint32_t len = iv.len;
-            wave_sync();                                  // pieces of 16 may run over the end of the previous interval's bytes
-            for (uint32_t t0 = 16u * lane; t0 < len; t0 += 1024u) {
-                const uint32_t n = min(16u, len - t0);
-                // forward reference positions of this piece: [g0, g0 + n)
-                const uint64_t g0 = iv.gbase + iv.s + (iv.minus ? len - t0 - n : t0);
-                uint32_t d[4];
-                bool fast = !iv.literal;
-                if (fast) fast = R.blocktab[g0 >> BLOCK_SHIFT] == NO_BLOCK && R.blocktab[(g0 + n - 1) >> BLOCK_SHIFT] == NO_BLOCK;
-                if (fast) {
-                    const uint32_t w0 = R.packed[g0 >> 4], w1 = (g0 & 15) ? R.packed[(g0 >> 4) + 1] : 0u;
-                    uint32_t x = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> (2 * (g0 & 15)));      // n codes, first at bit 0
-                    if (iv.minus) {
-                        // last base first, complemented (complement = both bits inverted); the n codes sit at the top
-                        // after the reversal
-                        x = __builtin_bitreverse32(~x);
-                        x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-                        x >>= 2 * (16 - n);
-                    }
-                    d[0] = ascii4(x); d[1] = ascii4(x >> 8); d[2] = ascii4(x >> 16); d[3] = ascii4(x >> 24);
-                } else {
-                    d[0] = d[1] = d[2] = d[3] = 0u;
-                    for (uint32_t j = 0; j < n; j++) {
-                        const uint32_t src = iv.minus ? len - 1 - (t0 + j) : t0 + j;
-                        uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + iv.s + src]) : ref_base(R, iv.gbase + iv.s + src);
-                        b = iv.minus ? comp(b) : b;
-                        d[j >> 2] |= (uint32_t)b << (8 * (j & 3));
-                    }
+        for (uint32_t w = lane; w < total_pieces; w += 64) {
+            uint32_t i = 0;
+            for (uint32_t q = 1; q < ic; q++) i += tab[q].pc <= w ? 1u : 0u;
+            const PIvl e = tab[i];
+            const bool literal = e.flags & 1u, minus = e.flags & 2u;
+            const uint32_t len = e.len, t0 = 16u * (w - e.pc), n = min(16u, len - t0);
+            const uint64_t g0 = e.g + (minus ? len - t0 - n : t0);          // forward positions [g0, g0 + n)
+            uint32_t d[4];
+            bool fast = false;
+            if (!literal) {
+                const uint32_t bt0 = R.blocktab[g0 >> BLOCK_SHIFT], bt1 = R.blocktab[(g0 + n - 1) >> BLOCK_SHIFT];
+                const uint32_t w0 = R.packed[g0 >> 4], w1 = R.packed[(g0 >> 4) + 1];      // (the buffer has a spare line at its end)
+                fast = bt0 == NO_BLOCK && bt1 == NO_BLOCK;
+                uint32_t x = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> (2 * (g0 & 15)));          // n codes, first at bit 0
+                if (minus) {
+                    // last base first, complemented (= both bits inverted); after the reversal the n codes sit at the top
+                    x = __builtin_bitreverse32(~x);
+                    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+                    x >>= 2 * (16 - n);
                 }
-                __builtin_memcpy(bimg + o + t0, d, 16);
+                d[0] = ascii4(x); d[1] = ascii4(x >> 8); d[2] = ascii4(x >> 16); d[3] = ascii4(x >> 24);
             }
-            if (iv.mod_end > iv.mod_begin) {
-                wave_sync();
-                if (lane == 0)
-                    for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++) {
-                        const uint32_t mp = B.mods[2ull * mi], mc = B.mods[2ull * mi + 1];
-                        if (mp < len) bimg[o + (iv.minus ? len - 1 - mp : mp)] = iv.minus ? comp((uint8_t)mc) : (uint8_t)mc;
-                    }
+            if (!fast) {
+                d[0] = d[1] = d[2] = d[3] = 0u;
+                for (uint32_t j = 0; j < n; j++) {
+                    const uint32_t src = minus ? len - 1 - (t0 + j) : t0 + j;
+                    uint8_t b = literal ? upper(B.litpool[e.g + src]) : ref_base(R, e.g + src);
+                    b = minus ? comp(b) : b;
+                    d[j >> 2] |= (uint32_t)b << (8 * (j & 3));
+                }
             }
-            o += len;
+            uint8_t* dstp = bimg + e.o + t0;
+            if (n == 16) __builtin_memcpy(dstp, d, 16);
+            else for (uint32_t j = 0; j < n; j++) dstp[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));     // never past the interval: its neighbour is written in the same pass
         }
         wave_sync();
+        // ---- substitutions: before the strand flip, later entries win (py/sequence.py:229-239); one lane per interval
+        if ((uint32_t)lane < ic) {
+            const PIvl e = tab[lane];
+            for (uint32_t mi = e.mod_begin; mi < e.mod_end; mi++) {
+                const uint32_t mp = B.mods[2ull * mi], mc = B.mods[2ull * mi + 1];
+                if (mp < e.len) bimg[e.o + ((e.flags & 2u) ? e.len - 1 - mp : mp)] = (e.flags & 2u) ? comp((uint8_t)mc) : (uint8_t)mc;
+            }
+        }
         // ---- separator and quality line
         if (lane == 0) {
             bimg[L] = '\n';
@@ -2265,7 +2284,7 @@ __global__ __launch_bounds__(256) void k_perfect(BatchView B, RefView R, SimPara
         if (P.fastq) {
             uint8_t* kq = bimg + L + 3;
             // whole words of 'K' between the unaligned ends
-            const uint32_t head = (uint32_t)((16 - ((uintptr_t)kq & 15)) & 15);
+            const uint32_t head = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(kq) & 15)) & 15);
             for (uint32_t t = lane; t < min(head, L); t += 64) kq[t] = 'K';
             if (L > head) {
                 const uint32_t body = (L - head) & ~15u;
@@ -2276,18 +2295,14 @@ __global__ __launch_bounds__(256) void k_perfect(BatchView B, RefView R, SimPara
         }
         wave_sync();
         // ---- out: image bytes [a, a + rec_len) -> records[off ..)
-        uint8_t* gbase = records + (off - (uint64_t)a);
-        const uint32_t end = (uint32_t)a + (uint32_t)rec_len, n_pieces = (end + 15) >> 4;
-        for (uint32_t c = lane; c < n_pieces; c += 64) {
-            const uint4 v = *reinterpret_cast<const uint4*>(img + 16u * c);
-            const uint32_t lo = 16u * c, hi = lo + 16u;
-            if (lo >= (uint32_t)a && hi <= end) *reinterpret_cast<uint4*>(gbase + lo) = v;
-            else {
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (uint32_t j = 0; j < 16; j++)
-                    if (lo + j >= (uint32_t)a && lo + j < end) gbase[lo + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
-            }
+        uint8_t* gout = records + off - a;
+        const uint32_t end = (uint32_t)a + (uint32_t)rec_len;
+        const uint32_t c0 = a ? 1u : 0u, c1 = end >> 4;          // whole pieces: [c0, c1)
+        for (uint32_t c = c0 + lane; c < c1; c += 64) *reinterpret_cast<uint4*>(gout + 16u * c) = *reinterpret_cast<const uint4*>(img + 16u * c);
+        // the pieces shared with the neighbouring records: lane 0 the first one, lane 1 the last one
+        if (lane < 2) {
+            const uint32_t lo = lane == 0 ? (uint32_t)a : max(16u * c1, (uint32_t)a), hi = lane == 0 ? (a ? min(16u, end) : 0u) : end;
+            for (uint32_t t = lo; t < hi; t++) gout[t] = img[t];
         }
     }
 }
@@ -2456,10 +2471,21 @@ hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const Si
     return hipGetLastError();
 }
 hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,
-                          int n_cus, hipStream_t s) {
+                          uint32_t max_raw, int n_cus, hipStream_t s) {
     if (!b.n_reads) return hipSuccess;
+    // LDS image per wave: sized for the batch's longest record (header and id: a few hundred bytes), 8 KB at most
+    const int img_bytes = (int)std::min<uint64_t>(PERFECT_IMG_MAX, ((p.fastq ? 2ull : 1ull) * max_raw + 512 + 255) & ~255ull);
+    const int lds = perfect_lds_bytes(img_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_perfect), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    // a persistent grid: exactly the workgroups that are resident at once (registers and LDS decide)
+    int wgs_per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void*>(k_perfect), 64 * WAVES_PER_WG, (size_t)lds);
+    if (e != hipSuccess) return e;
+    wgs_per_cu = std::max(1, wgs_per_cu);
     const uint64_t want = (b.n_reads + WAVES_PER_WG - 1) / WAVES_PER_WG;
-    hipLaunchKernelGGL(k_perfect, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)n_cus * 4)), dim3(64 * WAVES_PER_WG), 0, s, b, r, p, o, rec_off, records);   // 4 workgroups of 33 KB LDS per CU
+    hipLaunchKernelGGL(k_perfect, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)n_cus * wgs_per_cu)), dim3(64 * WAVES_PER_WG), lds, s, b, r, p, o,
+                       rec_off, records, img_bytes);
     return hipGetLastError();
 }
 hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank, uint64_t n_total,
