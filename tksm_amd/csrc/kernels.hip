@@ -2162,7 +2162,10 @@ int perfect_lds_bytes(int img_bytes) { return WAVES_PER_WG * (img_bytes + 32 + P
 // reads of a record are in flight together: two packed words, a funnel shift, for the minus strand a bit reversal and
 // complement, then four codes -> four ASCII bytes by byte-parallel arithmetic.  Literal segments and reference blocks that
 // hold other symbols than ACGT are copied bytewise; substitutions are written over the image afterwards, in order.
-__global__ __launch_bounds__(256, 6) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
+#ifndef PERFECT_WAVES
+#define PERFECT_WAVES 6
+#endif
+__global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
                                                      uint8_t* __restrict__ records, int img_bytes) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_wave = img_bytes + 32 + PERFECT_IVLS * (int)sizeof(PIvl) + 160;
@@ -2254,18 +2257,22 @@ __global__ __launch_bounds__(256, 6) void k_perfect(BatchView B, RefView R, SimP
                 }
                 d[0] = ascii4(x); d[1] = ascii4(x >> 8); d[2] = ascii4(x >> 16); d[3] = ascii4(x >> 24);
             }
+            uint8_t* dstp = bimg + e.o + t0;
             if (!fast) {
-                d[0] = d[1] = d[2] = d[3] = 0u;
                 for (uint32_t j = 0; j < n; j++) {
                     const uint32_t src = minus ? len - 1 - (t0 + j) : t0 + j;
-                    uint8_t b = literal ? upper(B.litpool[e.g + src]) : ref_base(R, e.g + src);
-                    b = minus ? comp(b) : b;
-                    d[j >> 2] |= (uint32_t)b << (8 * (j & 3));
+                    const uint8_t b = literal ? upper(B.litpool[e.g + src]) : ref_base(R, e.g + src);
+                    dstp[j] = minus ? comp(b) : b;
+                }
+            } else if (n == 16) __builtin_memcpy(dstp, d, 16);
+            else {
+                // never past the interval: its neighbour is written in the same pass
+                unsigned long long lo8 = ((unsigned long long)d[1] << 32) | d[0], hi8 = ((unsigned long long)d[3] << 32) | d[2];
+                for (uint32_t j = 0; j < n; j++) {
+                    dstp[j] = (uint8_t)lo8;
+                    lo8 = (lo8 >> 8) | (hi8 << 56); hi8 >>= 8;
                 }
             }
-            uint8_t* dstp = bimg + e.o + t0;
-            if (n == 16) __builtin_memcpy(dstp, d, 16);
-            else for (uint32_t j = 0; j < n; j++) dstp[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));     // never past the interval: its neighbour is written in the same pass
         }
         wave_sync();
         // ---- substitutions: before the strand flip, later entries win (py/sequence.py:229-239); one lane per interval
