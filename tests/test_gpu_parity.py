@@ -422,10 +422,11 @@ def test_clone_shares_reference_and_models_across_threads(oracle_models):
     s.close()
 
 
-@pytest.mark.parametrize("kind", ["bulk", "scrna"])
+@pytest.mark.parametrize("kind", ["bulk", "scrna", "long"])
 def test_perfect_direct_kernel_equals_wave_wide_kernel(monkeypatch, kind):
     """--perfect: the direct kernel (packed reference -> records) and the wave-wide kernel (splice into LDS, emit) write
-    the same bytes for 65 536 synthetic molecules (both strands, substitutions, literals, N / IUPAC / lower-case blocks)."""
+    the same bytes for 65 536 synthetic molecules (both strands, substitutions, literals, N / IUPAC / lower-case blocks).
+    "long": skewed lengths up to 16 kb -- records beyond the first launch's LDS images go to the second launch."""
     from tksm_amd import synthetic
     from tksm_amd.sequence import Sequencer
     rs = np.random.RandomState(3)
@@ -437,7 +438,11 @@ def test_perfect_direct_kernel_equals_wave_wide_kernel(monkeypatch, kind):
             p = int(rs.randint(0, n - 500))
             seq[p:p + int(rs.randint(1, 400))] = b"N" * 400 if rs.rand() < 0.5 else b"RYKM" * 100
         contigs.append(bytes(seq[:n]))
-    m = synthetic.make_molecules(rs, lens, 65536, 700, 200, kind=kind)
+    if kind == "long":
+        m = synthetic.make_molecules(rs, lens, 8192, 2500, 500, lognormal_sigma=0.8)
+        assert (m["raw_len"] > 4000).sum() > 1000 and m["raw_len"].max() > 12000
+    else:
+        m = synthetic.make_molecules(rs, lens, 65536, 700, 200, kind=kind)
     out = {}
     for mode in ("direct", "wave"):
         monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if mode == "wave" else "0")

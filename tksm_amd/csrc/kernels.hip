@@ -2150,7 +2150,8 @@ DEV uint32_t ascii4(uint32_t v) {
 
 __constant__ char PERFECT_TEXT[] = " length= error_free_length= read_identity=100.00% molecule_id=";
 constexpr int PT_LEN = 8, PT_EFL = 19, PT_REST = 35;
-constexpr int PERFECT_IMG_MAX = 8192;    // largest LDS image of a record (bytes); longer records are written bytewise
+constexpr int PERFECT_IMG_MAX = 8192;    // largest LDS image of a record (bytes) in the first launch
+constexpr int PERFECT_IMG_LONG = 36864;  // ... and in the second one, for the long records of a batch; longer ones are written bytewise
 constexpr int PERFECT_IVLS = 32;         // intervals of a read held in the wave's LDS table; reads with more are written bytewise
 struct PIvl { unsigned long long g; uint32_t len, o, pc, flags, mod_begin, mod_end; };   // flags: bit 0 literal, bit 1 minus
 int perfect_lds_bytes(int img_bytes) { return WAVES_PER_WG * (img_bytes + 32 + PERFECT_IVLS * (int)sizeof(PIvl) + 160); }
@@ -2166,7 +2167,7 @@ int perfect_lds_bytes(int img_bytes) { return WAVES_PER_WG * (img_bytes + 32 + P
 #define PERFECT_WAVES 6
 #endif
 __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
-                                                     uint8_t* __restrict__ records, int img_bytes) {
+                                                     uint8_t* __restrict__ records, int img_bytes, int skip_below, int last) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_wave = img_bytes + 32 + PERFECT_IVLS * (int)sizeof(PIvl) + 160;
     uint8_t* img = lds_raw + (size_t)wave * per_wave;
@@ -2179,8 +2180,12 @@ __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, Ref
         const uint32_t ib = B.reads[2 * r], ic = B.reads[2 * r + 1];
         const uint32_t ido = B.ids[2 * r], idl = B.ids[2 * r + 1];
         const int a = (int)(reinterpret_cast<uintptr_t>(records + off) & 15);
-        if (rec_len + (uint64_t)a > (uint64_t)img_bytes || ic > (uint32_t)PERFECT_IVLS) {
-            perfect_record_bytewise(B, R, P, r, L, hdr, records + off, lane);
+        // a batch with long records is written by two launches: the first one with small images (many waves per CU)
+        // leaves the records that do not fit to the second one with large images
+        const bool few = ic <= (uint32_t)PERFECT_IVLS;
+        if (few && rec_len + (uint64_t)a <= (uint64_t)skip_below) continue;
+        if (!few || rec_len + (uint64_t)a > (uint64_t)img_bytes) {
+            if (last) perfect_record_bytewise(B, R, P, r, L, hdr, records + off, lane);
             continue;
         }
         wave_sync();                                      // the previous record's image and table have been read
@@ -2199,8 +2204,8 @@ __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, Ref
             }
         }
         // ---- header (format_header, one character per lane), molecule id, newline
-        // the digits of L, first one in the low byte (a record that fits the image has at most 4)
-        int nd = 0; uint32_t dpack = 0;
+        // the digits of L, first one in the low byte (a record that fits an image has at most 5)
+        int nd = 0; unsigned long long dpack = 0;
         for (uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)L);; v /= 10) { dpack = (dpack << 8) | ('0' + v % 10); nd++; if (v < 10) break; }
         const int hl = 1 + 36 + PT_LEN + nd + PT_EFL + nd + PT_REST;
         {
@@ -2225,7 +2230,7 @@ __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, Ref
                     else if (u < PT_LEN + nd + PT_EFL) ch = (uint8_t)PERFECT_TEXT[u - nd];
                     else if (u < PT_LEN + nd + PT_EFL + nd) { dg = u - (PT_LEN + nd + PT_EFL); ch = 0; }
                     else ch = (uint8_t)PERFECT_TEXT[u - 2 * nd];
-                    if (dg >= 0) ch = (dpack >> (8 * dg)) & 255u;
+                    if (dg >= 0) ch = (uint32_t)(dpack >> (8 * dg)) & 255u;
                 }
                 img[a + t] = (uint8_t)ch;
             }
@@ -2480,20 +2485,26 @@ hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const Si
 hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,
                           uint32_t max_raw, int n_cus, hipStream_t s) {
     if (!b.n_reads) return hipSuccess;
-    // LDS image per wave: sized for the batch's longest record (header and id: a few hundred bytes), 8 KB at most
-    const int img_bytes = (int)std::min<uint64_t>(PERFECT_IMG_MAX, ((p.fastq ? 2ull : 1ull) * max_raw + 512 + 255) & ~255ull);
-    const int lds = perfect_lds_bytes(img_bytes);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_perfect), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    // a persistent grid: exactly the workgroups that are resident at once (registers and LDS decide)
-    int wgs_per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void*>(k_perfect), 64 * WAVES_PER_WG, (size_t)lds);
-    if (e != hipSuccess) return e;
-    wgs_per_cu = std::max(1, wgs_per_cu);
-    const uint64_t want = (b.n_reads + WAVES_PER_WG - 1) / WAVES_PER_WG;
-    hipLaunchKernelGGL(k_perfect, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)n_cus * wgs_per_cu)), dim3(64 * WAVES_PER_WG), lds, s, b, r, p, o,
-                       rec_off, records, img_bytes);
-    return hipGetLastError();
+    // LDS image per wave: sized for the batch's longest record (header and id: a few hundred bytes), 8 KB at most in the
+    // first launch; longer records get a second launch with images up to 36 KB (one workgroup per CU)
+    const uint64_t need = ((p.fastq ? 2ull : 1ull) * max_raw + 512 + 255) & ~255ull;
+    const int img[2] = {(int)std::min<uint64_t>(PERFECT_IMG_MAX, need), (int)std::min<uint64_t>(PERFECT_IMG_LONG, need)};
+    const int n_launch = need > (uint64_t)PERFECT_IMG_MAX ? 2 : 1;
+    for (int k = 0; k < n_launch; k++) {
+        const int lds = perfect_lds_bytes(img[k]);
+        // a persistent grid: exactly the workgroups that are resident at once (registers and LDS decide)
+        int wgs_per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void*>(k_perfect), 64 * WAVES_PER_WG, (size_t)lds);
+        if (e != hipSuccess) return e;
+        wgs_per_cu = std::max(1, wgs_per_cu);
+        const uint64_t want = (b.n_reads + WAVES_PER_WG - 1) / WAVES_PER_WG;
+        hipLaunchKernelGGL(k_perfect, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)n_cus * wgs_per_cu)), dim3(64 * WAVES_PER_WG), lds, s, b, r, p, o,
+                           rec_off, records, img[k], k ? img[0] : 0, k == n_launch - 1 ? 1 : 0);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 hipError_t launch_interleave_lens(int n_ranks, const uint64_t* const* offsets, const uint64_t* n_per_rank, uint64_t n_total,
                                   uint64_t* lens, hipStream_t s) {
