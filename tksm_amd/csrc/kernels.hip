@@ -1616,14 +1616,16 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
     for (int q = 0; q < 4; q++) mjq[q] = __shfl(act ? m : 0, q * 16 + (lane >> 2), 64);
     // Job records travel in groups of 4 (32 columns, one 64-byte line per job): whole lines are loaded by 4 threads
     // per job one group ahead and handed to the owning lanes through LDS
-    uint4 rg[4];
+    // (four named registers, not an array: the array was kept in scratch memory, which also made every group load wait)
+    uint4 rg0, rg1, rg2, rg3;
+    const uint4* jrow = J.jc0 + (size_t)(lane >> 2) * J.cw + (lane & 3);
+    const size_t jq = (size_t)16 * J.cw;
     auto load_group = [&](int g) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) rg[q] = J.jc0[(size_t)(q * 16 + (lane >> 2)) * J.cw + 4 * g + (lane & 3)];
+        rg0 = jrow[4 * g]; rg1 = jrow[jq + 4 * g]; rg2 = jrow[2 * jq + 4 * g]; rg3 = jrow[3 * jq + 4 * g];
     };
     auto stage_group = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; q++) rec_lds[(lane & 3) * 64 + q * 16 + (lane >> 2)] = rg[q];
+        uint4* d = rec_lds + (lane & 3) * 64 + (lane >> 2);
+        d[0] = rg0; d[16] = rg1; d[32] = rg2; d[48] = rg3;
     };
     load_group(0); stage_group(); wave_sync();
     for (int c0 = 0; c0 < mmax; c0 += 32) {
