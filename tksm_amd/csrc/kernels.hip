@@ -197,6 +197,53 @@ DEV Ivl load_interval(const BatchView& B, const RefView& R, uint32_t idx) {
     return iv;
 }
 
+// four 2-bit base codes (bits 0..7 of v) -> four ASCII bytes "ACGT"[code], first code in the low byte
+DEV uint32_t ascii4(uint32_t v) {
+    v &= 0xffu;
+    uint32_t t = (v | (v << 12)) & 0x000f000fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    const uint32_t b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u;
+    return 0x41414141u + 2u * b0 + 6u * b1 + 11u * (b0 & b1);     // A 0x41, C +2, G +6, T +2+6+11
+}
+
+// 16 bases (fewer at the end) of one interval, in output order: piece t0 of the slice that starts at forward position g.
+// From the packed reference: two words, a funnel shift, for the minus strand a bit reversal + complement (= both bits
+// inverted), four codes -> four ASCII bytes at a time.  Literal segments and reference blocks that hold other symbols
+// than ACGT: bytewise.  Writes exactly the piece's bytes (a neighbouring interval may be written in the same pass).
+DEV void splice_piece(const BatchView& B, const RefView& R, uint64_t g, uint32_t len, bool literal, bool minus, uint32_t t0, uint8_t* dstp) {
+    const uint32_t n = min(16u, len - t0);
+    const uint64_t g0 = g + (minus ? len - t0 - n : t0);              // forward positions [g0, g0 + n)
+    uint32_t d[4];
+    bool fast = false;
+    if (!literal) {
+        const uint32_t bt0 = R.blocktab[g0 >> BLOCK_SHIFT], bt1 = R.blocktab[(g0 + n - 1) >> BLOCK_SHIFT];
+        const uint32_t w0 = R.packed[g0 >> 4], w1 = R.packed[(g0 >> 4) + 1];      // (the buffer has a spare line at its end)
+        fast = bt0 == NO_BLOCK && bt1 == NO_BLOCK;
+        uint32_t x = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> (2 * (g0 & 15)));          // n codes, first at bit 0
+        if (minus) {
+            // last base first; after the reversal the n codes sit at the top
+            x = __builtin_bitreverse32(~x);
+            x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+            x >>= 2 * (16 - n);
+        }
+        d[0] = ascii4(x); d[1] = ascii4(x >> 8); d[2] = ascii4(x >> 16); d[3] = ascii4(x >> 24);
+    }
+    if (!fast) {
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t src = minus ? len - 1 - (t0 + j) : t0 + j;
+            const uint8_t b = literal ? upper(B.litpool[g + src]) : ref_base(R, g + src);
+            dstp[j] = minus ? comp(b) : b;
+        }
+    } else if (n == 16) __builtin_memcpy(dstp, d, 16);
+    else {
+        unsigned long long lo8 = ((unsigned long long)d[1] << 32) | d[0], hi8 = ((unsigned long long)d[3] << 32) | d[2];
+        for (uint32_t j = 0; j < n; j++) {
+            dstp[j] = (uint8_t)lo8;
+            lo8 = (lo8 >> 8) | (hi8 << 56); hi8 >>= 8;
+        }
+    }
+}
+
 // tail noise length of one read (KDE_noise_generator.noise_seq / Custom2Dist.__call__ / CustomDist.__call__,
 // py/tksm_badread.py:919-926, :1023-1033, :988-991): nothing with probability 1 - ratio; else the row of the first label
 // >= the fragment length (past the last label: the last row and the factor len(ly) / ly[-1], as the reference has it),
@@ -874,11 +921,8 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
         for (uint32_t ii = 0; ii < ic; ii++) {
             const Ivl iv = load_interval(B, R, ib + ii);
             const int len = (int)iv.len;
-            for (int t = lane; t < len; t += 64) {
-                const uint32_t src = iv.minus ? iv.s + (uint32_t)(len - 1 - t) : iv.s + (uint32_t)t;
-                uint8_t b = iv.literal ? upper(B.litpool[iv.gbase + src]) : ref_base(R, iv.gbase + src);
-                frag[o + t] = iv.minus ? comp(b) : b;
-            }
+            for (uint32_t t0 = 16u * lane; t0 < (uint32_t)len; t0 += 1024u)
+                splice_piece(B, R, iv.gbase + iv.s, (uint32_t)len, iv.literal, iv.minus, t0, frag + o + t0);
             wave_sync();
             for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++) {
                 const uint32_t mp = B.mods[2ull * mi], mc = B.mods[2ull * mi + 1];
@@ -2141,15 +2185,6 @@ DEV void perfect_record_bytewise(const BatchView& B, const RefView& R, const Sim
     }
 }
 
-// four 2-bit base codes (bits 0..7 of v) -> four ASCII bytes "ACGT"[code], first code in the low byte
-DEV uint32_t ascii4(uint32_t v) {
-    v &= 0xffu;
-    uint32_t t = (v | (v << 12)) & 0x000f000fu;
-    t = (t | (t << 6)) & 0x03030303u;
-    const uint32_t b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u;
-    return 0x41414141u + 2u * b0 + 6u * b1 + 11u * (b0 & b1);     // A 0x41, C +2, G +6, T +2+6+11
-}
-
 __constant__ char PERFECT_TEXT[] = " length= error_free_length= read_identity=100.00% molecule_id=";
 constexpr int PT_LEN = 8, PT_EFL = 19, PT_REST = 35;
 constexpr int PERFECT_IMG_MAX = 8192;    // largest LDS image of a record (bytes) in the first launch
@@ -2246,40 +2281,7 @@ __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, Ref
             uint32_t i = 0;
             for (uint32_t q = 1; q < ic; q++) i += tab[q].pc <= w ? 1u : 0u;
             const PIvl e = tab[i];
-            const bool literal = e.flags & 1u, minus = e.flags & 2u;
-            const uint32_t len = e.len, t0 = 16u * (w - e.pc), n = min(16u, len - t0);
-            const uint64_t g0 = e.g + (minus ? len - t0 - n : t0);          // forward positions [g0, g0 + n)
-            uint32_t d[4];
-            bool fast = false;
-            if (!literal) {
-                const uint32_t bt0 = R.blocktab[g0 >> BLOCK_SHIFT], bt1 = R.blocktab[(g0 + n - 1) >> BLOCK_SHIFT];
-                const uint32_t w0 = R.packed[g0 >> 4], w1 = R.packed[(g0 >> 4) + 1];      // (the buffer has a spare line at its end)
-                fast = bt0 == NO_BLOCK && bt1 == NO_BLOCK;
-                uint32_t x = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> (2 * (g0 & 15)));          // n codes, first at bit 0
-                if (minus) {
-                    // last base first, complemented (= both bits inverted); after the reversal the n codes sit at the top
-                    x = __builtin_bitreverse32(~x);
-                    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-                    x >>= 2 * (16 - n);
-                }
-                d[0] = ascii4(x); d[1] = ascii4(x >> 8); d[2] = ascii4(x >> 16); d[3] = ascii4(x >> 24);
-            }
-            uint8_t* dstp = bimg + e.o + t0;
-            if (!fast) {
-                for (uint32_t j = 0; j < n; j++) {
-                    const uint32_t src = minus ? len - 1 - (t0 + j) : t0 + j;
-                    const uint8_t b = literal ? upper(B.litpool[e.g + src]) : ref_base(R, e.g + src);
-                    dstp[j] = minus ? comp(b) : b;
-                }
-            } else if (n == 16) __builtin_memcpy(dstp, d, 16);
-            else {
-                // never past the interval: its neighbour is written in the same pass
-                unsigned long long lo8 = ((unsigned long long)d[1] << 32) | d[0], hi8 = ((unsigned long long)d[3] << 32) | d[2];
-                for (uint32_t j = 0; j < n; j++) {
-                    dstp[j] = (uint8_t)lo8;
-                    lo8 = (lo8 >> 8) | (hi8 << 56); hi8 >>= 8;
-                }
-            }
+            splice_piece(B, R, e.g, e.len, e.flags & 1u, e.flags & 2u, 16u * (w - e.pc), bimg + e.o + 16u * (w - e.pc));
         }
         wave_sync();
         // ---- substitutions: before the strand flip, later entries win (py/sequence.py:229-239); one lane per interval
