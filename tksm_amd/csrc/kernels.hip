@@ -952,16 +952,24 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
     wave_sync();
     uint8_t* gfrag = FB.st_frag + r * (size_t)P.lcap;
     unsigned long long* fpl = FB.st_fplanes + r * 2ull * FB.fw;
+    // the fragment goes to HBM in 8-byte pieces (the slot is a multiple of 8 long; bytes past L are never used)
+    for (int t = 8 * lane; t < L; t += 512) *reinterpret_cast<uint2*>(gfrag + t) = *reinterpret_cast<const uint2*>(frag + t);
+    // code planes, 64 positions per pair of words: lane q keeps the pair of word q, one 16-byte store per lane then;
+    // the words past the fragment are zero (the alignment's window runs into them)
     bool dirty = false;
-    for (int q = 0; q < FB.fw; q++) {
-        const int p = q * 64 + lane;
-        const bool valid = p < L;
-        const uint8_t c = valid ? frag[p] : (uint8_t)'A';
-        if (valid) gfrag[p] = c;
-        const int code = code_of(c);
-        dirty |= code < 0;
-        const unsigned long long lo = __ballot(valid && (code & 1)), hi = __ballot(valid && (code & 2));
-        if (lane == 0) { fpl[2 * q] = lo; fpl[2 * q + 1] = hi; }
+    const int nw = (L + 63) >> 6;
+    for (int q0 = 0; q0 < FB.fw; q0 += 64) {
+        unsigned long long mylo = 0ull, myhi = 0ull;
+        for (int q = q0; q < min(q0 + 64, nw); q++) {
+            const int p = q * 64 + lane;
+            const bool valid = p < L;
+            const uint8_t c = valid ? frag[p] : (uint8_t)'A';
+            const int code = code_of(c);
+            dirty |= code < 0;
+            const unsigned long long lo = __ballot(valid && (code & 1)), hi = __ballot(valid && (code & 2));
+            if (lane == q - q0) { mylo = lo; myhi = hi; }
+        }
+        if (q0 + lane < FB.fw) { ulonglong2 v; v.x = mylo; v.y = myhi; *reinterpret_cast<ulonglong2*>(fpl + 2 * (q0 + lane)) = v; }
     }
     const bool slow = __ballot(dirty) != 0ull;
     if (lane == 0) {
