@@ -2213,7 +2213,7 @@ int perfect_lds_bytes(int img_bytes) { return WAVES_PER_WG * (img_bytes + 32 + P
 #endif
 __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
                                                      uint8_t* __restrict__ records, int img_bytes, int skip_below, int last) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: the read index and its metadata stay scalar
     const int per_wave = img_bytes + 32 + PERFECT_IVLS * (int)sizeof(PIvl) + 160;
     uint8_t* img = lds_raw + (size_t)wave * per_wave;
     PIvl* tab = reinterpret_cast<PIvl*>(img + img_bytes + 32);
