@@ -952,8 +952,14 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
     wave_sync();
     uint8_t* gfrag = FB.st_frag + r * (size_t)P.lcap;
     unsigned long long* fpl = FB.st_fplanes + r * 2ull * FB.fw;
-    // the fragment goes to HBM in 8-byte pieces (the slot is a multiple of 8 long; bytes past L are never used)
-    for (int t = 8 * lane; t < L; t += 512) *reinterpret_cast<uint2*>(gfrag + t) = *reinterpret_cast<const uint2*>(frag + t);
+    // the fragment goes to HBM as one 2-bit code per byte ("ACGT" -> 0..3: bits 1 and 2 of the letter, xor-ed), in 8-byte
+    // pieces (the slot is a multiple of 8 long; bytes past L are never used).  Reads with other letters never use it:
+    // they take the wave-wide kernel, which splices its own fragment.
+    for (int t = 8 * lane; t < L; t += 512) {
+        uint2 c = *reinterpret_cast<const uint2*>(frag + t);
+        c.x = ((c.x >> 1) ^ (c.x >> 2)) & 0x03030303u; c.y = ((c.y >> 1) ^ (c.y >> 2)) & 0x03030303u;
+        *reinterpret_cast<uint2*>(gfrag + t) = c;
+    }
     // code planes, 64 positions per pair of words: lane q keeps the pair of word q, one 16-byte store per lane then;
     // the words past the fragment are zero (the alignment's window runs into them)
     bool dirty = false;
@@ -1009,16 +1015,15 @@ DEV void finish_read(const BatchView& B, const SimParams& P, const SimBuffers& O
 
 // one slot of one draw: new length / encoding and whether it is applied (differs from the original base and the
 // position is still pristine), py/tksm_badread.py:378-390
-DEV bool eval_slot(const uint8_t* frag, const uint16_t* nb, int ai, int jj, int akind, uint64_t aalt, int& len, uint32_t& enc) {
+// (frag holds 2-bit codes; boff = bases of the alternative before slot jj)
+DEV bool eval_slot(const uint8_t* frag, const uint16_t* nb, int ai, int jj, int akind, uint64_t aalt, int boff, int& len, uint32_t& enc) {
     const int p = ai + jj;
-    const uint8_t orig = frag[p];
+    const uint32_t orig = frag[p];
     bool differs;
     if (akind == 1) {
-        int boff = 0;
-        for (int x2 = 0; x2 < jj; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
         len = (int)((aalt >> (3 * jj)) & 7);
         const uint32_t codes = (uint32_t)((aalt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u));
-        differs = !(len == 1 && base_char((int)codes) == orig);
+        differs = !(len == 1 && codes == orig);
         enc = 0x8000u | ((uint32_t)len << 12) | codes;
     } else {
         const int type = (int)(aalt & 3), pos = (int)((aalt >> 2) & 15);
@@ -1026,8 +1031,8 @@ DEV bool eval_slot(const uint8_t* frag, const uint16_t* nb, int ai, int jj, int 
         const int r3 = (int)((aalt >> 12) & 3);
         differs = jj == pos;
         if (type == 0) {
-            const int cc = code_of(orig);
-            len = 1; enc = 0x8000u | (1u << 12) | (uint32_t)(cc < 0 ? (int)base4 : ((cc + r3) & 3));
+            (void)base4;
+            len = 1; enc = 0x8000u | (1u << 12) | ((orig + (uint32_t)r3) & 3u);
         } else if (type == 1) {
             len = 2;
             enc = side ? (0x8000u | (2u << 12) | (1u << 10) | (base4 << 2)) : (0x8000u | (2u << 12) | (2u << 10) | base4);
@@ -1042,11 +1047,13 @@ DEV SlotEval eval_draw(const uint8_t* frag, const uint16_t* nb, int k, int i, in
     SlotEval r;
     r.am = 0; r.lens = 0; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0;
     if (acc) {
+        int boff = 0;
 #pragma unroll
         for (int jj = 0; jj < 8; jj++) {
             if (jj < k) {
                 int len = 1; uint32_t enc = 0;
-                const bool app = eval_slot(frag, nb, i, jj, kind, alt, len, enc);
+                const bool app = eval_slot(frag, nb, i, jj, kind, alt, boff, len, enc);
+                boff += kind == 1 ? len : 0;
                 if (app) r.am |= 1u << jj;
                 r.lens |= (uint32_t)len << (3 * jj);
                 r.e[jj >> 1] |= (enc & 0xffffu) << (16 * (jj & 1));
@@ -1107,7 +1114,7 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             atomicOr(&shn[off >> 3], (uint32_t)(sh & 15) << (4 * (off & 7)));
             atomicOr(&pl32[4 * lnw + (off >> 5)], (uint32_t)((sh >> 4) & 1) << (off & 31));
             // symbol x of a slot: the original base where the marker says so, else the stored 2-bit code
-            const uint32_t oc = (uint32_t)code_of(orig) & 3u;
+            const uint32_t oc = orig;                       // (the fragment's bytes are 2-bit codes)
             const int mk = code ? (int)((code >> 10) & 3) : 1;
             for (int x2 = 0; x2 < len; x2++) {
                 const int c = off + x2;
@@ -1117,7 +1124,7 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             }
         }
         if (out_seq)
-            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = slot_sym(code, x2, orig); }
+            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = slot_sym(code, x2, base_char(orig)); }
         if (ne) last_nonempty = q + 63 - __builtin_clzll(ne);
         base += total;
     }
@@ -1273,7 +1280,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
 #endif
             if (live) {
                 int kidx = 0; bool valid = true;
-                for (int jj = 0; jj < k; jj++) { const int cc = code_of(frag[i + jj]); valid &= cc >= 0; kidx = (kidx << 2) | (cc & 3); }
+                for (int jj = 0; jj < k; jj++) kidx = (kidx << 2) | (int)frag[i + jj];      // 2-bit codes; only plain ACGT reads come here
 #ifdef TKSM_ABLATE
                 if (P.ablate == 7) { if (kidx == -12345) FB.counters[15] = d.z + d.w + d.y; return; }
                 if (P.ablate == 8) { const uint2 q2 = EM.pself2[kidx]; if (q2.x == 12345u && q2.y == d.y) FB.counters[15] = d.z + d.w; return; }
@@ -1352,7 +1359,11 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)alt, src);
                     if (resume) { jj0 = S.resume_j; est = S.est; resume = false; }
                     uint32_t enc = 0; int len = 1; bool app = false;
-                    if (lane < k && lane >= jj0) app = eval_slot(frag, nb, ai, lane, akind, aalt, len, enc);
+                    if (lane < k && lane >= jj0) {
+                        int boff = 0;
+                        for (int x2 = 0; x2 < lane; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
+                        app = eval_slot(frag, nb, ai, lane, akind, aalt, boff, len, enc);
+                    }
                     am_s = (uint32_t)__ballot(app);
                     // lengths of the applied slots, 3 bits each
                     uint32_t lv = app ? (uint32_t)len << (3 * lane) : 0u;
