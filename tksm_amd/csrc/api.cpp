@@ -104,7 +104,7 @@ struct tksmseq_ctx : ContigLookup {
     bool em_uniform = false, em_alt0 = false;
     TailModelHost tail; uint64_t tail_version = 0;
     DevBuf d_tail_lx, d_tail_ly, d_tail_cdf, d_tail_chain;
-    DevBuf d_pself, d_cdf32, d_cdf, d_alts, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
+    DevBuf d_pself, d_cdf32, d_cdf, d_alts, d_altenc, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
@@ -182,7 +182,7 @@ int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out) {
     c->total_alloc = src->total_alloc; c->total_bases = src->total_bases; c->pool_blocks = src->pool_blocks;
     c->d_packed.borrow(src->d_packed); c->d_blocktab.borrow(src->d_blocktab); c->d_pool.borrow(src->d_pool); c->d_contigs.borrow(src->d_contigs);
     c->em = src->em; c->qm = src->qm; c->idm = src->idm; c->em_uniform = src->em_uniform; c->em_alt0 = src->em_alt0;
-    c->d_pself.borrow(src->d_pself); c->d_cdf32.borrow(src->d_cdf32); c->d_cdf.borrow(src->d_cdf); c->d_alts.borrow(src->d_alts);
+    c->d_pself.borrow(src->d_pself); c->d_cdf32.borrow(src->d_cdf32); c->d_cdf.borrow(src->d_cdf); c->d_alts.borrow(src->d_alts); c->d_altenc.borrow(src->d_altenc);
     c->d_nalts.borrow(src->d_nalts); c->d_qkeys.borrow(src->d_qkeys); c->d_qoff.borrow(src->d_qoff); c->d_qcnt.borrow(src->d_qcnt);
     c->d_qcdf.borrow(src->d_qcdf); c->d_qq.borrow(src->d_qq); c->d_qtab.borrow(src->d_qtab); c->d_qent.borrow(src->d_qent);
     c->d_qpairs.borrow(src->d_qpairs); c->d_qguide.borrow(src->d_qguide);
@@ -336,6 +336,29 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
         if ((rc = upload(ctx, ctx->d_pself, ps))) return rc;
     }
     if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
+    {
+        // the alternatives once more, as the fast pipeline applies them (kernels.h ErrModelView::alts_enc): per slot the
+        // 16-bit encoding it would write, bit 15 telling whether the slot differs from the k-mer's own base
+        const size_t nk = ctx->em.nalts.size(), A = (size_t)ctx->em.max_alts;
+        const int k = ctx->em.k;
+        std::vector<uint32_t> enc(nk * A * 4, 0u);
+        for (size_t i = 0; i < nk && ctx->em.type == 1; i++)
+            for (size_t a = 0; a < A; a++) {
+                const uint64_t alt = ctx->em.alts[i * A + a];
+                uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int boff = 0;
+                for (int j = 0; j < k; j++) {
+                    const uint32_t kc = (uint32_t)(i >> (2 * (k - 1 - j))) & 3u;
+                    if (alt >> 63) { e[j] = (1u << 12) | kc; continue; }          // the k-mer itself
+                    const uint32_t len = (uint32_t)(alt >> (3 * j)) & 7u;
+                    const uint32_t codes = (uint32_t)(alt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u);
+                    boff += (int)len;
+                    e[j] = ((len == 1 && codes == kc) ? 0u : 0x8000u) | (len << 12) | codes;
+                }
+                for (int q = 0; q < 4; q++) enc[(i * A + a) * 4 + q] = e[2 * q] | (e[2 * q + 1] << 16);
+            }
+        if ((rc = upload(ctx, ctx->d_altenc, enc))) return rc;
+    }
     return upload(ctx, ctx->d_nalts, ctx->em.nalts);
 }
 
@@ -673,7 +696,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
 
     const tk::BatchView B = batch_view(b);
     const tk::RefView R = ref_view(ctx);
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>(), ctx->d_altenc.as<uint4>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
                        ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>()};
@@ -796,8 +819,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, place_ranges());
         HIPCHK(ctx, ctx->f_svi.ensure(n * 128 + 64));
         HIPCHK(ctx, ctx->f_svk.ensure(n * 64 + 64));
-        HIPCHK(ctx, ctx->f_sva.ensure(n * 512 + 64));
-        FB.sv_i = ctx->f_svi.as<uint16_t>(); FB.sv_kind = ctx->f_svk.as<uint8_t>(); FB.sv_alt = ctx->f_sva.as<unsigned long long>();
+        HIPCHK(ctx, ctx->f_sva.ensure(n * 1024 + 64));
+        FB.sv_i = ctx->f_svi.as<uint16_t>(); FB.sv_kind = ctx->f_svk.as<uint8_t>(); FB.sv_alt = ctx->f_sva.as<uint4>();
         std::vector<uint32_t> hcnt((size_t)FB.n_ranges * 32);
         // length buckets over the sorted read order: each bucket gets its own LDS geometry
         struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; bool hbm; };

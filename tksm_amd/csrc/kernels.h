@@ -38,6 +38,8 @@ struct ErrModelView {
     const uint8_t* nalts;
     const uint2* pself2;    // [4^k] {first, last} threshold of every row (cache-resident, 128 KB)
     const uint32_t* cdf32;  // [4^k][32] the same thresholds padded to 128-byte rows (max_alts <= 32 only)
+    const uint4* alts_enc;  // [4^k][max_alts] the alternatives as the fast pipeline applies them: eight 16-bit slot
+                            // encodings (length << 12 | 2-bit codes), bit 15 = the slot differs from the k-mer's base
 };
 
 struct QsModelView {
@@ -160,7 +162,7 @@ struct FastBuffers {
     // stay dense as the reads finish (fewer pages touched, no empty waves)
     const uint32_t* base_cur; const uint32_t* base_prev;
     const RangeGeo* geo_cur; const RangeGeo* geo_prev;   // [n_ranges]
-    uint16_t* sv_i; uint8_t* sv_kind; unsigned long long* sv_alt;   // [n_reads][64] draws of an interrupted round
+    uint16_t* sv_i; uint8_t* sv_kind; uint4* sv_alt;                // [n_reads][64] draws of an interrupted round
     uint32_t* slow_list;              // [n_reads]
     // reads longer than defer_len wait (stage 3) with their q-score alignment until the regular rounds are over
     uint2* defer_list;                // [n_reads] {read, range}; counters[1] counts

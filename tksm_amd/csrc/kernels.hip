@@ -1013,50 +1013,44 @@ DEV void finish_read(const BatchView& B, const SimParams& P, const SimBuffers& O
     }
 }
 
-// one slot of one draw: new length / encoding and whether it is applied (differs from the original base and the
-// position is still pristine), py/tksm_badread.py:378-390
-// (frag holds 2-bit codes; boff = bases of the alternative before slot jj)
-DEV bool eval_slot(const uint8_t* frag, const uint16_t* nb, int ai, int jj, int akind, uint64_t aalt, int boff, int& len, uint32_t& enc) {
-    const int p = ai + jj;
-    const uint32_t orig = frag[p];
-    bool differs;
-    if (akind == 1) {
-        len = (int)((aalt >> (3 * jj)) & 7);
-        const uint32_t codes = (uint32_t)((aalt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u));
-        differs = !(len == 1 && codes == orig);
-        enc = 0x8000u | ((uint32_t)len << 12) | codes;
-    } else {
-        const int type = (int)(aalt & 3), pos = (int)((aalt >> 2) & 15);
-        const uint32_t base4 = (uint32_t)((aalt >> 8) & 3), side = (uint32_t)((aalt >> 10) & 1);
-        const int r3 = (int)((aalt >> 12) & 3);
-        differs = jj == pos;
-        if (type == 0) {
-            (void)base4;
-            len = 1; enc = 0x8000u | (1u << 12) | ((orig + (uint32_t)r3) & 3u);
-        } else if (type == 1) {
-            len = 2;
-            enc = side ? (0x8000u | (2u << 12) | (1u << 10) | (base4 << 2)) : (0x8000u | (2u << 12) | (2u << 10) | base4);
-        } else { len = 0; enc = 0x8000u; }
-    }
-    return differs && nb[p] == 0;
+// A draw as the fast pipeline carries it: the alternative's eight 16-bit slot encodings (length << 12 | 2-bit codes; bit
+// 15 = the slot differs from the original base), ErrModelView::alts_enc for a model alternative, random_change_enc for
+// add_one_random_change.  A slot is applied if it differs and the position is still pristine (py/tksm_badread.py:378-390).
+DEV uint32_t draw_slot(const uint4& A, int jj) {
+    const uint32_t w = (jj >> 1) == 0 ? A.x : (jj >> 1) == 1 ? A.y : (jj >> 1) == 2 ? A.z : A.w;
+    return (w >> (16 * (jj & 1))) & 0xffffu;
 }
 
-// all k slots of a lane's own draw: am = applied mask, lens = 3 bits per slot, e = 16-bit encodings
+// add_one_random_change (py/tksm_badread.py:199-213) on the k-mer with index kidx (first base in the high bits): every
+// slot keeps its base except slot pos: substitution by the r3-th next base, insertion of base4 before / after, deletion
+DEV uint4 random_change_enc(int kidx, int k, uint32_t type, uint32_t pos, uint32_t base4, uint32_t side, uint32_t r3) {
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t kc = j < k ? (uint32_t)(kidx >> (2 * (k - 1 - j))) & 3u : 0u;
+        uint32_t v = (1u << 12) | kc;
+        if ((uint32_t)j == pos)
+            v = type == 0 ? 0x8000u | (1u << 12) | ((kc + r3) & 3u)
+              : type == 1 ? 0x8000u | (2u << 12) | (side ? (kc | (base4 << 2)) : (base4 | (kc << 2)))
+                          : 0x8000u;
+        e[j] = j < k ? v : 0u;
+    }
+    return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
+// all k slots of a lane's own draw: am = applied mask, lens = 3 bits per slot, e = 16-bit encodings (bit 15 set)
 struct SlotEval { uint32_t am, lens; uint32_t e[4]; };
-DEV SlotEval eval_draw(const uint8_t* frag, const uint16_t* nb, int k, int i, int kind, uint64_t alt, bool acc) {
+DEV SlotEval eval_draw(const uint16_t* nb, int k, int i, const uint4& A, bool acc) {
     SlotEval r;
-    r.am = 0; r.lens = 0; r.e[0] = r.e[1] = r.e[2] = r.e[3] = 0;
+    r.am = 0; r.lens = 0;
+    r.e[0] = A.x | 0x80008000u; r.e[1] = A.y | 0x80008000u; r.e[2] = A.z | 0x80008000u; r.e[3] = A.w | 0x80008000u;
     if (acc) {
-        int boff = 0;
 #pragma unroll
         for (int jj = 0; jj < 8; jj++) {
             if (jj < k) {
-                int len = 1; uint32_t enc = 0;
-                const bool app = eval_slot(frag, nb, i, jj, kind, alt, boff, len, enc);
-                boff += kind == 1 ? len : 0;
-                if (app) r.am |= 1u << jj;
-                r.lens |= (uint32_t)len << (3 * jj);
-                r.e[jj >> 1] |= (enc & 0xffffu) << (16 * (jj & 1));
+                const uint32_t e = draw_slot(A, jj);
+                if ((e >> 15) && nb[i + jj] == 0) r.am |= 1u << jj;
+                r.lens |= ((e >> 12) & 7u) << (3 * jj);
             }
         }
     }
@@ -1222,7 +1216,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     uint8_t* out_seq = O.scratch + slot;
     uint8_t* out_qual = out_seq + cap;
     // the draws of the round that was interrupted by the re-estimation come back with the state (no regeneration)
-    int sv_i = 0, sv_kind = 0; uint64_t sv_alt = 0;
+    int sv_i = 0, sv_kind = 0; uint4 sv_alt = make_uint4(0u, 0u, 0u, 0u);
     if (S.stage == 0 && S.resume_src >= 0) {
         sv_i = FB.sv_i[r * 64 + lane]; sv_kind = FB.sv_kind[r * 64 + lane]; sv_alt = FB.sv_alt[r * 64 + lane];
     }
@@ -1269,8 +1263,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         while (!done && !need_aln) {
             const uint32_t n = n_base + (uint32_t)lane;
             const bool live = (long long)n + 1 <= loop_limit;
-            int i, kind = 0;
-            uint64_t alt = 0;
+            int i, kind = 0;                              // kind: 0 no-op, 1 a draw that changes something
+            uint4 alt = make_uint4(0u, 0u, 0u, 0u);
             if (resume) { i = sv_i; kind = sv_kind; alt = sv_alt; }
             else {
             const Ph4 d = philox(P.seed, g, ST_DRAW, n);
@@ -1293,13 +1287,14 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                     const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, pp2.x, pp2.y, na, d.y);
                     if (a == na) kind = 2;
                     else if (a == 0 && EM.alt0_noop) kind = 0;      // the k-mer itself: no need to fetch its packed form
-                    else { alt = EM.alts[(size_t)kidx * EM.max_alts + a]; kind = (alt >> 63) ? 0 : 1; }
+                    else { alt = EM.alts_enc[(size_t)kidx * EM.max_alts + a]; kind = ((alt.x | alt.y | alt.z | alt.w) & 0x80008000u) ? 1 : 0; }
                 }
                 if (kind == 2) {
                     const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
                     const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
                     const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
-                    alt = type | (pos << 2) | (base4 << 8) | (side << 10) | (r3 << 12);
+                    alt = random_change_enc(kidx, k, type, pos, base4, side, r3);
+                    kind = 1;
                 }
             }
             }
@@ -1312,7 +1307,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             // ---- every accepted draw is evaluated by its own lane against the slots as they are now ...
             wave_sync();
             const bool acc = (mask >> lane) & 1ull;
-            SlotEval ev = eval_draw(frag, nb, k, i, kind, alt, acc);
+            SlotEval ev = eval_draw(nb, k, i, alt, acc);
             // ... which is exact unless an earlier accepted draw of this round touches an overlapping window (rare);
             // those, and the draw being resumed, are re-evaluated at their turn
             unsigned long long depm = 0ull;
@@ -1354,15 +1349,16 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                     flush_writes();
                     wave_sync();
                     const int ai = __builtin_amdgcn_readlane(i, src);
-                    const int akind = __builtin_amdgcn_readlane(kind, src);
-                    const uint64_t aalt = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(alt >> 32), src) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)alt, src);
+                    uint4 aalt;
+                    aalt.x = (uint32_t)__builtin_amdgcn_readlane((int)alt.x, src); aalt.y = (uint32_t)__builtin_amdgcn_readlane((int)alt.y, src);
+                    aalt.z = (uint32_t)__builtin_amdgcn_readlane((int)alt.z, src); aalt.w = (uint32_t)__builtin_amdgcn_readlane((int)alt.w, src);
                     if (resume) { jj0 = S.resume_j; est = S.est; resume = false; }
                     uint32_t enc = 0; int len = 1; bool app = false;
                     if (lane < k && lane >= jj0) {
-                        int boff = 0;
-                        for (int x2 = 0; x2 < lane; x2++) boff += (int)((aalt >> (3 * x2)) & 7);
-                        app = eval_slot(frag, nb, ai, lane, akind, aalt, boff, len, enc);
+                        enc = draw_slot(aalt, lane);
+                        len = (int)((enc >> 12) & 7u);
+                        app = (enc >> 15) && nb[ai + lane] == 0;
+                        enc |= 0x8000u;
                     }
                     am_s = (uint32_t)__ballot(app);
                     // lengths of the applied slots, 3 bits each
