@@ -1107,18 +1107,20 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             if (sh > 31) fail = true;
             atomicOr(&shn[off >> 3], (uint32_t)(sh & 15) << (4 * (off & 7)));
             atomicOr(&pl32[4 * lnw + (off >> 5)], (uint32_t)((sh >> 4) & 1) << (off & 31));
-            // symbol x of a slot: the original base where the marker says so, else the stored 2-bit code
-            const uint32_t oc = orig;                       // (the fragment's bytes are 2-bit codes)
-            const int mk = code ? (int)((code >> 10) & 3) : 1;
+            // the slot's symbols, 2 bits each: the original base of a pristine slot, else the stored codes (the fast
+            // pipeline stores every symbol explicitly: its fragments are plain ACGT, no original-base markers)
+            const uint32_t syms = code ? code & 0x3ffu : (uint32_t)orig;
             for (int x2 = 0; x2 < len; x2++) {
                 const int c = off + x2;
-                const uint32_t cd = mk == x2 + 1 ? oc : (code >> (2 * x2)) & 3u;
+                const uint32_t cd = (syms >> (2 * x2)) & 3u;
                 atomicOr(&pl32[c >> 5], (cd & 1u) << (c & 31));
                 atomicOr(&pl32[2 * lnw + (c >> 5)], (cd >> 1) << (c & 31));
             }
         }
-        if (out_seq)
-            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = slot_sym(code, x2, base_char(orig)); }
+        if (out_seq) {
+            const uint32_t syms = code ? code & 0x3ffu : (uint32_t)orig;
+            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = base_char((int)(syms >> (2 * x2))); }
+        }
         if (ne) last_nonempty = q + 63 - __builtin_clzll(ne);
         base += total;
     }
