@@ -1336,7 +1336,11 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                 if (wm_mine) {
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++)
-                        if ((wm_mine >> jj) & 1u) nb[i + jj] = (uint16_t)((ev.e[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
+                        if ((wm_mine >> jj) & 1u) {
+                            const uint16_t v = (uint16_t)((ev.e[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
+                            nb[i + jj] = v;
+                            if (!STATE_IN_HBM) gnb[i + jj] = v;      // the copy in HBM follows slot by slot: no dense write-back
+                        }
                     wm_mine = 0u;
                 }
             };
@@ -1457,8 +1461,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             if (P.ablate == 5) return;
 #endif
             if (job >> 31) { go_slow(FB, r, lane, 1); return; }
-            if (!STATE_IN_HBM)
-                for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
             if (lane == 0) {
                 S.errors = errors; S.est = r_est; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
                 S.resume_src = (int16_t)r_src; S.resume_j = (int16_t)r_j; S.pending = 1; S.stage = 0;
@@ -1467,9 +1469,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
             }
             return;
         }
-        // the loop has ended: write the final slots back once (the FINAL stage re-joins from them)
-        if (!STATE_IN_HBM)
-            for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(gnb + t) = *reinterpret_cast<const uint32_t*>(nb + t);
     } else {
         st_draws = S.st_draws;
     }
