@@ -1106,7 +1106,7 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             const int sh = max(1, p + 1 - 31) - max(1, prevp + 1 - 31);
             if (sh > 31) fail = true;
             atomicOr(&shn[off >> 3], (uint32_t)(sh & 15) << (4 * (off & 7)));
-            atomicOr(&pl32[4 * lnw + (off >> 5)], (uint32_t)((sh >> 4) & 1) << (off & 31));
+            if (sh & 16) atomicOr(&pl32[4 * lnw + (off >> 5)], 1u << (off & 31));      // (rare: a window shift of 16 rows or more)
             // the slot's symbols, 2 bits each: the original base of a pristine slot, else the stored codes (the fast
             // pipeline stores every symbol explicitly: its fragments are plain ACGT, no original-base markers)
             const uint32_t syms = code ? code & 0x3ffu : (uint32_t)orig;
