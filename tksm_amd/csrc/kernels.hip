@@ -1078,18 +1078,16 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 // Returns the job id (bit 31: the job cannot be represented: a shift > 31 rows).
 DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
                       int p0, int n, int& m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
-    const int lnw = ncap_l / 64 + 2, lshw = ncap_l / 8 + 16;
-    uint32_t* pl32 = reinterpret_cast<uint32_t*>(stage);                        // planes: code low, code high, shift bit 4
-    uint32_t* shn = reinterpret_cast<uint32_t*>(stage + 24 * (size_t)lnw);
+    // staging: one byte per column of the joined sequence, {bits 0-1 base code, bits 2-6 window shift (first symbol of a
+    // slot only)}; every column is written exactly once, by plain byte stores (bit planes filled by LDS atomics had 32
+    // lanes serialising on one word)
+    uint8_t* colb = stage;
     uint32_t idx = 0;
     const uint32_t rc = pos / FB.rs;                       // the read's range of the sorted order
     if (build) {
         ncap_l = min(ncap_l, (int)FB.geo_cur[rc].ncap);    // rows of the range's jobs are this long
         if (lane == 0) idx = FB.base_cur[rc] + atomicAdd(&FB.job_cnt[rc * 32u], 1u);
         idx = __shfl(idx, 0, 64);
-        uint32_t* z = reinterpret_cast<uint32_t*>(stage);
-        for (int t = lane; t < 6 * lnw + lshw; t += 64) z[t] = 0u;
-        wave_sync();
     }
     bool fail = false;
     int base = 0, last_nonempty = -1;
@@ -1105,17 +1103,11 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             const int prevp = below ? q + 63 - __builtin_clzll(below) : last_nonempty;
             const int sh = max(1, p + 1 - 31) - max(1, prevp + 1 - 31);
             if (sh > 31) fail = true;
-            atomicOr(&shn[off >> 3], (uint32_t)(sh & 15) << (4 * (off & 7)));
-            if (sh & 16) atomicOr(&pl32[4 * lnw + (off >> 5)], 1u << (off & 31));      // (rare: a window shift of 16 rows or more)
             // the slot's symbols, 2 bits each: the original base of a pristine slot, else the stored codes (the fast
             // pipeline stores every symbol explicitly: its fragments are plain ACGT, no original-base markers)
             const uint32_t syms = code ? code & 0x3ffu : (uint32_t)orig;
-            for (int x2 = 0; x2 < len; x2++) {
-                const int c = off + x2;
-                const uint32_t cd = (syms >> (2 * x2)) & 3u;
-                atomicOr(&pl32[c >> 5], (cd & 1u) << (c & 31));
-                atomicOr(&pl32[2 * lnw + (c >> 5)], (cd >> 1) << (c & 31));
-            }
+            colb[off] = (uint8_t)((syms & 3u) | ((uint32_t)(sh & 31) << 2));
+            for (int x2 = 1; x2 < len; x2++) colb[off + x2] = (uint8_t)((syms >> (2 * x2)) & 3u);
         }
         if (out_seq) {
             const uint32_t syms = code ? code & 0x3ffu : (uint32_t)orig;
@@ -1134,19 +1126,24 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             meta[3] = (uint32_t)(m > ncap_l ? 0 : m);
         }
         if (m > ncap_l) return idx;
+        if (lane < 32) colb[m + lane] = 0;                        // the columns past the end that the last records cover
         wave_sync();
         // one record per 8 columns: {shifts, code bits, entering fragment rows}; one zero record after the end
         const RangeGeo G = FB.geo_cur[rc];
         uint4* jc = FB.job_cols + G.jc_off + (size_t)(idx - FB.base_cur[rc]) * G.cw;
-        const uint8_t* plb = stage;
         const unsigned long long* fp = FB.st_fplanes + r * 2ull * FB.fw;
         const int nrec = m / 8 + 2;
         int tcar = 1;                                             // window top at the start of the chunk's first block
         for (int q = 0; q < nrec; q += 64) {
             const int t = q + lane;
-            const uint32_t shw = t < nrec ? shn[t] : 0u, shx = t < nrec ? (uint32_t)plb[16 * lnw + t] : 0u;
-            const uint32_t x4 = (shw & 0x0f0f0f0fu) + ((shw >> 4) & 0x0f0f0f0fu);
-            const int adv = (int)((x4 * 0x01010101u) >> 24) + 16 * __popc(shx);
+            // the block's 8 column bytes -> shift nibbles, code bits and shift bit 4 of the 8 columns, sum of the shifts
+            const unsigned long long v = t < nrec ? *reinterpret_cast<const unsigned long long*>(colb + 8 * t) : 0ull;
+            auto bit_of_bytes = [](unsigned long long x) { return (uint32_t)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); };
+            unsigned long long nb4 = (v >> 2) & 0x0f0f0f0f0f0f0f0full;
+            nb4 = (nb4 | (nb4 >> 4)) & 0x00ff00ff00ff00ffull; nb4 = (nb4 | (nb4 >> 8)) & 0x0000ffff0000ffffull; nb4 = nb4 | (nb4 >> 16);
+            const uint32_t shw = (uint32_t)nb4, shx = bit_of_bytes(v >> 6);
+            const uint32_t clo = bit_of_bytes(v), chi = bit_of_bytes(v >> 1);
+            const int adv = (int)((((v >> 2) & 0x1f1f1f1f1f1f1f1full) * 0x0101010101010101ull) >> 56);
             const int incl = scan_add_incl(adv, lane);
             const int tk = tcar + incl - adv;                     // window top at the start of block t
             tcar += __shfl(incl, 63, 64);
@@ -1157,7 +1154,7 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
                 uint4 rec;
                 // bit 24: the window moves by more rows in this block than the record carries (a homopolymer that lost most of
                 // its bases): k_aln then takes the window from the read's fragment planes, column by column
-                rec.x = shw; rec.y = (uint32_t)plb[t] | ((uint32_t)plb[8 * lnw + t] << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u); rec.z = elo; rec.w = ehi;
+                rec.x = shw; rec.y = clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u); rec.z = elo; rec.w = ehi;
                 jc[t] = rec;
             }
         }
