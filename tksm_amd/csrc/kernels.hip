@@ -1071,9 +1071,8 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
 }
 
 // Walks the slots of window [p0, p0+n) once, slot per lane, and
-//  build != 0: packs the joined sequence straight into the alignment job (2-bit planes + 5-bit window shift per
-//              column) through a small LDS staging area filled with ds_or atomics -- the joined bytes and their
-//              owner array are never materialised;
+//  build != 0: packs the joined sequence straight into the alignment job's block records (base code + 5-bit window
+//              shift per column) through one staging byte per column in LDS -- the owner array is never materialised;
 //  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
 // Returns the job id (bit 31: the job cannot be represented: a shift > 31 rows).
 DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
