@@ -2095,8 +2095,27 @@ DEV int format_header(uint8_t* hdr, const SimParams& P, uint64_t g, uint32_t out
     return kx;
 }
 
+// a record's image in LDS (origin aligned like its place in the output, mod 16) -> the output: whole aligned 16-byte
+// pieces, 1 KB per store instruction; the first and the last piece, shared with the neighbouring records, byte by byte
+// (lanes 0 and 1)
+DEV void flush_image(const uint8_t* img, int a, uint32_t rec_len, uint8_t* gout /* record start - a */, int lane) {
+    const uint32_t end = (uint32_t)a + rec_len;
+    const uint32_t c0 = a ? 1u : 0u, c1 = end >> 4;          // whole pieces: [c0, c1)
+    for (uint32_t c = c0 + lane; c < c1; c += 64) *reinterpret_cast<uint4*>(gout + 16u * c) = *reinterpret_cast<const uint4*>(img + 16u * c);
+    if (lane < 2) {
+        const uint32_t lo = lane == 0 ? (uint32_t)a : max(16u * c1, (uint32_t)a), hi = lane == 0 ? (a ? min(16u, end) : 0u) : end;
+        for (uint32_t t = lo; t < hi; t++) gout[t] = img[t];
+    }
+}
+
+constexpr int EMIT_IMG = 6144;           // LDS image of a Badread record (bytes per wave); longer records go out bytewise
+
+// Record formatting of the Badread path (py/sequence.py:242-258, :273-300): header, sequence and quality line of a read
+// are assembled as an image in LDS (16 bytes per lane from the read's scratch slot) and leave in aligned 16-byte pieces,
+// like k_perfect's records.
 __global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
                                                uint8_t* __restrict__ records) {
+    __shared__ __attribute__((aligned(16))) uint8_t img_all[WAVES_PER_WG][EMIT_IMG + 32];
     __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t r = (uint64_t)blockIdx.x * WAVES_PER_WG + wave;
@@ -2108,29 +2127,59 @@ __global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffe
     if (lane == 0) hl = format_header(hdr, P, g, out_len, raw_len, O.identity[r]);
     hl = __shfl(hl, 0, 64);
     wave_sync();
-    uint8_t* dst = records + rec_off[r];
-    for (int t = lane; t < hl; t += 64) dst[t] = hdr[t];
-    dst += hl;
+    const uint64_t off = rec_off[r], rec_len = rec_off[r + 1] - off;
     const uint32_t ido = B.ids[2 * r], idl = B.ids[2 * r + 1];
-    for (uint32_t t = lane; t < idl; t += 64) dst[t] = B.idpool[ido + t];
-    dst += idl;
     const uint8_t* seq = O.scratch + O.slot_off[r];
     const uint64_t cap = (O.slot_off[r + 1] - O.slot_off[r]) >> 1;
-    if (lane == 0) dst[0] = '\n';
-    dst += 1;
-    for (uint32_t t = lane; t < out_len; t += 64) dst[t] = seq[t];
-    dst += out_len;
-    if (lane == 0) dst[0] = '\n';
-    dst += 1;
-    if (P.fastq) {
-        if (lane == 0) { dst[0] = '+'; dst[1] = '\n'; }
-        dst += 2;
-        const bool real_q = P.mode == 1 && P.compute_q && !P.quirk_perfect;
-        const uint8_t* qual = seq + cap;
-        for (uint32_t t = lane; t < out_len; t += 64) dst[t] = real_q ? qual[t] : (uint8_t)'K';
+    const bool real_q = P.mode == 1 && P.compute_q && !P.quirk_perfect;
+    const uint8_t* qual = seq + cap;
+    const int a = (int)(reinterpret_cast<uintptr_t>(records + off) & 15);
+    if (rec_len + (uint64_t)a > (uint64_t)EMIT_IMG) {
+        uint8_t* dst = records + off;
+        for (int t = lane; t < hl; t += 64) dst[t] = hdr[t];
+        dst += hl;
+        for (uint32_t t = lane; t < idl; t += 64) dst[t] = B.idpool[ido + t];
+        dst += idl;
+        if (lane == 0) dst[0] = '\n';
+        dst += 1;
+        for (uint32_t t = lane; t < out_len; t += 64) dst[t] = seq[t];
         dst += out_len;
         if (lane == 0) dst[0] = '\n';
+        dst += 1;
+        if (P.fastq) {
+            if (lane == 0) { dst[0] = '+'; dst[1] = '\n'; }
+            dst += 2;
+            for (uint32_t t = lane; t < out_len; t += 64) dst[t] = real_q ? qual[t] : (uint8_t)'K';
+            dst += out_len;
+            if (lane == 0) dst[0] = '\n';
+        }
+        return;
     }
+    uint8_t* img = img_all[wave];
+    for (int t = lane; t < hl; t += 64) img[a + t] = hdr[t];
+    for (uint32_t t = lane; t < idl; t += 64) img[a + hl + t] = B.idpool[ido + t];
+    if (lane == 0) img[a + hl + idl] = '\n';
+    // sequence and qualities: whole 16-byte pieces of the read's (16-byte aligned, padded) scratch slot; a last piece may
+    // run over its line's end, so what follows a line is written after it
+    uint8_t* simg = img + a + hl + idl + 1;
+    for (uint32_t t0 = 16u * lane; t0 < out_len; t0 += 1024u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(seq + t0);
+        __builtin_memcpy(simg + t0, &v, 16);
+    }
+    wave_sync();
+    if (lane == 0) { simg[out_len] = '\n'; if (P.fastq) { simg[out_len + 1] = '+'; simg[out_len + 2] = '\n'; } }
+    if (P.fastq) {
+        uint8_t* qimg = simg + out_len + 3;
+        for (uint32_t t0 = 16u * lane; t0 < out_len; t0 += 1024u) {
+            uint4 v = make_uint4(0x4b4b4b4bu, 0x4b4b4b4bu, 0x4b4b4b4bu, 0x4b4b4b4bu);
+            if (real_q) v = *reinterpret_cast<const uint4*>(qual + t0);
+            __builtin_memcpy(qimg + t0, &v, 16);
+        }
+        wave_sync();
+        if (lane == 0) qimg[out_len] = '\n';
+    }
+    wave_sync();
+    flush_image(img, a, (uint32_t)rec_len, records + off - a, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2323,15 +2372,7 @@ __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, Ref
         }
         wave_sync();
         // ---- out: image bytes [a, a + rec_len) -> records[off ..)
-        uint8_t* gout = records + off - a;
-        const uint32_t end = (uint32_t)a + (uint32_t)rec_len;
-        const uint32_t c0 = a ? 1u : 0u, c1 = end >> 4;          // whole pieces: [c0, c1)
-        for (uint32_t c = c0 + lane; c < c1; c += 64) *reinterpret_cast<uint4*>(gout + 16u * c) = *reinterpret_cast<const uint4*>(img + 16u * c);
-        // the pieces shared with the neighbouring records: lane 0 the first one, lane 1 the last one
-        if (lane < 2) {
-            const uint32_t lo = lane == 0 ? (uint32_t)a : max(16u * c1, (uint32_t)a), hi = lane == 0 ? (a ? min(16u, end) : 0u) : end;
-            for (uint32_t t = lo; t < hi; t++) gout[t] = img[t];
-        }
+        flush_image(img, a, (uint32_t)rec_len, records + off - a, lane);
     }
 }
 
