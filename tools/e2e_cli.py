@@ -18,7 +18,7 @@ env = dict(os.environ, TKSMSEQ_VERBOSE="1", TKSM_MODELS=os.path.join(os.getcwd()
 ext = ".fastq.gz" if os.environ.get("E2E_GZ") else ".fastq"
 for args, name in ((["--perfect", f"{d}/p{ext}"], "perfect"), (["-o", f"{d}/b{ext}"], "badread+qual")):
     t = time.time()
-    r = subprocess.run([os.path.join("tksm_amd", "tksm"), "sequence", "-i", f"{d}/mols.mdf", "-r", f"{d}/ref.fa"] + args + extra, capture_output=True, text=True, env=env)
+    r = subprocess.run([os.environ.get("E2E_EXE", os.path.join("tksm_amd", "tksm")), "sequence", "-i", f"{d}/mols.mdf", "-r", f"{d}/ref.fa"] + args + extra, capture_output=True, text=True, env=env)
     dt = time.time() - t
     out = args[-1]
     print(f"{name} {' '.join(extra)}: rc={r.returncode} {dt:.2f} s wall -> {n/dt:.0f} reads/s end to end, output {os.path.getsize(out)/1e6:.0f} MB", flush=True)
