@@ -30,6 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
 MODELS = os.path.join(ROOT, "tksm_amd", "models")
 
 
@@ -143,34 +144,23 @@ def strip_uuid(text):
 
 # ----------------------------------------------------------------------------- G6 stochastic stats
 _W = {}
+SHIPPED_MODELS = ("nanopore2020", "nanopore2018", "pacbio2016")
 
 
-def _worker_init():
+def _worker_init(model="nanopore2020"):
+    os.nice(10)
     pyoracle, tb, _ = import_reference()
     _W["po"], _W["tb"] = pyoracle, tb
     sink = io.StringIO()
-    _W["em"] = tb.ERROR_MODEL_PY.ErrorModel(os.path.join(MODELS, "badread", "nanopore2020.error.gz"), sink)
-    _W["qm"] = tb.QSCOREMODEL_PY.QScoreModel(os.path.join(MODELS, "badread", "nanopore2020.qscore.gz"), sink)
+    _W["em"] = tb.ERROR_MODEL_PY.ErrorModel(os.path.join(MODELS, "badread", model + ".error.gz"), sink)
+    _W["qm"] = tb.QSCOREMODEL_PY.QScoreModel(os.path.join(MODELS, "badread", model + ".qscore.gz"), sink)
     _W["tail"] = tb.TAIL_NOISE_MODEL_PY.KDE_noise_generator.load("no_noise")
     _W["ident"] = tb.IDENTITIES_PY.Identities(84.0, 5.5, 99.0, sink)
 
 
-def _cigar_counts(po, read, raw):
-    import re
-    _, cig = po.nw_cigar(read, raw)
-    cnt = {"=": 0, "X": 0, "I": 0, "D": 0}
-    maxi = 0
-    runs = []
-    for m in re.finditer(r"(\d+)([=XID])", cig):
-        n, t = int(m.group(1)), m.group(2)
-        cnt[t] += n
-        if t == "I":
-            runs.append(n)
-            maxi = max(maxi, n)
-    return cnt, runs, cig
-
-
 def _worker(job):
+    """One read through the reference's own sequence_fragment (+ get_qscores), seeded here (the reference is unseeded)."""
+    from stats_common import cigar_stats, qscore_hist
     L, seed, compute_q = job
     po, tb = _W["po"], _W["tb"]
     random.seed(seed)
@@ -201,39 +191,63 @@ def _worker(job):
     finally:
         em.add_errors_to_kmer = orig_add
         edl.align = orig_align
-    cnt, runs, cig = _cigar_counts(po, seq, raw) if len(seq) else ({"=": 0, "X": 0, "I": 0, "D": L}, [], "")
-    qh = np.zeros((3, 94), np.int64)
-    if compute_q and len(seq):
-        pos = 0
-        import re
-        for m in re.finditer(r"(\d+)([=XID])", cig):
-            n, t = int(m.group(1)), m.group(2)
-            if t == "D":
-                continue
-            row = "=XI".index(t)
-            for ch in qual[pos:pos + n]:
-                qh[row, ord(ch) - 33] += 1
-            pos += n
-    ins_hist = np.bincount(np.minimum(runs, 15), minlength=16) if runs else np.zeros(16, np.int64)
+    if len(seq):
+        _, cig = po.nw_cigar(seq, raw)
+        cnt, ins_hist, pos = cigar_stats(cig, L)
+        qh = qscore_hist(cig, qual) if compute_q else np.zeros((3, 94), np.int64)
+    else:
+        from stats_common import INS_BINS, POS_BINS
+        cnt, ins_hist, pos, qh = {"=": 0, "X": 0, "I": 0, "D": L}, np.zeros(INS_BINS, np.int64), np.zeros((3, POS_BINS), np.int64), np.zeros((3, 94), np.int64)
     return dict(L=L, out_len=len(seq), identity=ident, target=target, draws=calls["n"], noop=calls["noop"],
                 aligns=calls["aln"] - (1 if compute_q else 0), X=cnt["X"], I=cnt["I"], D=cnt["D"], M=cnt["="],
-                qh=qh, ins_hist=ins_hist)
+                qh=qh, ins_hist=ins_hist, pos=pos)
 
 
-def make_stochastic(jobs, procs):
-    with Pool(procs, initializer=_worker_init) as p:
-        return p.map(_worker, jobs, chunksize=8)
+def make_stochastic(model, jobs, procs):
+    with Pool(procs, initializer=_worker_init, initargs=(model,)) as p:
+        return p.map(_worker, jobs, chunksize=16)
+
+
+def stochastic_fixture(model, n_q, n_noq, procs, lengths=(300, 1000, 3000)):
+    """>= 20 k reference reads with q-scores and n_noq without, per length, for one shipped model."""
+    mi = SHIPPED_MODELS.index(model)
+    jobs = []
+    for L in lengths:
+        jobs += [(L, 1000000 * (10 * mi + L // 300) + i, True) for i in range(n_q)]
+        jobs += [(L, 500000000 + 1000000 * (10 * mi + L // 300) + i, False) for i in range(n_noq)]
+    res = make_stochastic(model, jobs, procs)
+    cols = ["L", "out_len", "identity", "target", "draws", "noop", "aligns", "X", "I", "D", "M"]
+    arr = {}
+    for c in cols:
+        a = np.array([r[c] for r in res])
+        arr[c] = a.astype(np.float32) if a.dtype.kind == "f" else a.astype(np.int32)
+    arr["with_q"] = np.array([j[2] for j in jobs])
+    for L in lengths:
+        for wq in (True, False):
+            sel = [r for r, j in zip(res, jobs) if j[0] == L and j[2] == wq]
+            tag = f"{L}_{'q' if wq else 'noq'}"
+            arr[f"ins_hist_{tag}"] = np.sum([r["ins_hist"] for r in sel], axis=0)
+            arr[f"pos_{tag}"] = np.sum([r["pos"] for r in sel], axis=0)
+            if wq:
+                arr[f"qhist_{L}"] = np.sum([r["qh"] for r in sel], axis=0)
+    np.savez_compressed(os.path.join(HERE, f"badread_reference_stats_{model}.npz"), **arr)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reads-300", type=int, default=3000)
-    ap.add_argument("--reads-1000", type=int, default=3000)
-    ap.add_argument("--reads-3000", type=int, default=600)
+    ap.add_argument("--reads-q", type=int, default=20000, help="reads with q-scores per model and length")
+    ap.add_argument("--reads-noq", type=int, default=10000, help="reads without q-scores per model and length")
+    ap.add_argument("--models", default=",".join(SHIPPED_MODELS))
+    ap.add_argument("--only-stochastic", action="store_true", help="regenerate the G6 statistics only")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--skip-stochastic", action="store_true")
     args = ap.parse_args()
     po, tb, ref_sequence = import_reference()
+    if args.only_stochastic:
+        for model in args.models.split(","):
+            stochastic_fixture(model, args.reads_q, args.reads_noq, args.procs)
+            print("G6", model, "done", flush=True)
+        return
 
     # G1 / G2 / G5: documentation known answers, evaluated by the reference's own functions
     ka = {}
@@ -282,22 +296,11 @@ def main():
                     "sample": {k: {"scores": qm.scores[k], "probs": qm.probabilities[k]} for k in pickq}}
     json.dump(g4, open(os.path.join(HERE, "model_parse_nanopore2020.json"), "w"), sort_keys=True)
 
-    # G6: per-read statistics of the reference's stochastic path (seeded here; the reference is unseeded)
+    # G6: per-read statistics of the reference's stochastic path, every shipped model (seeded here; the reference is unseeded)
     if not args.skip_stochastic:
-        jobs = []
-        for L, n in ((300, args.reads_300), (1000, args.reads_1000), (3000, args.reads_3000)):
-            jobs += [(L, 100000 * (L // 100) + i, True) for i in range(n)]
-            jobs += [(L, 50000000 + 100000 * (L // 100) + i, False) for i in range(n // 2)]
-        res = make_stochastic(jobs, args.procs)
-        cols = ["L", "out_len", "identity", "target", "draws", "noop", "aligns", "X", "I", "D", "M"]
-        arr = {c: np.array([r[c] for r in res]) for c in cols}
-        arr["with_q"] = np.array([j[2] for j in jobs])
-        for L in (300, 1000, 3000):
-            sel = [r for r, j in zip(res, jobs) if j[0] == L and j[2]]
-            arr[f"qhist_{L}"] = np.sum([r["qh"] for r in sel], axis=0) if sel else np.zeros((3, 94), np.int64)
-            selall = [r for r, j in zip(res, jobs) if j[0] == L]
-            arr[f"ins_hist_{L}"] = np.sum([r["ins_hist"] for r in selall], axis=0)
-        np.savez_compressed(os.path.join(HERE, "badread_reference_stats.npz"), **arr)
+        for model in args.models.split(","):
+            stochastic_fixture(model, args.reads_q, args.reads_noq, args.procs)
+            print("G6", model, "done", flush=True)
     print("golden fixtures written to", HERE)
 
 

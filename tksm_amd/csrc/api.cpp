@@ -111,7 +111,7 @@ struct tksmseq_ctx : ContigLookup {
         w_scratch, w_records, w_istats, w_dstats, w_sums, w_fullpool;
     unsigned long long full_pool_bytes = 1ull << 30;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_svi, f_svk, f_sva;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_frag2;
     bool force_slow = false;
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
@@ -706,7 +706,9 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     P.mode = badread ? 1 : 0; P.fastq = p->fastq ? 1 : 0;
     P.quirk_perfect = (badread && p->perfect_of_badread) ? 1 : 0;
     P.compute_q = (badread && p->compute_qual && p->fastq && !P.quirk_perfect) ? 1 : 0;
-    P.ablate = getenv("TKSMSEQ_ABLATE") ? atoi(getenv("TKSMSEQ_ABLATE")) : 0;
+#ifdef TKSM_ABLATE
+    P.ablate = getenv("TKSMSEQ_ABLATE") ? atoi(getenv("TKSMSEQ_ABLATE")) : 0;     // diagnostic build only (make ablate)
+#endif
     P.lcap = lcap; P.ncap = ncap; P.s_lcap = s_lcap; P.s_ncap = s_ncap; P.trace_words = trace_words; P.cap_num = cap_num; P.cap_den = cap_den; P.cap_add = cap_add;
     tk::SimBuffers O{};
     O.raw_len = ctx->w_rawlen.as<uint32_t>(); O.slot_off = ctx->w_slotoff.as<uint64_t>(); O.scratch = ctx->w_scratch.as<uint8_t>();
@@ -759,6 +761,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_frag.ensure(n * (size_t)lcap + 64));
         HIPCHK(ctx, ctx->f_nb.ensure(n * (size_t)lcap * 2 + 64));
         HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
+        FB.fw2 = ((lcap + 15) / 16 + 1 + 3) & ~3;
+        HIPCHK(ctx, ctx->f_frag2.ensure(n * (size_t)FB.fw2 * 4 + 64));
         for (int z = 0; z < 2; z++) {
             HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
             HIPCHK(ctx, ctx->f_jcols[z].ensure(tot_jc * 16 + 64));
@@ -776,7 +780,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_counters.ensure(256));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
-        FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>();
+        FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.st_frag2 = ctx->f_frag2.as<uint32_t>();
         FB.trace = ctx->f_trace.p; FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         HIPCHK(ctx, ctx->f_defer.ensure(n * 8 + 64));
@@ -817,10 +821,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             return hipMemcpyAsync(ctx->f_geo.p, hrg.data(), hrg.size() * sizeof(tk::RangeGeo), hipMemcpyHostToDevice, s);
         };
         HIPCHK(ctx, place_ranges());
-        HIPCHK(ctx, ctx->f_svi.ensure(n * 128 + 64));
-        HIPCHK(ctx, ctx->f_svk.ensure(n * 64 + 64));
-        HIPCHK(ctx, ctx->f_sva.ensure(n * 1024 + 64));
-        FB.sv_i = ctx->f_svi.as<uint16_t>(); FB.sv_kind = ctx->f_svk.as<uint8_t>(); FB.sv_alt = ctx->f_sva.as<uint4>();
         std::vector<uint32_t> hcnt((size_t)FB.n_ranges * 32);
         // length buckets over the sorted read order: each bucket gets its own LDS geometry
         struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; bool hbm; };
@@ -899,6 +899,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             kinds.push_back(-1);
             if (rounds == 0) {
                 for (const Bucket& bk : buckets)
+                    HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, 0, 0, 0, bk.hbm, s));
+                for (const Bucket& bk : buckets)
                     HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, 0, 0, 0, bk.wpw, bk.hbm, s));
             } else if (revive) {
                 // the deferred long reads build their q-score jobs now, all in this one round
@@ -912,6 +914,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                     // few reads left: the round is bound by launch and single-wave latency, not by occupancy -- one
                     // launch with the geometry of the longest bucket instead of one per bucket
                     const Bucket& bk = buckets.back();
+                    if (!revived) HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, total, bk.lcap, 1, 0, FB.n_ranges, bk.hbm, s));
                     HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, total, bk.lcap, bk.ncap, 1, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
                 } else {
                 size_t bi = 0;
@@ -926,6 +929,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                         c1++;
                     }
                     const uint32_t cntw = hprefix[c1] - hprefix[c];
+                    if (cntw && !revived)
+                        HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, 1, c, c1, buckets[bi].hbm, s));
                     if (cntw)
                         HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, buckets[bi].ncap, 1, c, c1, buckets[bi].wpw, buckets[bi].hbm, s));
                     c = c1;

@@ -112,9 +112,10 @@ struct ReadState {
     double errors, target, est;
     int32_t change_count;
     uint32_t n_base, aln_no;
-    int16_t resume_src, resume_j;   // draw (lane of its round) and slot to resume at; src < 0: none in progress
-    uint8_t stage;                  // 0 error loop, 1 waiting for the q-score alignment, 2 done, 3 error loop done, q-score alignment deferred
-    uint8_t pending, slow, pad;
+    int16_t resume_src, resume_j;   // resume_j > 0: draw n_base was interrupted by a re-estimation after its slot resume_j - 1 (resume_src unused)
+    uint8_t stage;                  // 0 error loop, 1 waiting for the q-score alignment, 2 done, 3 error loop done, q-score alignment deferred,
+                                    // 4 error loop done in this round (k_loop), trims / q-score job / output still to do (k_err)
+    uint8_t pending, slow, pad;     // pending: 1 an alignment result waits to be applied, 2 k_loop asks k_err for an alignment job
     int32_t st_draws, st_aligns;
     uint32_t job;
     int32_t raw_len;
@@ -140,6 +141,9 @@ struct FastBuffers {
     uint8_t* st_frag;                 // [n_reads][lcap]
     uint16_t* st_nb;                  // [n_reads][lcap]
     unsigned long long* st_fplanes;   // [n_reads][fw][2] 2-bit planes of the padded fragment, {lo, hi} word pairs
+    uint32_t* st_frag2;               // [n_reads][fw2] the padded fragment, 16 bases per word, first base in the top bits: what the
+                                      // error loop (k_loop, one LANE per read) keeps in LDS and cuts its k-mers from
+    int fw2;
     uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, m}
     // [n_reads][cw] one 16-byte record per 8 columns of the joined window: {bits 0-3 of the columns' window shifts,
     // low | high << 8 bits of the columns' 2-bit base codes | bit 4 of the shifts << 16, low / high code bit of the 32 fragment rows that follow
@@ -162,7 +166,6 @@ struct FastBuffers {
     // stay dense as the reads finish (fewer pages touched, no empty waves)
     const uint32_t* base_cur; const uint32_t* base_prev;
     const RangeGeo* geo_cur; const RangeGeo* geo_prev;   // [n_ranges]
-    uint16_t* sv_i; uint8_t* sv_kind; uint4* sv_alt;                // [n_reads][64] draws of an interrupted round
     uint32_t* slow_list;              // [n_reads]
     // reads longer than defer_len wait (stage 3) with their q-score alignment until the regular rounds are over
     uint2* defer_list;                // [n_reads] {read, range}; counters[1] counts
@@ -185,6 +188,11 @@ hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelV
 hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView& em, const IdentView& im, const SimParams& p,
                        const SimBuffers& o, const FastBuffers& fb, int waves_per_wg, hipStream_t s);
 int err_lds_bytes(int lcap, int ncap, int waves_per_wg, bool state_in_hbm);
+// error loop, one lane per read: reads order[begin .. begin+count) (from_jobs = 0) or the reads of the previous round's jobs
+// of ranges [c0, c1) (from_jobs = 1); words = fragment words per lane held in LDS (0: fragments stay in HBM)
+int loop_lds_bytes(int lcap);
+hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
+                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, bool frag_in_hbm, hipStream_t s);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
                       int from_jobs, uint32_t c0, uint32_t c1, int waves_per_wg, bool state_in_hbm, hipStream_t s);

@@ -960,6 +960,23 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
         c.x = ((c.x >> 1) ^ (c.x >> 2)) & 0x03030303u; c.y = ((c.y >> 1) ^ (c.y >> 2)) & 0x03030303u;
         *reinterpret_cast<uint2*>(gfrag + t) = c;
     }
+    // ... and once more packed, 16 bases per word with the first base in the top bits, for the error loop (k_loop cuts a
+    // k-mer's table index out of two consecutive words); bases past L are zero
+    {
+        uint32_t* f2 = FB.st_frag2 + r * (size_t)FB.fw2;
+        for (int w = lane; w < FB.fw2; w += 64) {
+            uint32_t word = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int t = 16 * w + 4 * q;
+                uint32_t c = t < P.lcap ? *reinterpret_cast<const uint32_t*>(frag + t) : 0u;
+                if (t + 4 > L) c = t >= L ? 0u : c & (0xffffffffu >> (8 * (t + 4 - L)));
+                const uint32_t codes4 = ((c >> 1) ^ (c >> 2)) & 0x03030303u;
+                word |= ((codes4 * 0x40100401u) >> 24) << (24 - 8 * q);
+            }
+            f2[w] = word;
+        }
+    }
     // code planes, 64 positions per pair of words: lane q keeps the pair of word q, one 16-byte store per lane then;
     // the words past the fragment are zero (the alignment's window runs into them)
     bool dirty = false;
@@ -1166,6 +1183,158 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
     return idx | (__ballot(fail) ? 0x80000000u : 0u);
 }
 
+// ---- k_loop: the error loop (py/tksm_badread.py:351-403), one LANE per read.
+// A read's loop is a serial chain: draw -> k-mer -> alternative -> (19 % of the draws) slots applied one by one, each
+// adding est^1.5-weighted errors that decide when the loop stops.  A wave cannot make one chain faster, but it can run 64
+// of them: every lane owns one read from its current draw to its next re-estimation point (every 25th applied change) or to
+// the end of its loop, in plain per-lane code; the wave leaves when all of its reads have got there.  Per lane in LDS: the
+// padded fragment at 2 bits per base (a k-mer's table index is a shift of two words); the slot codes stay in HBM (read
+// and written only by the 19 % of the draws that change something).  What a draw needs from the model comes from the
+// 128 KB {first, last} threshold table (81 % of the draws end there: the k-mer itself) and, for the rest, the k-mer's
+// 128-byte threshold row and the chosen alternative's 16-byte slot encodings.
+// A read that stops at a re-estimation point asks k_err for an alignment job (pending = 2); one whose loop has ended goes on
+// to its trims / q-score job / output there (stage 4).  k_err walks the same list of reads right after this kernel.
+template <bool FRAG_LDS>
+__global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
+                                              uint32_t begin, uint32_t count, int W, int from_jobs, uint32_t c0, uint32_t c1) {
+    uint32_t* lf = reinterpret_cast<uint32_t*>(lds_raw);      // [W][64]: word w of lane l at w * 64 + l (conflict-free)
+    const int lane = threadIdx.x;
+    const uint32_t widx = blockIdx.x * 64u + (uint32_t)lane;
+    bool act = widx < count;
+    uint32_t r = 0;
+    if (act) {
+        if (!from_jobs) r = order[begin + widx];
+        else {
+            const uint32_t target = FB.prefix[c0] + widx;
+            uint32_t lo2 = c0, hi2 = c1 - 1;
+            while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2 + 1) >> 1; if (FB.prefix[mid] <= target) lo2 = mid; else hi2 = mid - 1; }
+            r = FB.prev_meta[4ull * (FB.base_prev[lo2] + (target - FB.prefix[lo2]))];
+        }
+    }
+    ReadState* sp = FB.state + r;
+    ReadState S{};
+    if (act) S = *sp;
+    act = act && S.stage == 0 && !S.slow;
+    const int k = EM.k;
+    const int L = S.raw_len + 2 * k;
+    const uint32_t* f2 = FB.st_frag2 + (size_t)r * FB.fw2;
+    if (FRAG_LDS) {
+        // the lane's own fragment words (rows are zero beyond the fragment; W is the bucket's longest)
+        for (int w = 0; w < W; w += 4) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (act) v = *reinterpret_cast<const uint4*>(f2 + w);
+            lf[(w + 0) * 64 + lane] = v.x;
+            if (w + 1 < W) lf[(w + 1) * 64 + lane] = v.y;
+            if (w + 2 < W) lf[(w + 2) * 64 + lane] = v.z;
+            if (w + 3 < W) lf[(w + 3) * 64 + lane] = v.w;
+        }
+    }
+    uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
+    const uint64_t g = P.first_read + (uint64_t)r * P.stride;
+    const double frag_len = (double)L, target = S.target;
+    const double rcp_len = rcp_refined(act ? frag_len : 1.0);
+    double errors = S.errors;
+    int change_count = S.change_count;
+    uint32_t n = S.n_base, aln_no = S.aln_no;
+    int resume_j = S.resume_j, st_draws = S.st_draws;
+    double est_keep = S.est;
+    if (act && S.pending == 1) {                               // apply the re-estimation result (py/tksm_badread.py:412-432)
+        const uint32_t mt = S.res_mt, cols = S.res_cols;
+        if (S.res_fail) {
+            // the alignment left the band representation: the read takes the byte-exact wave-wide kernel
+            sp->slow = 1;
+            atomicAdd(&FB.counters[4], 1u);
+            FB.slow_list[atomicAdd(&FB.counters[2], 1u)] = r;
+            act = false;
+        } else {
+            const double ident = cols ? (double)mt / (double)cols : 0.0;
+            if (L <= 1000) errors = (1.0 - ident) * frag_len;
+            else {
+                const double estimated = (1.0 - ident) * frag_len;
+                const double weight = 1000.0 / frag_len;
+                errors = estimated * weight + errors * (1.0 - weight);
+            }
+            aln_no++;
+        }
+    }
+    const uint32_t kmer_range = (uint32_t)(L - k);            // max_kmer_index + 1
+    const long long loop_limit = 100ll * L;
+    const uint32_t kmask = (1u << (2 * k)) - 1u;
+    int cc25 = change_count % 25;
+    enum { RUN = 0, NEED_ALN = 1, DONE = 2, IDLE = 3 };
+    int st = act ? RUN : IDLE;
+    while (__ballot(st == RUN) != 0ull) {
+        if (st != RUN) continue;
+        double est = est_keep;
+        if (resume_j == 0) {
+            // stop rules at the top of an iteration (:353-367)
+            est = 1.0 - div_inrange(errors, frag_len, rcp_len);
+            if ((double)change_count > 0.9 * frag_len || est <= target) { st = DONE; st_draws = (int)n; continue; }
+            if ((long long)n + 1 > loop_limit) { st = DONE; st_draws = (int)loop_limit; continue; }
+        }
+        const Ph4 d = philox(P.seed, g, ST_DRAW, n);
+        const int i = (int)__umulhi(d.x, kmer_range);
+        // the k-mer's table index: first base in the high bits
+        int kidx;
+        {
+            const int w = i >> 4, o = i & 15;
+            const uint32_t hi = FRAG_LDS ? lf[w * 64 + lane] : f2[w], lo = FRAG_LDS ? lf[(w + 1) * 64 + lane] : f2[w + 1];
+            kidx = (int)((uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask);
+        }
+        int kind = 0;                                         // 0 no-op, 1 a draw that may change something
+        uint4 alt = make_uint4(0u, 0u, 0u, 0u);
+        if (EM.type == 0) kind = 2;
+        else {
+            const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
+            const uint2 pp2 = EM.pself2[kidx];                // {first threshold, last threshold}
+            const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, pp2.x, pp2.y, na, d.y);
+            if (a == na) kind = 2;
+            else if (a == 0 && EM.alt0_noop) kind = 0;        // the k-mer itself
+            else { alt = EM.alts_enc[(size_t)kidx * EM.max_alts + a]; kind = ((alt.x | alt.y | alt.z | alt.w) & 0x80008000u) ? 1 : 0; }
+        }
+        if (kind == 2) {                                      // add_one_random_change (:199-213)
+            const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
+            const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
+            const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
+            alt = random_change_enc(kidx, k, type, pos, base4, side, r3);
+            kind = 1;
+        }
+        if (kind) {
+            // slots in order (:378-403): applied if the slot differs from the original base and the position is pristine
+            uint32_t cur[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) cur[jj] = (jj < k && jj >= resume_j && (draw_slot(alt, jj) >> 15)) ? (uint32_t)gnb[i + jj] : 1u;
+            const double f15 = est * sqrt_inrange(est);
+            int stop_at = -1;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                if (cur[jj] == 0u && stop_at < 0) {
+                    const uint32_t e = draw_slot(alt, jj);
+                    gnb[i + jj] = (uint16_t)(e | 0x8000u);
+                    change_count++;
+                    const int len_j = (int)((e >> 12) & 7u);
+                    errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
+                    if (++cc25 == 25) { cc25 = 0; stop_at = jj; }       // ALIGNMENT_INTERVAL
+                }
+            }
+            if (stop_at >= 0) {
+                st = NEED_ALN;
+                if (stop_at + 1 < k) { resume_j = stop_at + 1; est_keep = est; }    // the rest of this draw follows the alignment
+                else { resume_j = 0; n++; }
+                continue;
+            }
+        }
+        resume_j = 0;
+        n++;
+    }
+    if (st == NEED_ALN || st == DONE) {
+        sp->errors = errors; sp->est = est_keep; sp->change_count = change_count; sp->n_base = n; sp->aln_no = aln_no;
+        sp->resume_src = -1; sp->resume_j = (int16_t)resume_j; sp->st_draws = st_draws;
+        sp->pending = st == NEED_ALN ? 2 : 0;
+        sp->stage = st == NEED_ALN ? 0 : 4;
+    }
+}
+
 // ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (job staging / alignment ops).
 // STATE_IN_HBM (long reads): the fragment and its slot codes stay in HBM and are edited in place -- a round touches ~130
 // candidate positions and a 1000-slot window, so staging the whole fragment costs more than it saves, and its LDS
@@ -1199,6 +1368,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     }
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
+    if (S.stage == 0 && S.pending != 2) return;               // (nothing asked of this visit)
     uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
     const int per_wave = STATE_IN_HBM ? lds_ncap + 128 : lds_lcap * 3 + lds_ncap + 128;
     uint8_t* lds_wave = lds_raw + (size_t)wave * per_wave;
@@ -1213,260 +1383,41 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const int cap = __builtin_amdgcn_readfirstlane((int)((O.slot_off[r + 1] - slot) >> 1));
     uint8_t* out_seq = O.scratch + slot;
     uint8_t* out_qual = out_seq + cap;
-    // the draws of the round that was interrupted by the re-estimation come back with the state (no regeneration)
-    int sv_i = 0, sv_kind = 0; uint4 sv_alt = make_uint4(0u, 0u, 0u, 0u);
-    if (S.stage == 0 && S.resume_src >= 0) {
-        sv_i = FB.sv_i[r * 64 + lane]; sv_kind = FB.sv_kind[r * 64 + lane]; sv_alt = FB.sv_alt[r * 64 + lane];
-    }
     if (!STATE_IN_HBM) {
         const uint8_t* gfrag0 = FB.st_frag + r * (size_t)P.lcap;
         for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag0 + t);
         for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
     }
     wave_sync();
-#ifdef TKSM_ABLATE
-    if (P.ablate == 1) return;
-#endif
     uint32_t status = 0;
     const double frag_len = (double)L;
-    double errors = S.errors;
+    const double errors = S.errors;
     const double target = S.target;
-    int change_count = __builtin_amdgcn_readfirstlane(S.change_count), st_draws = __builtin_amdgcn_readfirstlane(S.st_draws),
-        st_aligns = __builtin_amdgcn_readfirstlane(S.st_aligns);
-    uint32_t n_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.n_base), aln_no = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.aln_no);
+    const int change_count = __builtin_amdgcn_readfirstlane(S.change_count), st_draws = __builtin_amdgcn_readfirstlane(S.st_draws);
+    int st_aligns = __builtin_amdgcn_readfirstlane(S.st_aligns);
+    const uint32_t n_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.n_base), aln_no = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.aln_no);
     double identity = 1.0;
 
     if (S.stage == 0) {
-        bool resume = S.resume_src >= 0;
-        if (S.pending) {                                   // apply the re-estimation result (py/tksm_badread.py:412-432)
-            const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
-            if (fail) { go_slow(FB, r, lane, 0); return; }
-            const double ident = cols ? (double)mt / (double)cols : 0.0;
-            if (L <= 1000) errors = (1.0 - ident) * frag_len;
-            else {
-                const double estimated = (1.0 - ident) * frag_len;
-                const double weight = 1000.0 / frag_len;
-                errors = estimated * weight + errors * (1.0 - weight);
-            }
-            aln_no++;
+        // k_loop stopped this read at a re-estimation point (py/tksm_badread.py:405-432): its window -- the whole fragment,
+        // or a random 1000-base window of a longer one -- becomes an alignment job for k_aln
+        st_aligns++;
+        int p0 = 0, nrows = L;
+        if (L > 1000) {
+            const uint32_t w = philox(P.seed, g, ST_ALNPOS, aln_no).x;
+            p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
+            nrows = 1000;
         }
-        const int max_kmer_index = L - 1 - k;
-        const long long loop_limit = 100ll * L;
-        bool done = false, need_aln = false;
-        int r_src = 0, r_j = 0; double r_est = 0.0;
-        const double rcp_len = rcp_refined(frag_len);
-        int cc25 = change_count % 25;                       // changes since the last re-estimation point
-        if (!resume && !S.pending)
-            if ((double)change_count > 0.9 * frag_len || 1.0 - errors / frag_len <= target) done = true;
-        while (!done && !need_aln) {
-            const uint32_t n = n_base + (uint32_t)lane;
-            const bool live = (long long)n + 1 <= loop_limit;
-            int i, kind = 0;                              // kind: 0 no-op, 1 a draw that changes something
-            uint4 alt = make_uint4(0u, 0u, 0u, 0u);
-            if (resume) { i = sv_i; kind = sv_kind; alt = sv_alt; }
-            else {
-            const Ph4 d = philox(P.seed, g, ST_DRAW, n);
-            i = (int)__umulhi(d.x, (uint32_t)(max_kmer_index + 1));
-#ifdef TKSM_ABLATE
-            if (P.ablate == 6) { if (i == -12345 || d.y == 77u) FB.counters[15] = d.z + d.w; return; }
-#endif
-            if (live) {
-                int kidx = 0; bool valid = true;
-                for (int jj = 0; jj < k; jj++) kidx = (kidx << 2) | (int)frag[i + jj];      // 2-bit codes; only plain ACGT reads come here
-#ifdef TKSM_ABLATE
-                if (P.ablate == 7) { if (kidx == -12345) FB.counters[15] = d.z + d.w + d.y; return; }
-                if (P.ablate == 8) { const uint2 q2 = EM.pself2[kidx]; if (q2.x == 12345u && q2.y == d.y) FB.counters[15] = d.z + d.w; return; }
-#endif
-                if (EM.type == 0 || !valid) kind = 2;
-                else {
-                    const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
-                    // the first threshold (the k-mer itself, ~81 % of all draws) comes from a compact 64 KB array
-                    const uint2 pp2 = EM.pself2[kidx];   // {first threshold, last threshold}
-                    const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, pp2.x, pp2.y, na, d.y);
-                    if (a == na) kind = 2;
-                    else if (a == 0 && EM.alt0_noop) kind = 0;      // the k-mer itself: no need to fetch its packed form
-                    else { alt = EM.alts_enc[(size_t)kidx * EM.max_alts + a]; kind = ((alt.x | alt.y | alt.z | alt.w) & 0x80008000u) ? 1 : 0; }
-                }
-                if (kind == 2) {
-                    const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
-                    const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
-                    const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
-                    alt = random_change_enc(kidx, k, type, pos, base4, side, r3);
-                    kind = 1;
-                }
-            }
-            }
-#ifdef TKSM_ABLATE
-            if (P.ablate == 2) return;
-#endif
-            unsigned long long mask = __ballot(live && kind != 0);
-            const unsigned long long dead = __ballot(!live);
-            if (resume) mask &= ~((1ull << S.resume_src) - 1ull);
-            // ---- every accepted draw is evaluated by its own lane against the slots as they are now ...
-            wave_sync();
-            const bool acc = (mask >> lane) & 1ull;
-            SlotEval ev = eval_draw(nb, k, i, alt, acc);
-            // ... which is exact unless an earlier accepted draw of this round touches an overlapping window (rare);
-            // those, and the draw being resumed, are re-evaluated at their turn
-            unsigned long long depm = 0ull;
-            {
-                bool dep = false;
-                unsigned long long mm = mask;
-                while (mm) {
-                    const int s2 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mm));
-                    mm &= mm - 1;
-                    const int i2 = __builtin_amdgcn_readlane(i, s2);
-                    dep |= lane > s2 && abs(i - i2) < k;
-                }
-                depm = __ballot(acc && dep);
-                if (resume) depm |= 1ull << S.resume_src;
-            }
-#ifdef TKSM_ABLATE
-            if (P.ablate == 3) return;
-#endif
-            double est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
-            // slot writes of the processed draws are deferred: every lane keeps the mask of its own draw and all of
-            // them are written at once (before a dependent draw is evaluated, and at the end of the round)
-            uint32_t wm_mine = 0u;
-            auto flush_writes = [&]() {
-                if (wm_mine) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++)
-                        if ((wm_mine >> jj) & 1u) {
-                            const uint16_t v = (uint16_t)((ev.e[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
-                            nb[i + jj] = v;
-                            if (!STATE_IN_HBM) gnb[i + jj] = v;      // the copy in HBM follows slot by slot: no dense write-back
-                        }
-                    wm_mine = 0u;
-                }
-            };
-            while (mask) {
-                const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-                uint32_t am_s, lens_s;
-                double est = est_cur;
-                int jj0 = 0;
-                const bool isdep = (depm >> src) & 1ull;
-                if (isdep) {
-                    // sequential evaluation of this one draw: lanes 0..k-1 take its k slots
-                    flush_writes();
-                    wave_sync();
-                    const int ai = __builtin_amdgcn_readlane(i, src);
-                    uint4 aalt;
-                    aalt.x = (uint32_t)__builtin_amdgcn_readlane((int)alt.x, src); aalt.y = (uint32_t)__builtin_amdgcn_readlane((int)alt.y, src);
-                    aalt.z = (uint32_t)__builtin_amdgcn_readlane((int)alt.z, src); aalt.w = (uint32_t)__builtin_amdgcn_readlane((int)alt.w, src);
-                    if (resume) { jj0 = S.resume_j; est = S.est; resume = false; }
-                    uint32_t enc = 0; int len = 1; bool app = false;
-                    if (lane < k && lane >= jj0) {
-                        enc = draw_slot(aalt, lane);
-                        len = (int)((enc >> 12) & 7u);
-                        app = (enc >> 15) && nb[ai + lane] == 0;
-                        enc |= 0x8000u;
-                    }
-                    am_s = (uint32_t)__ballot(app);
-                    // lengths of the applied slots, 3 bits each
-                    uint32_t lv = app ? (uint32_t)len << (3 * lane) : 0u;
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) lv |= __shfl_xor(lv, o, 64);
-                    lens_s = __builtin_amdgcn_readfirstlane(lv);
-                    // hand the encodings to lane src so that the common write path below applies
-                    const uint32_t myenc = enc;
-                    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                    {
-                        const uint32_t a0 = __builtin_amdgcn_readlane(myenc, 0), a1 = __builtin_amdgcn_readlane(myenc, 1);
-                        const uint32_t a2 = __builtin_amdgcn_readlane(myenc, 2), a3 = __builtin_amdgcn_readlane(myenc, 3);
-                        const uint32_t a4 = __builtin_amdgcn_readlane(myenc, 4), a5 = __builtin_amdgcn_readlane(myenc, 5);
-                        const uint32_t a6 = __builtin_amdgcn_readlane(myenc, 6), a7 = __builtin_amdgcn_readlane(myenc, 7);
-                        e0 = a0 | (a1 << 16); e1 = a2 | (a3 << 16); e2 = a4 | (a5 << 16); e3 = a6 | (a7 << 16);
-                    }
-                    if (lane == src) { ev.e[0] = e0; ev.e[1] = e1; ev.e[2] = e2; ev.e[3] = e3; }
-                } else {
-                    am_s = __builtin_amdgcn_readlane(ev.am, src);
-                    lens_s = __builtin_amdgcn_readlane(ev.lens, src);
-                }
-                if (am_s) {
-                    const double f15 = est * sqrt_inrange(est);
-                    uint32_t rem = am_s;
-                    int last = -1;
-                    const int cnt = __builtin_popcount(am_s);
-                    if (cc25 + cnt < 25) {
-                        // no re-estimation point inside this draw (the common case)
-                        while (rem) {
-                            const int jj = __builtin_ctz(rem);
-                            rem &= rem - 1;
-                            const int len_j = (int)((lens_s >> (3 * jj)) & 7u);
-                            errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
-                        }
-                        last = 31 - __builtin_clz(am_s);
-                        change_count += cnt; cc25 += cnt;
-                    } else {
-                        while (rem) {
-                            const int jj = __builtin_ctz(rem);
-                            rem &= rem - 1;
-                            last = jj;
-                            change_count++;
-                            const int len_j = (int)((lens_s >> (3 * jj)) & 7u);
-                            const int new_errors = len_j < 2 ? 1 : len_j - 1;
-                            errors += (double)new_errors * f15;
-                            if (++cc25 == 25) { cc25 = 0; need_aln = true; r_src = src; r_j = jj + 1; r_est = est; break; }
-                        }
-                    }
-                    wm_mine = lane == src ? (am_s & ((2u << last) - 1u)) : wm_mine;
-                    if (need_aln) {                            // the round's draws travel with the state
-                        FB.sv_i[r * 64 + lane] = (uint16_t)i; FB.sv_kind[r * 64 + lane] = (uint8_t)kind; FB.sv_alt[r * 64 + lane] = alt;
-                        break;
-                    }
-                    est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
-                }
-                // stop rules at the top of the next iteration (also after a resumed draw that applied nothing more:
-                // the re-estimation changed `errors`)
-                if ((double)change_count > 0.9 * frag_len || est_cur <= target) {
-                    done = true; st_draws = (int)n_base + src + 1; break;
-                }
-                mask &= mask - 1;
-            }
-            flush_writes();
-            wave_sync();
-#ifdef TKSM_ABLATE
-            if (P.ablate == 22) return;
-#endif
-            if (!done && !need_aln) {
-                if (dead) { done = true; st_draws = (int)loop_limit; }
-                else n_base += 64;
-            }
-        }
-        wave_sync();
-#ifdef TKSM_ABLATE
-        if (P.ablate == 4) return;
-#endif
-        if (need_aln) {
-            st_aligns++;
-            int p0 = 0, nrows = L;
-            if (L > 1000) {
-                const uint32_t w = philox(P.seed, g, ST_ALNPOS, aln_no).x;
-                p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
-                nrows = 1000;
-            }
-            int m = 0;
-            const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
-            if (m > min(lds_ncap, (int)FB.geo_cur[pos / FB.rs].ncap)) {   // output slot overflow: the host reruns with larger slots
-                finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
-                if (lane == 0) FB.state[r].stage = 2;
-                return;
-            }
-#ifdef TKSM_ABLATE
-            if (P.ablate == 5) return;
-#endif
-            if (job >> 31) { go_slow(FB, r, lane, 1); return; }
-            if (lane == 0) {
-                S.errors = errors; S.est = r_est; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
-                S.resume_src = (int16_t)r_src; S.resume_j = (int16_t)r_j; S.pending = 1; S.stage = 0;
-                S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
-                FB.state[r] = S;
-            }
+        int m = 0;
+        const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
+        if (m > min(lds_ncap, (int)FB.geo_cur[pos / FB.rs].ncap)) {   // output slot overflow: the host reruns with larger slots
+            finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
+            if (lane == 0) FB.state[r].stage = 2;
             return;
         }
-    } else {
-        st_draws = S.st_draws;
+        if (job >> 31) { go_slow(FB, r, lane, 1); return; }
+        if (lane == 0) { ReadState* sp = FB.state + r; sp->pending = 1; sp->st_aligns = st_aligns; sp->job = job; }
+        return;
     }
 
     // ---- :434-437 trims and the joined sequence (both stages)
@@ -1483,7 +1434,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (m > jcap) { status |= 1; lo = hi = 0; }
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
-    if (S.stage == 0 && want_q && L > FB.defer_len) {
+    if (S.stage == 4 && want_q && L > FB.defer_len) {
         // A q-score alignment spans the whole read: on one lane, up to thousands of columns -- in the round its read
         // happens to finish in it would set the duration of k_aln for everybody, and the last visit of k_err would be
         // one more small launch.  Reads wait here (stage 3): all q-score alignments and all last visits run together
@@ -1498,7 +1449,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         }
         return;
     }
-    if ((S.stage == 0 || S.stage == 3) && want_q) {
+    if ((S.stage == 4 || S.stage == 3) && want_q) {
         int m1 = m;
         const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m1, lds_ncap, aux, nullptr, 0, 0, lane);
         if (job >> 31) { go_slow(FB, r, lane, 2); return; }
@@ -1522,9 +1473,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         wave_sync();
         const int margins = (QM.kmer_size - 1) / 2;
         const uint32_t hmask = (uint32_t)QM.n_slots - 1u;
-#ifdef TKSM_ABLATE
-        if (P.ablate == 30) hi = lo;
-#endif
         for (int i2 = lo + lane; i2 < hi; i2 += 64) {
             const int d = max(0, max(margins - i2, i2 + margins - (m - 1)));     // window shrunk symmetrically at the ends
             int row = -1; uint32_t roff = 0, rcnt = 0;
@@ -1602,9 +1550,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         identity = 1.0 - errors / frag_len;
     }
     int m2 = m;
-#ifdef TKSM_ABLATE
-    if (P.ablate != 31)
-#endif
     (void)join_job(FB, 0, r, 0, 0, frag, nb, 0, L, m2, lds_ncap, aux, out_seq, lo, hi, lane);
     if (P.quirk_perfect) identity = 1.0;
     finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
@@ -2516,6 +2461,21 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((count + wpw - 1) / wpw), dim3(64 * wpw), lds, s, b, em, qm, p, o, fb, order, begin, count, lds_lcap,
                        lds_ncap, from_jobs, c0, c1);
+    return hipGetLastError();
+}
+int loop_lds_bytes(int lcap) { return ((lcap + 15) / 16 + 1) * 256; }
+hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
+                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, bool frag_in_hbm, hipStream_t s) {
+    if (!count) return hipSuccess;
+    const int W = (lcap + 15) / 16 + 1;
+    if (frag_in_hbm) {
+        hipLaunchKernelGGL(k_loop<false>, dim3((count + 63) / 64), dim3(64), 0, s, em, p, fb, order, begin, count, W, from_jobs, c0, c1);
+    } else {
+        const int lds = loop_lds_bytes(lcap);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_loop<true>, dim3((count + 63) / 64), dim3(64), lds, s, em, p, fb, order, begin, count, W, from_jobs, c0, c1);
+    }
     return hipGetLastError();
 }
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s) {
