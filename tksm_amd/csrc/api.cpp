@@ -104,7 +104,7 @@ struct tksmseq_ctx : ContigLookup {
     bool em_uniform = false, em_alt0 = false;
     TailModelHost tail; uint64_t tail_version = 0;
     DevBuf d_tail_lx, d_tail_ly, d_tail_cdf, d_tail_chain;
-    DevBuf d_pself, d_cdf32, d_cdf, d_alts, d_altenc, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
+    DevBuf d_pself, d_pseg, d_cdf32, d_cdf, d_alts, d_altenc, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
@@ -182,7 +182,7 @@ int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out) {
     c->total_alloc = src->total_alloc; c->total_bases = src->total_bases; c->pool_blocks = src->pool_blocks;
     c->d_packed.borrow(src->d_packed); c->d_blocktab.borrow(src->d_blocktab); c->d_pool.borrow(src->d_pool); c->d_contigs.borrow(src->d_contigs);
     c->em = src->em; c->qm = src->qm; c->idm = src->idm; c->em_uniform = src->em_uniform; c->em_alt0 = src->em_alt0;
-    c->d_pself.borrow(src->d_pself); c->d_cdf32.borrow(src->d_cdf32); c->d_cdf.borrow(src->d_cdf); c->d_alts.borrow(src->d_alts); c->d_altenc.borrow(src->d_altenc);
+    c->d_pself.borrow(src->d_pself); c->d_pseg.borrow(src->d_pseg); c->d_cdf32.borrow(src->d_cdf32); c->d_cdf.borrow(src->d_cdf); c->d_alts.borrow(src->d_alts); c->d_altenc.borrow(src->d_altenc);
     c->d_nalts.borrow(src->d_nalts); c->d_qkeys.borrow(src->d_qkeys); c->d_qoff.borrow(src->d_qoff); c->d_qcnt.borrow(src->d_qcnt);
     c->d_qcdf.borrow(src->d_qcdf); c->d_qq.borrow(src->d_qq); c->d_qtab.borrow(src->d_qtab); c->d_qent.borrow(src->d_qent);
     c->d_qpairs.borrow(src->d_qpairs); c->d_qguide.borrow(src->d_qguide);
@@ -334,6 +334,9 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
         std::vector<uint32_t> ps(nk * 2);
         for (size_t i = 0; i < nk; i++) { ps[2 * i] = c32[i * 32]; ps[2 * i + 1] = ctx->em.nalts[i] ? c32[i * 32 + ctx->em.nalts[i] - 1] : 0u; }
         if ((rc = upload(ctx, ctx->d_pself, ps))) return rc;
+        std::vector<uint32_t> sg(nk * 4);                     // thresholds 0, 8, 16, 24 of every row (kernels.h ErrModelView::pseg)
+        for (size_t i = 0; i < nk; i++) for (int q = 0; q < 4; q++) sg[4 * i + q] = c32[i * 32 + 8 * q];
+        if ((rc = upload(ctx, ctx->d_pseg, sg))) return rc;
     }
     if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
     {
@@ -696,7 +699,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
 
     const tk::BatchView B = batch_view(b);
     const tk::RefView R = ref_view(ctx);
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>(), ctx->d_altenc.as<uint4>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>(), ctx->d_pseg.as<uint4>(), ctx->d_altenc.as<uint4>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
                        ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>()};
@@ -897,26 +900,15 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, hipMemsetAsync((void*)FB.job_cnt, 0, (size_t)FB.n_ranges * 128, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            if (rounds == 0) {
-                for (const Bucket& bk : buckets)
-                    HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, 0, 0, 0, bk.hbm, s));
-                for (const Bucket& bk : buckets)
-                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), bk.begin, bk.count, bk.lcap, bk.ncap, 0, 0, 0, bk.wpw, bk.hbm, s));
-            } else if (revive) {
-                // the deferred long reads build their q-score jobs now, all in this one round
+            if (revive) {
+                // the reads whose error loop has ended (all of them by now) build their q-score jobs, or -- without q-scores --
+                // write their output, all in this one round
                 const Bucket& bk = buckets.back();
                 HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, n_deferred, bk.lcap, bk.ncap, 2, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
                 revive = false;
-            } else {
-                // one wave per job of the previous round; ranges are chunks of the sorted order, so a bucket is a run of ranges
-                const uint32_t total = hprefix[FB.n_ranges];
-                if (total <= ctx->small_round || total * 16ull < n) {
-                    // few reads left: the round is bound by launch and single-wave latency, not by occupancy -- one
-                    // launch with the geometry of the longest bucket instead of one per bucket
-                    const Bucket& bk = buckets.back();
-                    if (!revived) HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, total, bk.lcap, 1, 0, FB.n_ranges, bk.hbm, s));
-                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, total, bk.lcap, bk.ncap, 1, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
-                } else {
+            } else if (revived) {
+                // last visits: q-score lookups and output, one wave per q-score job; ranges are chunks of the sorted order,
+                // so a bucket is a run of ranges
                 size_t bi = 0;
                 uint32_t c = 0;
                 while (c < FB.n_ranges) {
@@ -929,13 +921,16 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                         c1++;
                     }
                     const uint32_t cntw = hprefix[c1] - hprefix[c];
-                    if (cntw && !revived)
-                        HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, 1, c, c1, buckets[bi].hbm, s));
                     if (cntw)
                         HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, cntw, buckets[bi].lcap, buckets[bi].ncap, 1, c, c1, buckets[bi].wpw, buckets[bi].hbm, s));
                     c = c1;
                 }
-                }
+            } else {
+                // the error loops of all reads that are still running, one lane each (round 0: every read, in sorted order;
+                // later: the reads of the previous round's jobs), then this round's jobs packed for k_aln, one lane each
+                if (rounds == 0) HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, (uint32_t)n, lcap, 0, 0, 0, s));
+                else HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
+                HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(1);

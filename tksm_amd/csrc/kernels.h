@@ -38,6 +38,8 @@ struct ErrModelView {
     const uint8_t* nalts;
     const uint2* pself2;    // [4^k] {first, last} threshold of every row (cache-resident, 128 KB)
     const uint32_t* cdf32;  // [4^k][32] the same thresholds padded to 128-byte rows (max_alts <= 32 only)
+    const uint4* pseg;      // [4^k] thresholds 0, 8, 16 and 24 of every row: a draw's first-level lookup in k_loop (k-mer itself /
+                            // which 8-threshold segment of cdf32 to read)
     const uint4* alts_enc;  // [4^k][max_alts] the alternatives as the fast pipeline applies them: eight 16-bit slot
                             // encodings (length << 12 | 2-bit codes), bit 15 = the slot differs from the k-mer's base
 };
@@ -190,12 +192,14 @@ hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView&
 int err_lds_bytes(int lcap, int ncap, int waves_per_wg, bool state_in_hbm);
 // error loop, one lane per read: reads order[begin .. begin+count) (from_jobs = 0) or the reads of the previous round's jobs
 // of ranges [c0, c1) (from_jobs = 1); words = fragment words per lane held in LDS (0: fragments stay in HBM)
-int loop_lds_bytes(int lcap);
+int loop_lds_words(int lcap);
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
-                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, bool frag_in_hbm, hipStream_t s);
+                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
                       int from_jobs, uint32_t c0, uint32_t c1, int waves_per_wg, bool state_in_hbm, hipStream_t s);
+// this round's alignment jobs (ids below n_jobs; per-range counts in fb.job_cnt) packed into block records, one lane per job
+hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, hipStream_t s);
 hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s);

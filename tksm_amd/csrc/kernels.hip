@@ -1187,28 +1187,32 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
 // A read's loop is a serial chain: draw -> k-mer -> alternative -> (19 % of the draws) slots applied one by one, each
 // adding est^1.5-weighted errors that decide when the loop stops.  A wave cannot make one chain faster, but it can run 64
 // of them: every lane owns one read from its current draw to its next re-estimation point (every 25th applied change) or to
-// the end of its loop, in plain per-lane code; the wave leaves when all of its reads have got there.  Per lane in LDS: the
-// padded fragment at 2 bits per base (a k-mer's table index is a shift of two words); the slot codes stay in HBM (read
-// and written only by the 19 % of the draws that change something).  What a draw needs from the model comes from the
-// 128 KB {first, last} threshold table (81 % of the draws end there: the k-mer itself) and, for the rest, the k-mer's
-// 128-byte threshold row and the chosen alternative's 16-byte slot encodings.
+// the end of its loop, in plain per-lane code; the wave leaves when all of its reads have got there.
+// A draw's table reads depend on each other (k-mer -> thresholds -> alternative), and a lane cannot hide its own latency, so
+// draws are taken four at a time: the four k-mers, then the four first-level threshold entries, then -- only for the draws
+// that change something -- the 8 thresholds of the segment the draw falls in and the slot codes under the k-mer, then the
+// alternatives' slot encodings: three rounds of loads per four draws.  The draws are then applied in order; whatever
+// follows a stop (re-estimation point, end of the loop) is dropped and drawn again on the next visit.
+// Per lane in LDS: the first Wl words of the padded fragment at 2 bits per base (longer fragments read the rest from HBM); the
+// slot codes stay in HBM (read and written only by the draws that change something).
 // A read that stops at a re-estimation point asks k_err for an alignment job (pending = 2); one whose loop has ended goes on
 // to its trims / q-score job / output there (stage 4).  k_err walks the same list of reads right after this kernel.
-template <bool FRAG_LDS>
+constexpr int LOOP_B = 6;
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
-                                              uint32_t begin, uint32_t count, int W, int from_jobs, uint32_t c0, uint32_t c1) {
-    uint32_t* lf = reinterpret_cast<uint32_t*>(lds_raw);      // [W][64]: word w of lane l at w * 64 + l (conflict-free)
+                                              uint32_t begin, uint32_t count, int Wl, int from_jobs, uint32_t c0, uint32_t c1) {
+    uint32_t* lf = reinterpret_cast<uint32_t*>(lds_raw);      // [Wl][64]: word w of lane l at w * 64 + l (conflict-free)
     const int lane = threadIdx.x;
     const uint32_t widx = blockIdx.x * 64u + (uint32_t)lane;
     bool act = widx < count;
-    uint32_t r = 0;
+    uint32_t r = 0, rc = 0;                                   // the read and its range of the sorted order
     if (act) {
-        if (!from_jobs) r = order[begin + widx];
+        if (!from_jobs) { r = order[begin + widx]; rc = (begin + widx) / FB.rs; }
         else {
             const uint32_t target = FB.prefix[c0] + widx;
             uint32_t lo2 = c0, hi2 = c1 - 1;
             while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2 + 1) >> 1; if (FB.prefix[mid] <= target) lo2 = mid; else hi2 = mid - 1; }
             r = FB.prev_meta[4ull * (FB.base_prev[lo2] + (target - FB.prefix[lo2]))];
+            rc = lo2;
         }
     }
     ReadState* sp = FB.state + r;
@@ -1218,15 +1222,16 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     const int k = EM.k;
     const int L = S.raw_len + 2 * k;
     const uint32_t* f2 = FB.st_frag2 + (size_t)r * FB.fw2;
-    if (FRAG_LDS) {
-        // the lane's own fragment words (rows are zero beyond the fragment; W is the bucket's longest)
-        for (int w = 0; w < W; w += 4) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (act) v = *reinterpret_cast<const uint4*>(f2 + w);
-            lf[(w + 0) * 64 + lane] = v.x;
-            if (w + 1 < W) lf[(w + 1) * 64 + lane] = v.y;
-            if (w + 2 < W) lf[(w + 2) * 64 + lane] = v.z;
-            if (w + 3 < W) lf[(w + 3) * 64 + lane] = v.w;
+    // rows are zero beyond the fragment; Wl is a multiple of 4 <= fw2; unconditional loads, four in flight (idle lanes read
+    // read 0's row)
+    for (int w = 0; w < Wl; w += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4*>(f2 + min(w + 4 * q, Wl - 4));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ww = min(w + 4 * q, Wl - 4);
+            lf[(ww + 0) * 64 + lane] = v[q].x; lf[(ww + 1) * 64 + lane] = v[q].y; lf[(ww + 2) * 64 + lane] = v[q].z; lf[(ww + 3) * 64 + lane] = v[q].w;
         }
     }
     uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
@@ -1265,73 +1270,173 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     int st = act ? RUN : IDLE;
     while (__ballot(st == RUN) != 0ull) {
         if (st != RUN) continue;
-        double est = est_keep;
-        if (resume_j == 0) {
-            // stop rules at the top of an iteration (:353-367)
-            est = 1.0 - div_inrange(errors, frag_len, rcp_len);
-            if ((double)change_count > 0.9 * frag_len || est <= target) { st = DONE; st_draws = (int)n; continue; }
-            if ((long long)n + 1 > loop_limit) { st = DONE; st_draws = (int)loop_limit; continue; }
-        }
-        const Ph4 d = philox(P.seed, g, ST_DRAW, n);
-        const int i = (int)__umulhi(d.x, kmer_range);
-        // the k-mer's table index: first base in the high bits
-        int kidx;
-        {
-            const int w = i >> 4, o = i & 15;
-            const uint32_t hi = FRAG_LDS ? lf[w * 64 + lane] : f2[w], lo = FRAG_LDS ? lf[(w + 1) * 64 + lane] : f2[w + 1];
-            kidx = (int)((uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask);
-        }
-        int kind = 0;                                         // 0 no-op, 1 a draw that may change something
-        uint4 alt = make_uint4(0u, 0u, 0u, 0u);
-        if (EM.type == 0) kind = 2;
-        else {
-            const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
-            const uint2 pp2 = EM.pself2[kidx];                // {first threshold, last threshold}
-            const int a = cdf_pick(EM.cdf32 + (size_t)kidx * 32, pp2.x, pp2.y, na, d.y);
-            if (a == na) kind = 2;
-            else if (a == 0 && EM.alt0_noop) kind = 0;        // the k-mer itself
-            else { alt = EM.alts_enc[(size_t)kidx * EM.max_alts + a]; kind = ((alt.x | alt.y | alt.z | alt.w) & 0x80008000u) ? 1 : 0; }
-        }
-        if (kind == 2) {                                      // add_one_random_change (:199-213)
-            const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
-            const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
-            const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
-            alt = random_change_enc(kidx, k, type, pos, base4, side, r3);
-            kind = 1;
-        }
-        if (kind) {
-            // slots in order (:378-403): applied if the slot differs from the original base and the position is pristine
-            uint32_t cur[8];
+        // ---- four draws: positions and k-mers (first base in the high bits of the table index)
+        int di[LOOP_B], kidx[LOOP_B];
+        uint32_t dw[LOOP_B], dz[LOOP_B], dv[LOOP_B];
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) cur[jj] = (jj < k && jj >= resume_j && (draw_slot(alt, jj) >> 15)) ? (uint32_t)gnb[i + jj] : 1u;
-            const double f15 = est * sqrt_inrange(est);
-            int stop_at = -1;
+        for (int b = 0; b < LOOP_B; b++) {
+            const Ph4 d = philox(P.seed, g, ST_DRAW, n + (uint32_t)b);
+            di[b] = (int)__umulhi(d.x, kmer_range); dw[b] = d.y; dz[b] = d.z; dv[b] = d.w;
+        }
+#pragma unroll
+        for (int b = 0; b < LOOP_B; b++) {
+            const int w = di[b] >> 4, o = di[b] & 15;
+            const uint32_t hi = w < Wl ? lf[w * 64 + lane] : f2[w], lo = w + 1 < Wl ? lf[(w + 1) * 64 + lane] : f2[w + 1];
+            kidx[b] = (int)((uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask);
+        }
+        // ---- first-level thresholds {t0, t8, t16, t24}: the k-mer itself (t0, ~81 % of the draws) ends here.
+        // Every load below is unconditional and straight-line, so that the four draws' requests are in flight together
+        // (a load inside a divergent region is waited for at the region's end); lanes that do not need one read a common
+        // dummy address (one cache line for the whole wave).
+        int cls[LOOP_B];                                      // 0 no-op, 1 alternative a (thresholds needed), 2 random change, 3 alternative 0
+        uint4 seg[LOOP_B];
+        int nab[LOOP_B];
+#pragma unroll
+        for (int b = 0; b < LOOP_B; b++) { seg[b] = EM.pseg[kidx[b]]; nab[b] = EM.max_alts; }
+        if (!EM.uniform_nalts) {
+#pragma unroll
+            for (int b = 0; b < LOOP_B; b++) nab[b] = (int)EM.nalts[kidx[b]];
+        }
+        int sbase[LOOP_B];
+        uint4 th0[LOOP_B], th1[LOOP_B];
+        struct __attribute__((packed, aligned(4))) W5 { uint32_t v[5]; };
+        W5 nbw[LOOP_B];                                       // the slot codes under the k-mer: 10 u16 from the even position below i
+#pragma unroll
+        for (int b = 0; b < LOOP_B; b++) {
+            cls[b] = EM.type == 0 ? 2 : (dw[b] < seg[b].x ? (EM.alt0_noop ? 0 : 3) : 1);
+            sbase[b] = 8 * ((dw[b] < seg[b].y ? 0 : 1) + (dw[b] < seg[b].z ? 0 : 1) + (dw[b] < seg[b].w ? 0 : 1));
+            const uint4* c4 = reinterpret_cast<const uint4*>(EM.cdf32 + (cls[b] == 1 ? (size_t)kidx[b] * 32 + sbase[b] : (size_t)0));
+            th0[b] = c4[0]; th1[b] = c4[1];
+            const uint16_t* gp = cls[b] != 0 ? gnb + (di[b] & ~1) : FB.st_nb;
+            nbw[b] = *reinterpret_cast<const W5*>(gp);
+        }
+        // ---- the alternatives
+        uint4 alt[LOOP_B];
+#pragma unroll
+        for (int b = 0; b < LOOP_B; b++) {
+            size_t at = 0;
+            if (cls[b] == 1 || cls[b] == 3) {
+                const int na = nab[b];
+                int a = 0;
+                if (cls[b] == 1) {
+                    const uint32_t w = dw[b];
+                    a = sbase[b];
+                    a += !(w < th0[b].x) ? 1 : 0; a += !(w < th0[b].y) ? 1 : 0; a += !(w < th0[b].z) ? 1 : 0; a += !(w < th0[b].w) ? 1 : 0;
+                    a += !(w < th1[b].x) ? 1 : 0; a += !(w < th1[b].y) ? 1 : 0; a += !(w < th1[b].z) ? 1 : 0; a += !(w < th1[b].w) ? 1 : 0;
+                    a = min(a, na);
+                }
+                if (a == na) cls[b] = 2;                      // residual mass: add_one_random_change
+                else if (a == 0 && EM.alt0_noop) cls[b] = 0;
+                else at = (size_t)kidx[b] * EM.max_alts + a;
+            }
+            alt[b] = EM.alts_enc[at];
+        }
+        uint32_t cur[LOOP_B][8];
+#pragma unroll
+        for (int b = 0; b < LOOP_B; b++) {
+            const bool odd = di[b] & 1;
 #pragma unroll
             for (int jj = 0; jj < 8; jj++) {
-                if (cur[jj] == 0u && stop_at < 0) {
-                    const uint32_t e = draw_slot(alt, jj);
-                    gnb[i + jj] = (uint16_t)(e | 0x8000u);
-                    change_count++;
-                    const int len_j = (int)((e >> 12) & 7u);
-                    errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
-                    if (++cc25 == 25) { cc25 = 0; stop_at = jj; }       // ALIGNMENT_INTERVAL
-                }
-            }
-            if (stop_at >= 0) {
-                st = NEED_ALN;
-                if (stop_at + 1 < k) { resume_j = stop_at + 1; est_keep = est; }    // the rest of this draw follows the alignment
-                else { resume_j = 0; n++; }
-                continue;
+                const uint32_t e0 = (nbw[b].v[jj >> 1] >> (16 * (jj & 1))) & 0xffffu, e1 = (nbw[b].v[(jj + 1) >> 1] >> (16 * ((jj + 1) & 1))) & 0xffffu;
+                cur[b][jj] = odd ? e1 : e0;
             }
         }
-        resume_j = 0;
-        n++;
+        // ---- apply in order
+        uint32_t wrote = 0u;                                  // draws of this batch that wrote slots
+#pragma unroll
+        for (int b = 0; b < LOOP_B; b++) {
+            if (st != RUN) break;
+            double est = est_keep;
+            if (resume_j == 0) {
+                // stop rules at the top of an iteration (:353-367)
+                est = 1.0 - div_inrange(errors, frag_len, rcp_len);
+                if ((double)change_count > 0.9 * frag_len || est <= target) { st = DONE; st_draws = (int)n; break; }
+                if ((long long)n + 1 > loop_limit) { st = DONE; st_draws = (int)loop_limit; break; }
+            }
+            if (cls[b] != 0) {
+                uint4 A = (cls[b] == 2) ? make_uint4(0u, 0u, 0u, 0u) : alt[b];
+                if (cls[b] == 2) {                            // add_one_random_change (:199-213)
+                    const uint32_t type = __umulhi(dz[b], 3u), pos = __umulhi(dv[b], (uint32_t)k);
+                    const uint32_t base4 = dv[b] & 3u, side = (dv[b] >> 2) & 1u;
+                    const uint32_t r3 = (((dz[b] & 0xffffu) * 3u) >> 16) + 1u;
+                    A = random_change_enc(kidx[b], k, type, pos, base4, side, r3);
+                }
+                if ((A.x | A.y | A.z | A.w) & 0x80008000u) {
+                    // slot codes read before an overlapping earlier draw of this batch wrote: read them again (rare)
+                    bool stale = false;
+#pragma unroll
+                    for (int b2 = 0; b2 < LOOP_B; b2++) if (b2 < b) stale |= ((wrote >> b2) & 1u) && abs(di[b] - di[b2]) < k;
+                    if (stale) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) if (jj < k) cur[b][jj] = (uint32_t)gnb[di[b] + jj];
+                    }
+                    // slots in order (:378-403): applied if the slot differs from the original base and the position is pristine
+                    const double f15 = est * sqrt_inrange(est);
+                    int stop_at = -1;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        const uint32_t e = draw_slot(A, jj);
+                        if (jj < k && jj >= resume_j && (e >> 15) && cur[b][jj] == 0u && stop_at < 0) {
+                            gnb[di[b] + jj] = (uint16_t)(e | 0x8000u);
+                            wrote |= 1u << b;
+                            change_count++;
+                            const int len_j = (int)((e >> 12) & 7u);
+                            errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
+                            if (++cc25 == 25) { cc25 = 0; stop_at = jj; }       // ALIGNMENT_INTERVAL
+                        }
+                    }
+                    if (stop_at >= 0) {
+                        st = NEED_ALN;
+                        if (stop_at + 1 < k) { resume_j = stop_at + 1; est_keep = est; }    // the rest of this draw follows the alignment
+                        else { resume_j = 0; n++; }
+                        break;
+                    }
+                }
+            }
+            resume_j = 0;
+            n++;
+        }
+    }
+    // ---- a read at a re-estimation point gets an alignment job: id from its range's counter (one atomic per range and wave),
+    // meta record for k_job (which packs the window) and k_aln.  Window: the whole fragment, or a random 1000-base window of a
+    // longer one (py/tksm_badread.py:405-432).
+    int st_aligns = S.st_aligns;
+    uint32_t job = 0;
+    {
+        bool need = st == NEED_ALN;
+        unsigned long long todo = __ballot(need);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t lrc = (uint32_t)__shfl((int)rc, leader, 64);
+            const unsigned long long grp = __ballot(need && rc == lrc);
+            uint32_t base = 0;
+            if (lane == leader) base = FB.base_cur[lrc] + atomicAdd(&FB.job_cnt[lrc * 32u], (uint32_t)__popcll(grp));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (need && rc == lrc) { job = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull)); need = false; }
+            todo &= ~grp;
+        }
+    }
+    if (st == NEED_ALN) {
+        st_aligns++;
+        uint32_t p0 = 0, nrows = (uint32_t)L;
+        if (L > 1000) {
+            p0 = __umulhi(philox(P.seed, g, ST_ALNPOS, aln_no).x, (uint32_t)(L - 1000 + 1));
+            nrows = 1000u;
+        }
+        *reinterpret_cast<uint4*>(FB.job_meta + 4ull * job) = make_uint4(r, p0, nrows, 0u);
     }
     if (st == NEED_ALN || st == DONE) {
         sp->errors = errors; sp->est = est_keep; sp->change_count = change_count; sp->n_base = n; sp->aln_no = aln_no;
-        sp->resume_src = -1; sp->resume_j = (int16_t)resume_j; sp->st_draws = st_draws;
-        sp->pending = st == NEED_ALN ? 2 : 0;
-        sp->stage = st == NEED_ALN ? 0 : 4;
+        sp->resume_src = -1; sp->resume_j = (int16_t)resume_j; sp->st_draws = st_draws; sp->st_aligns = st_aligns;
+        sp->pending = st == NEED_ALN ? 1 : 0;
+        sp->job = job;
+        // a read whose loop has ended waits (stage 3): trims, q-score alignment and output of all reads run together after
+        // the last regular round, at full occupancy (k_err)
+        sp->stage = st == NEED_ALN ? 0 : 3;
+        if (st == DONE) {
+            atomicAdd(&FB.defer_cnt[rc * 32u], 1u);
+            FB.defer_list[atomicAdd(&FB.counters[1], 1u)] = make_uint2(r, rc);
+        }
     }
 }
 
@@ -1368,7 +1473,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     }
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
-    if (S.stage == 0 && S.pending != 2) return;               // (nothing asked of this visit)
+    if (S.stage == 0) return;                                  // still in its error loop (k_loop's business)
     uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
     const int per_wave = STATE_IN_HBM ? lds_ncap + 128 : lds_lcap * 3 + lds_ncap + 128;
     uint8_t* lds_wave = lds_raw + (size_t)wave * per_wave;
@@ -1398,28 +1503,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const uint32_t n_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.n_base), aln_no = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.aln_no);
     double identity = 1.0;
 
-    if (S.stage == 0) {
-        // k_loop stopped this read at a re-estimation point (py/tksm_badread.py:405-432): its window -- the whole fragment,
-        // or a random 1000-base window of a longer one -- becomes an alignment job for k_aln
-        st_aligns++;
-        int p0 = 0, nrows = L;
-        if (L > 1000) {
-            const uint32_t w = philox(P.seed, g, ST_ALNPOS, aln_no).x;
-            p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
-            nrows = 1000;
-        }
-        int m = 0;
-        const uint32_t job = join_job(FB, 1, r, pos, 0, frag, nb, p0, nrows, m, lds_ncap, aux, nullptr, 0, 0, lane);
-        if (m > min(lds_ncap, (int)FB.geo_cur[pos / FB.rs].ncap)) {   // output slot overflow: the host reruns with larger slots
-            finish_read(B, P, O, r, raw_len, 0, 0.0, 1u, st_draws, change_count, st_aligns, L, m, 0, 0, errors, target, lane);
-            if (lane == 0) FB.state[r].stage = 2;
-            return;
-        }
-        if (job >> 31) { go_slow(FB, r, lane, 1); return; }
-        if (lane == 0) { ReadState* sp = FB.state + r; sp->pending = 1; sp->st_aligns = st_aligns; sp->job = job; }
-        return;
-    }
-
     // ---- :434-437 trims and the joined sequence (both stages)
     int start_trim, end_trim;
     {
@@ -1434,22 +1517,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (m > jcap) { status |= 1; lo = hi = 0; }
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
-    if (S.stage == 4 && want_q && L > FB.defer_len) {
-        // A q-score alignment spans the whole read: on one lane, up to thousands of columns -- in the round its read
-        // happens to finish in it would set the duration of k_aln for everybody, and the last visit of k_err would be
-        // one more small launch.  Reads wait here (stage 3): all q-score alignments and all last visits run together
-        // after the last regular round, at full occupancy (FB.defer_len = 0; a larger value defers only longer reads).
-        if (lane == 0) {
-            S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
-            S.resume_src = -1; S.pending = 0; S.stage = 3; S.st_draws = st_draws; S.st_aligns = st_aligns;
-            FB.state[r] = S;
-            const uint32_t rc3 = pos / FB.rs;
-            atomicAdd(&FB.defer_cnt[rc3 * 32u], 1u);
-            FB.defer_list[atomicAdd(&FB.counters[1], 1u)] = make_uint2((uint32_t)r, rc3);
-        }
-        return;
-    }
-    if ((S.stage == 4 || S.stage == 3) && want_q) {
+    if (S.stage == 3 && want_q) {
         int m1 = m;
         const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m1, lds_ncap, aux, nullptr, 0, 0, lane);
         if (job >> 31) { go_slow(FB, r, lane, 2); return; }
@@ -1918,6 +1986,133 @@ DEV uint32_t range_of_job(const FastBuffers& FB, uint32_t job0) {
     while (rng < hi2) { const uint32_t mid = (rng + hi2 + 1) >> 1; if (FB.base_cur[mid] <= job0) rng = mid; else hi2 = mid - 1; }
     return rng;
 }
+// ---- k_job: packs the windows of this round's alignment jobs into the block records k_aln reads, one LANE per job.
+// All lanes walk their windows slot by slot in lockstep (slot s of every window in iteration s), so everything a lane
+// reads comes at wave-uniform offsets of its own rows: 32 slot codes (64 bytes) per 32 iterations, one pair of fragment-plane
+// words per 64 -- unconditional, prefetched loads; what differs between lanes is how many columns a slot emits (0 .. 5
+// symbols) and therefore when a record of 8 columns is complete: records are kept in registers and stored four at a
+// time (one 64-byte line).  Record layout: see FastBuffers::job_cols; `sh` of a slot's first column = rows the window top moves,
+// top = max(1, slot + 1 - 31) (the guided band).
+struct __attribute__((packed, aligned(4))) U4a { uint32_t x, y, z, w; };
+__global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
+    const int lane = threadIdx.x;
+    const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
+    const uint32_t rng = range_of_job(FB, job0);
+    const uint32_t rbase = FB.base_cur[rng];
+    const uint32_t in_rng = FB.job_cnt[rng * 32u];
+    if (in_rng <= job0 - rbase) return;                               // whole wave beyond the range's job count
+    const bool act = job < n_jobs && job - rbase < in_rng;
+    uint4 meta = make_uint4(0u, 0u, 0u, 0u);
+    if (act) meta = *reinterpret_cast<const uint4*>(FB.job_meta + 4ull * job);
+    const uint32_t r = meta.x;
+    const int p0 = (int)meta.y, n = (int)(meta.z & 0x7fffffffu);
+    const RangeGeo G = FB.geo_cur[rng];
+    uint4* jc = FB.job_cols + G.jc_off + (size_t)(job - rbase) * G.cw;
+    const int ncap_l = (int)G.ncap;
+    const uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
+    const ulonglong2* fp = reinterpret_cast<const ulonglong2*>(FB.st_fplanes + (size_t)r * 2 * FB.fw);   // {lo, hi} per 64 positions
+    const int base = p0 & ~1;                                         // slot codes are fetched from an even position
+    const int skip = p0 - base;
+    int nmax = act ? n + skip : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    // fragment planes: a window of four 64-position words sliding with the slot position, the next word in flight
+    const int wbase = base >> 6;
+    const int wlast = FB.fw - 1;
+    ulonglong2 W0 = fp[min(wbase, wlast)], W1 = fp[min(wbase + 1, wlast)], W2 = fp[min(wbase + 2, wlast)], W3 = fp[min(wbase + 3, wlast)], Wn = W3;
+    int w0idx = wbase;                                                // word index of W0
+    auto bits32 = [&](int pos, bool hi) -> uint32_t {                 // planes bits [pos, pos + 32), pos >= 64 * w0idx
+        const int off = pos - 64 * w0idx;
+        const unsigned long long a0 = hi ? W0.y : W0.x, a1 = hi ? W1.y : W1.x, a2 = hi ? W2.y : W2.x;
+        return off < 64 ? lo32(funnel128(a0, a1, off)) : lo32(funnel128(a1, a2, off - 64));
+    };
+    if (act) {
+        const int w = p0 >> 6, s2 = p0 & 63;                          // the first 64 window rows (w is w0idx or w0idx + ... = wbase)
+        FB.job_win[2ull * job] = funnel128(W0.x, W1.x, s2);
+        FB.job_win[2ull * job + 1] = funnel128(W0.y, W1.y, s2);
+        (void)w;
+    }
+    int t = 1, col = 0;
+    uint32_t shw = 0u, clo = 0u, chi = 0u, shx = 0u, ea = 0u, eb = 0u; int adv = 0;
+    uint4 rb0 = make_uint4(0u, 0u, 0u, 0u), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+    bool fail = false;
+    for (int s0 = 0; s0 < nmax; s0 += 32) {
+        // 32 slot codes of every lane (lanes past their window re-read its start), and every other time the next plane word
+        const int src = (s0 <= n + skip) ? base + s0 : base;
+        const U4a* cp = reinterpret_cast<const U4a*>(gnb + src);
+        const U4a c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+        if ((s0 & 63) == 0) Wn = fp[min(wbase + (s0 >> 6) + 4, wlast)];
+        const uint32_t cw[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const int s = s0 + q, p = s - skip;                       // p: slot within the window
+            const bool on = act && p >= 0 && p < n;
+            const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+            const int pos = base + s;                                 // fragment position of the slot
+            int len = 0; uint32_t syms = 0u;
+            if (on) {
+                len = code ? (int)((code >> 12) & 7u) : 1;
+                const int bo = pos - 64 * w0idx;                      // 0 .. 63
+                syms = code ? code & 0x3ffu : (uint32_t)(((W0.x >> bo) & 1ull) | (((W0.y >> bo) & 1ull) << 1));
+            }
+            int sh = 0;
+            if (len > 0) { const int tn = max(1, p + 1 - 31); sh = tn - t; fail |= sh > 31; }
+            int x = 0;
+            while (__ballot(x < len) != 0ull) {
+                if (x < len) {
+                    const int c8 = col & 7;
+                    if (c8 == 0) {                                    // a block starts: the 32 fragment rows after the window
+                        const int o = p0 + t - 1 + 64;
+                        ea = bits32(o, false); eb = bits32(o, true);
+                    }
+                    const uint32_t shc = x == 0 ? (uint32_t)(sh & 31) : 0u;
+                    if (x == 0) t += sh;
+                    const uint32_t sym = (syms >> (2 * x)) & 3u;
+                    shw |= (shc & 15u) << (4 * c8); shx |= (shc >> 4) << c8; clo |= (sym & 1u) << c8; chi |= (sym >> 1) << c8; adv += (int)shc;
+                    col++;
+                    if ((col & 7) == 0) {
+                        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), ea, eb);
+                        shw = clo = chi = shx = 0u; adv = 0;
+                        const int tq = (col >> 3) - 1;                // record index
+                        if (col <= ncap_l) {
+                            if ((tq & 3) == 0) rb0 = rec; else if ((tq & 3) == 1) rb1 = rec; else if ((tq & 3) == 2) rb2 = rec;
+                            else { rb3 = rec; uint4* d = jc + (tq & ~3); d[0] = rb0; d[1] = rb1; d[2] = rb2; d[3] = rb3; }
+                        }
+                    }
+                }
+                x++;
+            }
+            // the window of plane words follows the slot position
+            if (((pos + 1) & 63) == 0) { W0 = W1; W1 = W2; W2 = W3; W3 = Wn; w0idx++; }
+        }
+    }
+    if (!act) return;
+    const int m = col;
+    if (m <= ncap_l) {
+        // the last, partial record and the complete ones still in registers
+        const int tq = m >> 3;
+        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), ea, eb);
+        if ((m & 7) != 0) { if ((tq & 3) == 0) rb0 = rec; else if ((tq & 3) == 1) rb1 = rec; else if ((tq & 3) == 2) rb2 = rec; else rb3 = rec; }
+        const int cnt = (tq & 3) + ((m & 7) != 0 ? 1 : 0);
+        uint4* d = jc + (tq & ~3);
+        if (cnt > 0) d[0] = rb0;
+        if (cnt > 1) d[1] = rb1;
+        if (cnt > 2) d[2] = rb2;
+        if (cnt > 3) d[3] = rb3;
+    }
+    FB.job_meta[4ull * job + 3] = (uint32_t)(m > ncap_l ? 0 : m);
+    if (m > ncap_l) {
+        // the window outgrew the range's rows (insertion-heavy read): the host reruns the batch with larger slots
+        O.status[r] |= 1u; O.out_len[r] = 0; O.rec_len[r] = 0; O.identity[r] = 0.0;
+        FB.state[r].stage = 2;
+    } else if (fail) {
+        // a window shift above 31 rows between two columns: the byte-exact wave-wide kernel takes the read
+        FB.state[r].slow = 1;
+        atomicAdd(&FB.counters[5], 1u);
+        FB.slow_list[atomicAdd(&FB.counters[2], 1u)] = r;
+    }
+}
+
 DEV void load_job(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act, AlnJob& J, uint32_t& r) {
     J.act = act;
     r = 0;
@@ -2463,19 +2658,20 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
                        lds_ncap, from_jobs, c0, c1);
     return hipGetLastError();
 }
-int loop_lds_bytes(int lcap) { return ((lcap + 15) / 16 + 1) * 256; }
+// fragment words per lane kept in LDS: the whole padded fragment of the longest read, at most LOOP_WL_MAX words (1280
+// bases, 20 KB per wave: 8 waves per CU); the words beyond come from HBM
+constexpr int LOOP_WL_MAX = 80;
+int loop_lds_words(int lcap) { return std::min(LOOP_WL_MAX, (((lcap + 15) / 16 + 1) + 3) & ~3); }
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
-                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, bool frag_in_hbm, hipStream_t s) {
+                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
-    const int W = (lcap + 15) / 16 + 1;
-    if (frag_in_hbm) {
-        hipLaunchKernelGGL(k_loop<false>, dim3((count + 63) / 64), dim3(64), 0, s, em, p, fb, order, begin, count, W, from_jobs, c0, c1);
-    } else {
-        const int lds = loop_lds_bytes(lcap);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_loop<true>, dim3((count + 63) / 64), dim3(64), lds, s, em, p, fb, order, begin, count, W, from_jobs, c0, c1);
-    }
+    const int Wl = std::min(loop_lds_words(lcap), fb.fw2);
+    hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
+    return hipGetLastError();
+}
+hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s) {
+    if (!n_jobs) return hipSuccess;
+    hipLaunchKernelGGL(k_job, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, o, n_jobs);
     return hipGetLastError();
 }
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s) {

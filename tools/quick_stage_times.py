@@ -1,7 +1,9 @@
 import sys, os, time, faulthandler, numpy as np
 faulthandler.dump_traceback_later(90, exit=True)
 _t0 = time.time()
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 import torch
 from tksm_amd import synthetic
 from tksm_amd.sequence import Sequencer
