@@ -1989,10 +1989,12 @@ DEV uint32_t range_of_job(const FastBuffers& FB, uint32_t job0) {
 // ---- k_job: packs the windows of this round's alignment jobs into the block records k_aln reads, one LANE per job.
 // All lanes walk their windows slot by slot in lockstep (slot s of every window in iteration s), so everything a lane
 // reads comes at wave-uniform offsets of its own rows: 32 slot codes (64 bytes) per 32 iterations, one pair of fragment-plane
-// words per 64 -- unconditional, prefetched loads; what differs between lanes is how many columns a slot emits (0 .. 5
-// symbols) and therefore when a record of 8 columns is complete: records are kept in registers and stored four at a
-// time (one 64-byte line).  Record layout: see FastBuffers::job_cols; `sh` of a slot's first column = rows the window top moves,
-// top = max(1, slot + 1 - 31) (the guided band).
+// words per 64 -- unconditional, prefetched loads.  What differs between lanes is how many columns a slot emits (0 .. 5
+// symbols), i.e. when a block of 8 columns is complete; since in every iteration SOME lane completes one, the lanes do not
+// pack a block the moment it is full: column bytes {symbol, window shift} queue up in three registers and every fourth slot
+// each lane packs at most one block (the queue holds 24; a lane that falls behind packs at once, rarely).  Records are
+// kept in registers and stored four at a time (one 64-byte line).  Record layout: FastBuffers::job_cols; the shift of a
+// slot's first column = rows the window top moves, top = max(1, slot + 1 - 31) (the guided band).
 struct __attribute__((packed, aligned(4))) U4a { uint32_t x, y, z, w; };
 __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
     const int lane = threadIdx.x;
@@ -2016,89 +2018,101 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
     int nmax = act ? n + skip : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-    // fragment planes: a window of four 64-position words sliding with the slot position, the next word in flight
+    // fragment planes: five 64-position words sliding with the slot position (W1 holds the current slot: a block is packed up
+    // to ~60 slots after it began, its entering rows lie between the word before the current one and two after), the next in flight
     const int wbase = base >> 6;
     const int wlast = FB.fw - 1;
-    ulonglong2 W0 = fp[min(wbase, wlast)], W1 = fp[min(wbase + 1, wlast)], W2 = fp[min(wbase + 2, wlast)], W3 = fp[min(wbase + 3, wlast)], Wn = W3;
-    int w0idx = wbase;                                                // word index of W0
-    auto bits32 = [&](int pos, bool hi) -> uint32_t {                 // planes bits [pos, pos + 32), pos >= 64 * w0idx
-        const int off = pos - 64 * w0idx;
-        const unsigned long long a0 = hi ? W0.y : W0.x, a1 = hi ? W1.y : W1.x, a2 = hi ? W2.y : W2.x;
-        return off < 64 ? lo32(funnel128(a0, a1, off)) : lo32(funnel128(a1, a2, off - 64));
+    auto fpw = [&](int w) { return fp[min(max(w, 0), wlast)]; };
+    ulonglong2 W0 = fpw(wbase - 1), W1 = fpw(wbase), W2 = fpw(wbase + 1), W3 = fpw(wbase + 2), W4 = fpw(wbase + 3), Wn = W4;
+    int w0idx = wbase - 1;                                            // word index of W0
+    auto bits32 = [&](int pos, bool hi) -> uint32_t {                 // plane bits [pos, pos + 32), 64 * w0idx <= pos < 64 * (w0idx + 3)
+        const int off = pos - 64 * w0idx, wq = off >> 6;
+        const unsigned long long a0 = hi ? W0.y : W0.x, a1 = hi ? W1.y : W1.x, a2 = hi ? W2.y : W2.x, a3 = hi ? W3.y : W3.x;
+        const unsigned long long lo = wq == 0 ? a0 : wq == 1 ? a1 : a2, up = wq == 0 ? a1 : wq == 1 ? a2 : a3;
+        return lo32(funnel128(lo, up, off & 63));
     };
-    if (act) {
-        const int w = p0 >> 6, s2 = p0 & 63;                          // the first 64 window rows (w is w0idx or w0idx + ... = wbase)
-        FB.job_win[2ull * job] = funnel128(W0.x, W1.x, s2);
-        FB.job_win[2ull * job + 1] = funnel128(W0.y, W1.y, s2);
-        (void)w;
+    if (act) {                                                        // the first 64 window rows
+        FB.job_win[2ull * job] = funnel128(W1.x, W2.x, p0 & 63);
+        FB.job_win[2ull * job + 1] = funnel128(W1.y, W2.y, p0 & 63);
     }
-    int t = 1, col = 0;
-    uint32_t shw = 0u, clo = 0u, chi = 0u, shx = 0u, ea = 0u, eb = 0u; int adv = 0;
+    int t = 1, col = 0;                                               // window top after the last column; columns emitted
+    int tk = 1, npend = 0, nrec = 0;                                  // top before the first queued column; queued column bytes; records packed
+    unsigned long long q0 = 0ull, q1 = 0ull, q2 = 0ull;               // the queue: {bits 0-1 symbol, bits 2-6 shift} per column
     uint4 rb0 = make_uint4(0u, 0u, 0u, 0u), rb1 = rb0, rb2 = rb0, rb3 = rb0;
     bool fail = false;
+    auto bit_of_bytes = [](unsigned long long x) { return (uint32_t)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); };
+    auto pack_block = [&](int ncols) {                                // the first (up to 8) queued columns -> one record
+        const unsigned long long v = q0;
+        unsigned long long nb4 = (v >> 2) & 0x0f0f0f0f0f0f0f0full;
+        nb4 = (nb4 | (nb4 >> 4)) & 0x00ff00ff00ff00ffull; nb4 = (nb4 | (nb4 >> 8)) & 0x0000ffff0000ffffull; nb4 = nb4 | (nb4 >> 16);
+        const uint32_t shw = (uint32_t)nb4, shx = bit_of_bytes(v >> 6), clo = bit_of_bytes(v), chi = bit_of_bytes(v >> 1);
+        const int adv = (int)((((v >> 2) & 0x1f1f1f1f1f1f1f1full) * 0x0101010101010101ull) >> 56);
+        const int o = p0 + tk - 1 + 64;                               // the 32 fragment rows after the window at the block's start
+        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), bits32(o, false), bits32(o, true));
+        tk += adv;
+        q0 = q1; q1 = q2; q2 = 0ull; npend -= ncols;
+        const int tq = nrec++;
+        if (8 * tq < ncap_l) {
+            if ((tq & 3) == 0) rb0 = rec; else if ((tq & 3) == 1) rb1 = rec; else if ((tq & 3) == 2) rb2 = rec;
+            else { rb3 = rec; uint4* d = jc + (tq & ~3); d[0] = rb0; d[1] = rb1; d[2] = rb2; d[3] = rb3; }
+        }
+    };
     for (int s0 = 0; s0 < nmax; s0 += 32) {
         // 32 slot codes of every lane (lanes past their window re-read its start), and every other time the next plane word
         const int src = (s0 <= n + skip) ? base + s0 : base;
         const U4a* cp = reinterpret_cast<const U4a*>(gnb + src);
         const U4a c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-        if ((s0 & 63) == 0) Wn = fp[min(wbase + (s0 >> 6) + 4, wlast)];
+        if ((s0 & 63) == 0) Wn = fpw(wbase + (s0 >> 6) + 4);
         const uint32_t cw[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
 #pragma unroll
         for (int q = 0; q < 32; q++) {
             const int s = s0 + q, p = s - skip;                       // p: slot within the window
             const bool on = act && p >= 0 && p < n;
             const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-            const int pos = base + s;                                 // fragment position of the slot
+            const int pos = base + s;                                 // fragment position of the slot (in word W1)
             int len = 0; uint32_t syms = 0u;
             if (on) {
                 len = code ? (int)((code >> 12) & 7u) : 1;
-                const int bo = pos - 64 * w0idx;                      // 0 .. 63
-                syms = code ? code & 0x3ffu : (uint32_t)(((W0.x >> bo) & 1ull) | (((W0.y >> bo) & 1ull) << 1));
+                const int bo = pos & 63;
+                syms = code ? code & 0x3ffu : (uint32_t)(((W1.x >> bo) & 1ull) | (((W1.y >> bo) & 1ull) << 1));
             }
-            int sh = 0;
-            if (len > 0) { const int tn = max(1, p + 1 - 31); sh = tn - t; fail |= sh > 31; }
+            uint32_t shb = 0u;                                        // the slot's first column carries the shift of the window top
+            if (len > 0) {
+                const int tn = max(1, p + 1 - 31), sh = tn - t;
+                fail |= sh > 31;
+                t = tn;
+                shb = (uint32_t)(sh & 31) << 2;
+            }
+            // the slot's symbols join the queue (first one: {symbol, shift}; the others: symbol only)
             int x = 0;
             while (__ballot(x < len) != 0ull) {
                 if (x < len) {
-                    const int c8 = col & 7;
-                    if (c8 == 0) {                                    // a block starts: the 32 fragment rows after the window
-                        const int o = p0 + t - 1 + 64;
-                        ea = bits32(o, false); eb = bits32(o, true);
-                    }
-                    const uint32_t shc = x == 0 ? (uint32_t)(sh & 31) : 0u;
-                    if (x == 0) t += sh;
-                    const uint32_t sym = (syms >> (2 * x)) & 3u;
-                    shw |= (shc & 15u) << (4 * c8); shx |= (shc >> 4) << c8; clo |= (sym & 1u) << c8; chi |= (sym >> 1) << c8; adv += (int)shc;
-                    col++;
-                    if ((col & 7) == 0) {
-                        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), ea, eb);
-                        shw = clo = chi = shx = 0u; adv = 0;
-                        const int tq = (col >> 3) - 1;                // record index
-                        if (col <= ncap_l) {
-                            if ((tq & 3) == 0) rb0 = rec; else if ((tq & 3) == 1) rb1 = rec; else if ((tq & 3) == 2) rb2 = rec;
-                            else { rb3 = rec; uint4* d = jc + (tq & ~3); d[0] = rb0; d[1] = rb1; d[2] = rb2; d[3] = rb3; }
-                        }
-                    }
+                    const uint32_t byte = ((syms >> (2 * x)) & 3u) | (x == 0 ? shb : 0u);
+                    const unsigned long long v = (unsigned long long)byte << (8 * (npend & 7));
+                    const int which = npend >> 3;
+                    q0 |= which == 0 ? v : 0ull; q1 |= which == 1 ? v : 0ull; q2 |= which == 2 ? v : 0ull;
+                    npend++; col++;
                 }
                 x++;
             }
+            // every fourth slot a lane packs one block if it has one; a lane whose queue could overflow with the next slot at once
+            if ((q & 3) == 3) { if (npend >= 8) pack_block(8); }
+            else if (__ballot(npend > 19) != 0ull) { if (npend > 19) pack_block(8); }
             // the window of plane words follows the slot position
-            if (((pos + 1) & 63) == 0) { W0 = W1; W1 = W2; W2 = W3; W3 = Wn; w0idx++; }
+            if (((pos + 1) & 63) == 0) { W0 = W1; W1 = W2; W2 = W3; W3 = W4; W4 = Wn; w0idx++; }
         }
     }
     if (!act) return;
     const int m = col;
+    while (npend >= 8) pack_block(8);
+    if (npend > 0) pack_block(npend);                                 // the last, partial block
     if (m <= ncap_l) {
-        // the last, partial record and the complete ones still in registers
-        const int tq = m >> 3;
-        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), ea, eb);
-        if ((m & 7) != 0) { if ((tq & 3) == 0) rb0 = rec; else if ((tq & 3) == 1) rb1 = rec; else if ((tq & 3) == 2) rb2 = rec; else rb3 = rec; }
-        const int cnt = (tq & 3) + ((m & 7) != 0 ? 1 : 0);
-        uint4* d = jc + (tq & ~3);
+        // the complete records still in registers
+        const int cnt = nrec & 3;
+        uint4* d = jc + (nrec & ~3);
         if (cnt > 0) d[0] = rb0;
         if (cnt > 1) d[1] = rb1;
         if (cnt > 2) d[2] = rb2;
-        if (cnt > 3) d[3] = rb3;
     }
     FB.job_meta[4ull * job + 3] = (uint32_t)(m > ncap_l ? 0 : m);
     if (m > ncap_l) {
