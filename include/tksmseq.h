@@ -172,6 +172,14 @@ int tksmseq_run(tksmseq_ctx* ctx, const tksmseq_batch* batch, const tksmseq_run_
 /* Caller-provided device buffer for the record stream (e.g. a torch tensor); NULL restores the
  * library-owned buffer.  tksmseq_run fails with TKSMSEQ_ENOMEM if it is too small. */
 int tksmseq_set_output_buffer(tksmseq_ctx* ctx, void* device_ptr, uint64_t capacity);
+/* Host threads used to parse MDF text in tksmseq_batch_from_mdf_text (default 1).  The reference's parallel knob is
+ * -t/--threads: multiprocessing.Pool(args.threads) over molecules, py/sequence.py:360-368; here the device does the per-molecule
+ * work and the threads go to the text -> binary batch conversion. */
+int tksmseq_set_host_threads(tksmseq_ctx* ctx, int n);
+/* 1 if `name` resolves to a model file of `kind` ("error", "qscore", "tail") in the built-in directory or $TKSM_MODELS
+ * (set_tksm_models_dicts, py/sequence.py:17-31): the CLI's default-model rule "nanopore2020 if discoverable else random"
+ * (py/sequence.py:86-107). */
+int tksmseq_model_available(const char* name, const char* kind);
 int tksmseq_set_timing(tksmseq_ctx* ctx, int enable);   /* hipEvent per stage, read via result.kernel_ms */
 /* Copies the last result to host memory (records: records_bytes, offsets: n_reads + 1). */
 int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets);

@@ -567,3 +567,44 @@ def test_cli_tail_model_flag(tmp_path, po, oracle_models):
     r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", str(tmp_path / "x.fastq"),
                         "--badread-tail-model", str(bad)], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "tail model" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_devices_list_threads_and_error_path(tmp_path, po, oracle_models):
+    """--devices 0,0 (two device groups, here on the same GPU) with -t 4 parse threads writes the bytes of --devices 0 -t 1;
+    an unwritable output with several batches in flight ends with exit code 1 instead of hanging (workers waiting for
+    the writer are woken); --verbosity / --log-file are honoured."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    d = os.path.join(GOLDEN, "splice_corpus")
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    base = [exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-s", "11", "--batch-bytes", "4096"]
+    one, two = tmp_path / "one.fastq", tmp_path / "two.fastq"
+    r = subprocess.run(base + ["-o", str(one), "--devices", "0", "--in-flight", "1", "-t", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    logf = tmp_path / "run.log"
+    r = subprocess.run(base + ["-o", str(two), "--devices", "0,0", "--in-flight", "2", "-t", "4", "--verbosity", "DEBUG", "--log-file", str(logf)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert one.read_bytes() == two.read_bytes() and len(one.read_bytes()) > 10000
+    log = logf.read_text()
+    assert "2 device group(s) x 2 contexts" in log and "Sequencing:" in log and "[sequence DBG]" in log
+    r = subprocess.run(base + ["-o", str(tmp_path / "q.fastq"), "--verbosity", "OFF"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "Sequencing:" not in r.stderr
+    # the default models are the nanopore2020 pair (py/sequence.py:86-107): same bytes as naming them
+    named = tmp_path / "named.fastq"
+    r = subprocess.run(base + ["-o", str(named), "--devices", "0", "--badread-error-model", "nanopore2020", "--badread-qscore-model", "nanopore2020"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and named.read_bytes() == one.read_bytes()
+    # the other shipped models by name
+    for model in ("nanopore2018", "pacbio2016"):
+        o2 = tmp_path / f"{model}.fastq"
+        r = subprocess.run(base + ["-o", str(o2), "--badread-error-model", model, "--badread-qscore-model", model], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert o2.read_bytes().count(b"\n@") > 100 and o2.read_bytes() != one.read_bytes()
+    # error path: /dev/full fails on write; several small batches, three in flight
+    r = subprocess.run(base + ["-o", "/dev/full", "--skip-qual-compute", "--in-flight", "3", "--batch-bytes", "2048"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 1 and "write failed" in r.stderr
+    r = subprocess.run(base + ["-o", str(tmp_path / "x.fastq"), "--devices", "99"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 1 and "device index out of range" in r.stderr

@@ -47,6 +47,7 @@ SYMBOLS = [
     "tksmseq_batch_free", "tksmseq_run", "tksmseq_set_output_buffer", "tksmseq_set_timing",
     "tksmseq_result_download", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
     "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
+    "tksmseq_set_host_threads", "tksmseq_model_available",
 ]
 
 _lib = None
@@ -81,6 +82,8 @@ def load():
         "tksmseq_load_qscore_model": (C.c_int, [vp, C.c_char_p]),
         "tksmseq_load_tail_model": (C.c_int, [vp, C.c_char_p]),
         "tksmseq_set_tail_model": (C.c_int, [vp, vp]),
+        "tksmseq_set_host_threads": (C.c_int, [vp, C.c_int]),
+        "tksmseq_model_available": (C.c_int, [C.c_char_p, C.c_char_p]),
         "tksmseq_set_identity": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "tksmseq_get_error_model": (C.c_int, [vp, P(i32), P(i32), P(i32), vp, vp, vp]),
         "tksmseq_get_qscore_model": (C.c_int, [vp, P(i32), P(i32), P(u64), vp, vp, vp, vp, vp]),

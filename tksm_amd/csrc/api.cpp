@@ -122,6 +122,7 @@ struct tksmseq_ctx : ContigLookup {
     uint32_t last_rounds = 0, last_slow = 0;
     void* user_out = nullptr; uint64_t user_out_cap = 0;
     bool timing = false;
+    int host_threads = 1;       // host threads for MDF parsing (tksmseq_set_host_threads)
     hipEvent_t ev[6] = {};
     tksmseq_result last{};
     bool have_last = false, have_stats = false;
@@ -186,7 +187,7 @@ int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out) {
     c->d_nalts.borrow(src->d_nalts); c->d_qkeys.borrow(src->d_qkeys); c->d_qoff.borrow(src->d_qoff); c->d_qcnt.borrow(src->d_qcnt);
     c->d_qcdf.borrow(src->d_qcdf); c->d_qq.borrow(src->d_qq); c->d_qtab.borrow(src->d_qtab); c->d_qent.borrow(src->d_qent);
     c->d_qpairs.borrow(src->d_qpairs); c->d_qguide.borrow(src->d_qguide);
-    c->tail = src->tail; c->tail_version = src->tail_version;
+    c->tail = src->tail; c->tail_version = src->tail_version; c->host_threads = src->host_threads;
     c->d_tail_lx.borrow(src->d_tail_lx); c->d_tail_ly.borrow(src->d_tail_ly); c->d_tail_cdf.borrow(src->d_tail_cdf); c->d_tail_chain.borrow(src->d_tail_chain);
     return TKSMSEQ_OK;
 }
@@ -228,6 +229,10 @@ int tksmseq_synchronize(tksmseq_ctx* ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TKSMSEQ_OK;
 }
+
+int tksmseq_set_host_threads(tksmseq_ctx* ctx, int n) { if (!ctx || n < 1) return TKSMSEQ_EINVAL; ctx->host_threads = std::min(n, 64); return TKSMSEQ_OK; }
+
+int tksmseq_model_available(const char* name, const char* kind) { return (name && kind && model_available(name, kind)) ? 1 : 0; }
 
 int tksmseq_set_timing(tksmseq_ctx* ctx, int enable) { if (!ctx) return TKSMSEQ_EINVAL; ctx->timing = enable != 0; return TKSMSEQ_OK; }
 
@@ -566,7 +571,7 @@ int tksmseq_batch_create(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmseq_
 int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out) {
     if (!ctx || (!text && len) || !out) return TKSMSEQ_EINVAL;
     BatchHost h;
-    if (!parse_mdf(text, len, *ctx, h, ctx->err)) return TKSMSEQ_EINVAL;
+    if (!parse_mdf_mt(text, len, *ctx, h, ctx->err, ctx->host_threads)) return TKSMSEQ_EINVAL;
     tksmseq_batch_desc d{};
     d.n_reads = h.reads.size() / 2; d.n_intervals = h.intervals.size() / 4; d.n_mods = h.mods.size() / 2;
     d.n_literals = h.literals.size() / 2; d.literal_bytes = h.literal_pool.size(); d.id_bytes = h.id_pool.size();

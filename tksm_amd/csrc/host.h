@@ -67,5 +67,8 @@ bool read_fasta(const std::string& path, std::vector<FastaRecord>& out, std::str
 // MDF text (py/sequence.py:197-221) -> binary batch; contig_id(name) returns -1 for literals
 struct ContigLookup { virtual int find(const std::string& name) const = 0; virtual ~ContigLookup() {} };
 bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, BatchHost& out, std::string& err);
+// the same on n_threads host threads (pieces cut at molecule headers)
+bool parse_mdf_mt(const char* text, uint64_t len, const ContigLookup& contigs, BatchHost& out, std::string& err, int n_threads);
+bool model_available(const std::string& name, const char* kind);   // resolve_model() finds a file
 
 }  // namespace tkh

@@ -7,6 +7,8 @@
 //                src/interval.h:898-905 (always 5 tab fields)
 #include "host.h"
 
+#include <thread>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -133,6 +135,78 @@ bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, Batc
         p = nl ? nl + 1 : end;
     }
     flush();
+    return true;
+}
+
+// parse_mdf on several threads: the text is cut at molecule headers into one piece per thread, the pieces are parsed
+// side by side and their tables appended with the offsets fixed up.  A literal contig that occurs in two pieces is kept
+// twice (harmless); error messages count lines from the start of the whole text.
+bool parse_mdf_mt(const char* text, uint64_t len, const ContigLookup& contigs, BatchHost& out, std::string& err, int n_threads) {
+    if (n_threads <= 1 || len < (1u << 20)) return parse_mdf(text, len, contigs, out, err);
+    std::vector<uint64_t> cut{0};
+    for (int t = 1; t < n_threads; t++) {
+        uint64_t at = len * (uint64_t)t / (uint64_t)n_threads;
+        if (at <= cut.back()) continue;
+        const char* q = text + at;
+        const char* end = text + len;
+        while (q < end) {                                         // the next line that starts a molecule
+            const char* nl = (const char*)memchr(q, '\n', (size_t)(end - q));
+            if (!nl || nl + 1 >= end) { q = end; break; }
+            q = nl + 1;
+            if (*q == '+') break;
+        }
+        if (q < end && (uint64_t)(q - text) > cut.back()) cut.push_back((uint64_t)(q - text));
+    }
+    cut.push_back(len);
+    const size_t np = cut.size() - 1;
+    if (np <= 1) return parse_mdf(text, len, contigs, out, err);
+    std::vector<BatchHost> parts(np);
+    std::vector<std::string> errs(np);
+    std::vector<char> ok(np, 0);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < np; i++)
+        th.emplace_back([&, i]() { ok[i] = parse_mdf(text + cut[i], cut[i + 1] - cut[i], contigs, parts[i], errs[i]) ? 1 : 0; });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < np; i++)
+        if (!ok[i]) {
+            // the piece counted its own lines: add the lines before it
+            uint64_t before = 0;
+            for (const char* q = text; q < text + cut[i]; q++) before += *q == '\n';
+            err = errs[i];
+            const std::string tag = "MDF line ";
+            if (err.compare(0, tag.size(), tag) == 0) {
+                size_t e = tag.size();
+                unsigned long long ln = 0;
+                while (e < err.size() && err[e] >= '0' && err[e] <= '9') ln = ln * 10 + (unsigned)(err[e++] - '0');
+                err = tag + std::to_string(ln + before) + err.substr(e);
+            }
+            return false;
+        }
+    out = BatchHost();
+    size_t nr = 0, ni = 0, nm = 0, nl = 0, nlp = 0, nip = 0;
+    for (auto& b : parts) { nr += b.reads.size(); ni += b.intervals.size(); nm += b.mods.size(); nl += b.literals.size(); nlp += b.literal_pool.size(); nip += b.id_pool.size(); }
+    if (ni / 4 >= 0x7fffffffull || nm / 2 >= 0x7fffffffull || nip >= 0xffffffffull) { err = "batch too large (split it: < 2^31 intervals/mods per batch)"; return false; }
+    out.reads.reserve(nr); out.ids.reserve(nr); out.intervals.reserve(ni); out.mods.reserve(nm); out.literals.reserve(nl);
+    out.literal_pool.reserve(nlp); out.id_pool.reserve(nip);
+    for (auto& b : parts) {
+        const uint32_t io = (uint32_t)(out.intervals.size() / 4), mo = (uint32_t)(out.mods.size() / 2), lo = (uint32_t)(out.literals.size() / 2);
+        const uint64_t lpo = out.literal_pool.size();
+        const uint32_t ido = (uint32_t)out.id_pool.size();
+        for (size_t q = 0; q < b.reads.size(); q += 2) { out.reads.push_back(b.reads[q] + io); out.reads.push_back(b.reads[q + 1]); }
+        for (size_t q = 0; q < b.ids.size(); q += 2) { out.ids.push_back(b.ids[q] + ido); out.ids.push_back(b.ids[q + 1]); }
+        for (size_t q = 0; q < b.intervals.size(); q += 4) {
+            const uint32_t c = b.intervals[q];
+            out.intervals.push_back((c >> 31) ? (0x80000000u | ((c & 0x7fffffffu) + lo)) : c);
+            out.intervals.push_back(b.intervals[q + 1]); out.intervals.push_back(b.intervals[q + 2]);
+            const uint32_t w = b.intervals[q + 3];
+            out.intervals.push_back((w & 0x80000000u) | ((w & 0x7fffffffu) + mo));
+        }
+        out.mods.insert(out.mods.end(), b.mods.begin(), b.mods.end());
+        for (size_t q = 0; q < b.literals.size(); q += 2) { out.literals.push_back(b.literals[q] + lpo); out.literals.push_back(b.literals[q + 1]); }
+        out.literal_pool.insert(out.literal_pool.end(), b.literal_pool.begin(), b.literal_pool.end());
+        out.id_pool.insert(out.id_pool.end(), b.id_pool.begin(), b.id_pool.end());
+        b = BatchHost();
+    }
     return true;
 }
 

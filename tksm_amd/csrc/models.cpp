@@ -70,6 +70,8 @@ std::string resolve_model(const std::string& name, const char* kind) {
     return name;   // fall through: treated as a path (the reference does the same, py/tksm_badread.py:88-89)
 }
 
+bool model_available(const std::string& name, const char* kind) { return file_exists(resolve_model(name, kind)); }
+
 // ---------------------------------------------------------------------------------------------
 // tiny global alignment with path for align_kmers (strings of length <= ~12)
 // ---------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -37,10 +38,11 @@ namespace {
 
 struct Args {
     std::string input, badread, perfect, output_format, identity = "84.0,99.0,5.5";
-    std::string error_model = "nanopore2020", qscore_model = "nanopore2020", tail_model = "no_noise";
+    std::string error_model, qscore_model, tail_model = "no_noise";      // "": nanopore2020 if discoverable, else random
     std::vector<std::string> references;
     bool skip_qual = false, list = false, help = false;
-    int threads = 1, device = 0, in_flight = 3;
+    int threads = 1, in_flight = 3;
+    std::vector<int> devices{0};
     long long seed = 42;
     uint64_t batch_bytes = 64ull << 20;
     std::string verbosity = "INFO", log_file = "stderr";
@@ -55,7 +57,7 @@ void usage(FILE* f) {
             "usage: sequence [-h] -i INPUT [-r REFERENCES [REFERENCES ...]] [-o BADREAD] [--perfect PERFECT]\n"
             "                [--skip-qual-compute] [-O {fastq,fasta}] [-t THREADS] [--badread-identity BADREAD_IDENTITY]\n"
             "                [--badread-error-model M] [--badread-qscore-model M] [--badread-tail-model M] [--list]\n"
-            "                [-s SEED] [--devices D] [--batch-bytes B] [--in-flight N] [--verbosity L] [--log-file F]\n");
+            "                [-s SEED] [--devices D[,D...]] [--batch-bytes B] [--in-flight N] [--verbosity L] [--log-file F]\n");
 }
 
 // one gzip member (RFC 1952) holding d[0..n): members simply follow each other in a .gz file, so batches -- and pieces of
@@ -87,11 +89,44 @@ struct Writer {
         wrote = wrote || n;
         return fwrite(d, 1, n, f) == n;
     }
-    void close() {
-        if (!f) return;
-        if (gz && !wrote) { std::vector<uint8_t> e; if (gzip_member(nullptr, 0, e)) fwrite(e.data(), 1, e.size(), f); }   // a valid empty .gz
-        fclose(f); f = nullptr;
+    bool close() {                                       // false: the last buffered bytes could not be written
+        if (!f) return true;
+        bool ok = true;
+        if (gz && !wrote) { std::vector<uint8_t> e; if (gzip_member(nullptr, 0, e)) ok = fwrite(e.data(), 1, e.size(), f) == e.size(); }   // a valid empty .gz
+        ok = fclose(f) == 0 && ok;
+        f = nullptr;
+        return ok;
     }
+};
+
+// --verbosity / --log-file (src/module.h:95-122, src/util.h:94-120): levels DEBUG < INFO < WARN < ERROR < OFF; the file is
+// "stderr", "stdout" or a path.  What the reference's Python prints unconditionally (model loading progress, "Loading
+// reference") stays unconditional; the module's own diagnostics go through here.
+struct Logger {
+    enum Level { DEBUG = 0, INFO = 1, WARN = 2, ERROR = 3, OFF = 4 };
+    int level = INFO; FILE* f = stderr; bool own = false; std::mutex m;
+    static int parse(const std::string& v) {
+        static const char* names[] = {"DEBUG", "INFO", "WARN", "ERROR", "OFF"};
+        for (int i = 0; i < 5; i++) if (v == names[i]) return i;
+        return -1;
+    }
+    bool open(const std::string& path) {
+        if (path == "stderr") { f = stderr; return true; }
+        if (path == "stdout") { f = stdout; return true; }
+        FILE* g = fopen(path.c_str(), "a");
+        if (!g) return false;
+        f = g; own = true;
+        return true;
+    }
+    void log(int lv, const char* fmt, ...) __attribute__((format(printf, 3, 4))) {
+        if (lv < level || level == OFF) return;
+        static const char* tag[] = {"DBG", "INF", "WRN", "ERR"};
+        std::lock_guard<std::mutex> l(m);
+        fprintf(f, "[sequence %s] ", tag[lv]);
+        va_list ap; va_start(ap, fmt); vfprintf(f, fmt, ap); va_end(ap);
+        fputc('\n', f); fflush(f);
+    }
+    ~Logger() { if (own) fclose(f); }
 };
 
 // reads a batch of MDF text will produce: the depth column of every molecule header (mdf_generator, py/sequence.py:206-213)
@@ -171,9 +206,31 @@ class Sequencer_module::impl {
             else if (o == "--badread-tail-model") { if (!(v = need(i))) return 2; a.tail_model = v; }
             else if (o == "--list") a.list = true;
             else if (o == "-s" || o == "--seed") { if (!(v = need(i))) return 2; a.seed = atoll(v); }
-            else if (o == "--devices") { if (!(v = need(i))) return 2; a.device = atoi(v); }
-            else if (o == "--batch-bytes") { if (!(v = need(i))) return 2; a.batch_bytes = strtoull(v, nullptr, 10); }
-            else if (o == "--in-flight") { if (!(v = need(i))) return 2; a.in_flight = atoi(v); }
+            else if (o == "--devices") {
+                // comma-separated device list: one group of --in-flight contexts per entry (an entry may repeat)
+                if (!(v = need(i))) return 2;
+                a.devices.clear();
+                const char* q = v;
+                for (;;) {
+                    char* e = nullptr;
+                    const long d = strtol(q, &e, 10);
+                    if (e == q || d < 0 || (*e && *e != ',')) { usage(stderr); fprintf(stderr, "sequence: error: argument --devices: invalid device list: '%s'\n", v); return 2; }
+                    a.devices.push_back((int)d);
+                    if (!*e) break;
+                    q = e + 1;
+                }
+            }
+            else if (o == "--batch-bytes") {
+                if (!(v = need(i))) return 2;
+                char* e = nullptr;
+                a.batch_bytes = strtoull(v, &e, 10);
+                if (e == v || *e || a.batch_bytes < 1) { usage(stderr); fprintf(stderr, "sequence: error: argument --batch-bytes: expected a positive integer, got '%s'\n", v); return 2; }
+            }
+            else if (o == "--in-flight") {
+                if (!(v = need(i))) return 2;
+                a.in_flight = atoi(v);
+                if (a.in_flight < 1) { usage(stderr); fprintf(stderr, "sequence: error: argument --in-flight: expected a positive integer, got '%s'\n", v); return 2; }
+            }
             else if (o == "--verbosity") { if (!(v = need(i))) return 2; a.verbosity = v; }
             else if (o == "--log-file") { if (!(v = need(i))) return 2; a.log_file = v; }
             else { usage(stderr); fprintf(stderr, "sequence: error: unrecognized arguments: %s\n", argv[i]); return 2; }
@@ -218,45 +275,82 @@ public:
         if (sd < 0.0) return die("Error: read identity stdev cannot be negative");
         if (a.badread.empty() && a.perfect.empty()) { usage(stderr); fprintf(stderr, "sequence: error: Must specify either --output or --perfect.\n"); return 2; }
 
-        const auto t_begin = std::chrono::steady_clock::now();
-        tksmseq_ctx* ctx = nullptr;
-        if (tksmseq_create(a.device, &ctx)) return die(std::string("Error: ") + tksmseq_last_error(nullptr));
-        auto fail = [&](const std::string& what) { std::string m = "Error: " + what + ": " + tksmseq_last_error(ctx); tksmseq_destroy(ctx); return die(m); };
-        for (auto& r : a.references) {
-            printf("Loading reference %s...\n", r.c_str());
-            if (tksmseq_reference_add_fasta(ctx, r.c_str())) return fail("loading reference");
+        // utility flags (src/module.h:106-125)
+        Logger log;
+        {
+            const int lv = Logger::parse(a.verbosity);
+            if (lv < 0) return die("Error: unknown verbosity level '" + a.verbosity + "' (choose from DEBUG, INFO, WARN, ERROR, OFF)");
+            log.level = lv;
+            if (!log.open(a.log_file)) return die("Error: cannot open log file " + a.log_file);
         }
+        // $TKSM_MODELS handling of the shim (src/sequence.cpp:38-52) happens in the library's model lookup: the built-in model
+        // directory comes first, then the entries of $TKSM_MODELS in order.  Default models: nanopore2020 if it can be found,
+        // else `random` (py/sequence.py:86-107).
+        if (const char* env = getenv("TKSM_MODELS")) log.log(Logger::DEBUG, "TKSM_MODELS was set to %s; the built-in model directory is searched first", env);
+        else log.log(Logger::DEBUG, "TKSM_MODELS not set: built-in model directory only");
+        if (a.error_model.empty()) a.error_model = tksmseq_model_available("nanopore2020", "error") ? "nanopore2020" : "random";
+        if (a.qscore_model.empty()) a.qscore_model = tksmseq_model_available("nanopore2020", "qscore") ? "nanopore2020" : "random";
+        if (a.threads < 1) a.threads = 1;
+
+        const auto t_begin = std::chrono::steady_clock::now();
         Writer wb, wp;
         bool compute_q = false;
         if (!a.badread.empty()) {
-            if (tksmseq_set_identity(ctx, mean, maxi, sd)) return fail("identity distribution");
-            fprintf(stderr, "\nLoading error model from %s\n", a.error_model.c_str());
-            if (tksmseq_load_error_model(ctx, a.error_model.c_str())) return fail("error model");
-            if (!wb.open(a.badread)) { tksmseq_destroy(ctx); return die("Error: cannot open " + a.badread); }
+            if (!wb.open(a.badread)) return die("Error: cannot open " + a.badread);
             compute_q = !a.skip_qual && wb.fastq;
-            if (compute_q) {
-                fprintf(stderr, "\nLoading qscore model from %s\n", a.qscore_model.c_str());
-                if (tksmseq_load_qscore_model(ctx, a.qscore_model.c_str())) return fail("qscore model");
-            }
-            if (tksmseq_load_tail_model(ctx, a.tail_model.c_str())) return fail("tail model");     // py/sequence.py:343-345
         }
-        if (!a.perfect.empty() && !wp.open(a.perfect)) { tksmseq_destroy(ctx); return die("Error: cannot open " + a.perfect); }
+        if (!a.perfect.empty() && !wp.open(a.perfect)) return die("Error: cannot open " + a.perfect);
         if (!a.badread.empty() && !a.perfect.empty())
-            fprintf(stderr, "note: with both -o and --perfect the reference writes the badread sequence (quals 'K') to the "
-                            "--perfect file (py/sequence.py:317-319); reproduced here\n");
+            log.log(Logger::WARN, "with both -o and --perfect the reference writes the badread sequence (quals 'K') to the "
+                                  "--perfect file (py/sequence.py:317-319); reproduced here");
+
+        // One group of --in-flight contexts per entry of --devices: the first context of a group loads the reference and the
+        // models onto its device, the others share them (tksmseq_clone).  Reads are numbered by the reader, batches go to
+        // whichever context is free, the writer restores MDF order: the output does not depend on the device list.
+        const int n_groups = (int)a.devices.size();
+        const int per_group = std::max(1, std::min(a.in_flight, 8));
+        const int n_workers = n_groups * per_group;
+        std::vector<std::unique_ptr<Worker>> workers;
+        for (int w = 0; w < n_workers; w++) workers.emplace_back(new Worker());
+        auto destroy_all = [&]() {
+            // clones before the contexts they borrow from
+            for (int g = 0; g < n_groups; g++) for (int j = per_group - 1; j >= 0; j--) { tksmseq_ctx*& c = workers[(size_t)g * per_group + j]->ctx; if (c) { tksmseq_destroy(c); c = nullptr; } }
+        };
+        {
+            std::vector<std::string> gerr((size_t)n_groups);
+            std::vector<std::thread> gt;
+            std::mutex out_m;
+            for (int g = 0; g < n_groups; g++)
+                gt.emplace_back([&, g]() {
+                    tksmseq_ctx* ctx = nullptr;
+                    if (tksmseq_create(a.devices[(size_t)g], &ctx)) { gerr[(size_t)g] = std::string("Error: ") + tksmseq_last_error(nullptr); return; }
+                    workers[(size_t)g * per_group]->ctx = ctx;
+                    auto fail = [&](const std::string& what) { gerr[(size_t)g] = "Error: " + what + ": " + tksmseq_last_error(ctx); };
+                    tksmseq_set_host_threads(ctx, a.threads);
+                    for (auto& r : a.references) {
+                        if (g == 0) { std::lock_guard<std::mutex> l(out_m); printf("Loading reference %s...\n", r.c_str()); fflush(stdout); }
+                        if (tksmseq_reference_add_fasta(ctx, r.c_str())) return fail("loading reference");
+                    }
+                    if (!a.badread.empty()) {
+                        if (tksmseq_set_identity(ctx, mean, maxi, sd)) return fail("identity distribution");
+                        if (g == 0) fprintf(stderr, "\nLoading error model from %s\n", a.error_model.c_str());
+                        if (tksmseq_load_error_model(ctx, a.error_model.c_str())) return fail("error model");
+                        if (compute_q) {
+                            if (g == 0) fprintf(stderr, "\nLoading qscore model from %s\n", a.qscore_model.c_str());
+                            if (tksmseq_load_qscore_model(ctx, a.qscore_model.c_str())) return fail("qscore model");
+                        }
+                        if (tksmseq_load_tail_model(ctx, a.tail_model.c_str())) return fail("tail model");     // py/sequence.py:343-345
+                    }
+                    for (int j = 1; j < per_group; j++)
+                        if (tksmseq_clone(ctx, &workers[(size_t)g * per_group + j]->ctx)) return fail("second context");
+                });
+            for (auto& t : gt) t.join();
+            for (auto& e : gerr) if (!e.empty()) { destroy_all(); return die(e); }
+        }
+        log.log(Logger::INFO, "%d device group(s) x %d contexts in flight, %d host thread(s) per batch for MDF parsing", n_groups, per_group, a.threads);
 
         FILE* in = fopen(a.input.c_str(), "rb");
-        if (!in) { tksmseq_destroy(ctx); return die("Error: cannot open " + a.input); }
-        const int n_workers = std::max(1, std::min(a.in_flight, 8));
-        std::vector<std::unique_ptr<Worker>> workers;
-        for (int w = 0; w < n_workers; w++) {
-            workers.emplace_back(new Worker());
-            if (w == 0) workers[w]->ctx = ctx;
-            else if (tksmseq_clone(ctx, &workers[w]->ctx)) {
-                for (int x = 1; x < w; x++) tksmseq_destroy(workers[x]->ctx);
-                return fail("second context");
-            }
-        }
+        if (!in) { destroy_all(); return die("Error: cannot open " + a.input); }
         ChunkQueue queue;
         queue.cap = (size_t)n_workers;
         std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Finished> done;   // by batch number
@@ -267,10 +361,13 @@ public:
             if (!failed.exchange(true)) first_error = msg;
             queue.close();
             done_cv.notify_all();
+            // a worker may be waiting for the writer to release its host buffers: nobody will (the writer stops at the
+            // first error), so wake it -- its wait also checks `failed`
+            for (auto& W : workers) { std::lock_guard<std::mutex> wl(W->m); W->cv.notify_all(); }
         };
         uint64_t n_batches = 0; bool reader_done = false;                                          // guarded by done_m
         // stage clocks (TKSMSEQ_VERBOSE): seconds spent parsing, running, copying, writing, reading
-        const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr;
+        const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr || log.level <= Logger::DEBUG;
         std::mutex clk_m; double clk[6] = {0, 0, 0, 0, 0, 0};
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto add_clk = [&](int k, std::chrono::steady_clock::time_point t0) {
@@ -417,16 +514,15 @@ public:
                             "(summed over workers); write %.2f; read + count %.2f\n", (int)seq, n_workers,
                     std::chrono::duration<double>(now() - t_start).count(), clk[0], clk[1], clk[2], clk[4], clk[3], clk[5]);
         for (auto& W : workers) { tksmseq_host_free(W->host[0]); tksmseq_host_free(W->host[1]); }
-        for (int w = 1; w < n_workers; w++) tksmseq_destroy(workers[w]->ctx);
         const auto t_close = now();
         fclose(in);
-        wb.close(); wp.close();
+        if ((!wb.close() || !wp.close()) && !status) { status = 1; fprintf(stderr, "Error: write failed\n"); }
         const auto t_destroy = now();
-        tksmseq_destroy(ctx);
+        destroy_all();
         if (verbose)
             fprintf(stderr, "[sequence] closing the outputs %.2f s, releasing the device %.2f s\n",
                     std::chrono::duration<double>(t_destroy - t_close).count(), std::chrono::duration<double>(now() - t_destroy).count());
-        if (!status) fprintf(stderr, "Sequencing: %llu reads\n", (unsigned long long)total_reads);
+        if (!status) log.log(Logger::INFO, "Sequencing: %llu reads", (unsigned long long)total_reads);
         return status;
     }
 };
