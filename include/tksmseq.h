@@ -203,6 +203,54 @@ int tksmseq_interleave_records(tksmseq_ctx* ctx, int n_ranks, const void* const*
  * int Sequencer_module::run() (src/sequence.cpp:30-54, src/pimpl.h:5-9) with the CLI of
  * py/sequence.py:34-165; argv[0] is "sequence" as in src/tksm.cpp:164-166.  Returns the process
  * exit code (0 ok, 1 argument / input error). */
+/* ---- molecule-description transforms upstream of Seq (BASELINE config 5), on the device ----------------------------------
+ * Both take a batch and return a new one (free with tksmseq_batch_free) that tksmseq_run accepts directly: the molecule
+ * tables never leave the device between PCR, truncation and sequencing.  Molecules are taken depth-unrolled, as every
+ * C++ module of the reference reads them (stream_mdf(..., true), src/mdf.h:97-105): copies of a depth > 1 molecule
+ * become id_0, id_1, ...  Results depend only on (seed, molecule index), not on batching or the device.
+ *
+ * tksmseq_pcr replaces PCR::perform / do_pcr (src/pcr.cpp:40-89; module src/pcr.cpp:91-260): every cycle copies each
+ * molecule present with probability `efficiency`; a copy gets floor(4/3 error_rate x size) (+1 with the fractional
+ * probability) substitutions at distinct positions, bases uniform in "ACTG", on top of its template's; each copy is
+ * written with probability target_count / ((1 + efficiency)^cycles x molecules); id = template id + "." + cycle.
+ * More than 2 x target_count input molecules: 2 x target_count of them are used (:226-229). */
+typedef struct {
+    uint64_t seed;
+    uint64_t target_count;        /* --molecule-count */
+    int32_t cycles;               /* --cycles (at most 56) */
+    int32_t reserved;
+    double error_rate;            /* --error-rate, before the 4/3 adjustment of src/pcr.cpp:36 */
+    double efficiency;            /* --efficiency */
+} tksmseq_pcr_params;
+int tksmseq_pcr_preset(const char* name, double* error_rate, double* efficiency);   /* -x/--preset, src/pcr.cpp:136-140 */
+int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* params, tksmseq_batch** out);
+
+/* tksmseq_truncate replaces truncate() + truncate_transformer / truncate_transformer_kde (src/truncate.cpp:23-65, :322-351):
+ * NORMAL / LOGNORMAL: keep the first (int)X bases in segment order, X ~ Normal(mu, sigma) / exp(Normal(mu, sigma)), at least
+ * 100 (min_val); KDE: truncation length from the 2-D model of <kde_model_path> (custom_distribution2D, :163-203), split
+ * between the 3' end and the 5' end by the model's end-ratio histogram (or all at the 3' end with always_end when the
+ * model has none).  A cut segment keeps its substitutions re-based, sorted by position (einterval::truncate). */
+#define TKSMSEQ_TRC_NORMAL 0
+#define TKSMSEQ_TRC_LOGNORMAL 1
+#define TKSMSEQ_TRC_KDE 2
+typedef struct {
+    uint64_t seed;
+    uint64_t first_molecule_index;   /* index of the batch's first molecule in the whole input (RNG key) */
+    int32_t mode;                    /* TKSMSEQ_TRC_* */
+    int32_t always_end;              /* --always-end */
+    int32_t kde_models_length;       /* --kde-models-length */
+    int32_t reserved;
+    double mu, sigma;                /* --normal / --lognormal */
+    const char* kde_model_path;      /* --kde-model */
+} tksmseq_trc_params;
+int tksmseq_truncate(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_trc_params* params, tksmseq_batch** out);
+
+/* The batch as MDF text, the way molecule_descriptor::operator<< writes it (src/interval.h:898-905): "+id<TAB>depth<TAB>comment",
+ * then "chr<TAB>start<TAB>end<TAB>strand<TAB>pos<base>,..." per segment; depth 1 per molecule; comments re-serialised key-sorted
+ * like dump_comment (:880-890).  *text is malloc'ed: release with tksmseq_text_free. */
+int tksmseq_batch_to_mdf_text(tksmseq_ctx* ctx, const tksmseq_batch* b, char** text, uint64_t* len);
+void tksmseq_text_free(char* text);
+
 int tksmseq_sequence_main(int argc, char** argv);
 
 #ifdef __cplusplus

@@ -1,0 +1,244 @@
+"""PCR amplification and truncation (BASELINE config 5) and the MDF writer.
+
+CPU part: the oracle (oracle/mdf_ops_oracle.py) against the reference's own unit-test vectors for truncate()
+(test/truncate_test.cpp:12-55), hand-derived known answers for the C++ reader / writer pair (unroll naming src/mdf.h:97-105,
+operator<< src/interval.h:898-905, comment round trip :809-830 / :880-890), and the counter-based PCR specification against
+the reference's full-tree recursion (distribution of the written copies).
+GPU part (-m gpu): the HIP kernels through the C-ABI against the oracle, text for text, and the device pipeline
+PCR -> truncation -> Seq against the oracle's Seq on the transformed molecules."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+@pytest.fixture(scope="module")
+def mo():
+    import mdf_ops_oracle
+    return mdf_ops_oracle
+
+
+def _mol(segs, mid="m", depth=1):
+    return dict(id=mid, depth=depth, meta={}, segments=[dict(chr=c, start=s, end=e, plus=p, errors=list(er)) for c, s, e, p, er in segs])
+
+
+# ------------------------------------------------------------------------------------------------ CPU: reference vectors
+def test_truncate_reference_unit_test_vectors(mo):
+    """test/truncate_test.cpp:12-55: four 100-base segments truncated to 200, then 150, then 50 (min_val 100)"""
+    md = _mol([("1", 0, 100, True, []), ("1", 100, 200, True, []), ("1", 200, 300, True, []), ("1", 300, 400, True, [])])
+    mo.truncate(md, 200, 100)
+    assert mo.mol_size(md) == 200 and [(s["start"], s["end"]) for s in md["segments"]] == [(0, 100), (100, 200)]
+    mo.truncate(md, 150, 100)
+    assert mo.mol_size(md) == 150 and [(s["start"], s["end"]) for s in md["segments"]] == [(0, 100), (100, 150)]
+    mo.truncate(md, 50, 100)
+    assert mo.mol_size(md) == 100 and [(s["start"], s["end"]) for s in md["segments"]] == [(0, 100)]
+    # minus-strand cut segment keeps its END (the 5' part of the molecule), substitutions re-based and filtered
+    md = _mol([("1", 0, 100, True, [(5, "A")]), ("2", 1000, 1200, False, [(10, "C"), (150, "G"), (199, "T"), (150, "A")])])
+    mo.truncate(md, 160, 100)
+    assert [(s["chr"], s["start"], s["end"]) for s in md["segments"]] == [("1", 0, 100), ("2", 1140, 1200)]
+    assert md["segments"][1]["errors"] == [(10, "G"), (10, "A"), (59, "T")]
+    assert md["meta"]["truncated"] == ["2:1000-1140"]
+
+
+def test_mdf_reader_writer_known_answers(mo):
+    """Hand-derived from the C++ (a22): stream_mdf(unroll=true) names the copies of a depth > 1 molecule id_0.. with depth 1
+    (src/mdf.h:97-105); operator<< writes 5 fields per segment (src/interval.h:898-905); the comment goes through a key-sorted
+    map, a key without '=' prints bare, several values join with ',' (:809-830, :880-890); a 4-field segment line (no
+    substitution column) is accepted by the C++ reader (:82-85)."""
+    ka = json.load(open(os.path.join(GOLDEN, "mdf_writer_known_answers.json")))
+    for case in ka["cases"]:
+        assert mo.write_mdf(mo.stream_mdf(case["in"], unroll=True)) == case["out"], case["name"]
+
+
+def test_pcr_specification_has_the_reference_distribution(mo):
+    """The branch-pruned, counter-based PCR (what the kernels run) against the reference's full-tree recursion: number of written
+    copies per template, generation of a written copy, substitutions per written copy, and the share of written pairs of one
+    template that share a substitution (ancestry) -- chi-square / z tests over 3 000 templates, two parameter sets."""
+    from scipy.stats import chi2
+    for cycles, eff, er, per_template, seed in ((3, 0.56, 3e-4, 2.0, 5), (6, 0.7, 4e-4, 3.0, 9)):
+        n = 3000
+        mols = [_mol([("1", 0, 700, True, []), ("2", 50, 350, False, [])], mid=f"t{u}") for u in range(n)]
+        target = int(n * per_template)
+        ref = mo.pcr_reference(mols, cycles, eff, er, target, np.random.RandomState(seed))
+        got = mo.pcr_spec(mols, cycles, eff, er, target, seed)
+
+        def stats(out):
+            per = np.zeros(n, int); gen = np.zeros(cycles + 1, int); nm = np.zeros(8, int)
+            by_t = {}
+            for md in out:
+                parts = md["id"].split(".")
+                u = int(parts[0][1:])
+                per[u] += 1
+                gen[len(parts) - 1] += 1
+                errs = [(si, p, b) for si, s in enumerate(md["segments"]) for p, b in s["errors"]]
+                nm[min(7, len(errs))] += 1
+                by_t.setdefault(u, []).append(set(errs))
+            share = tot = 0
+            for lst in by_t.values():
+                for a in range(len(lst)):
+                    for b in range(a + 1, len(lst)):
+                        tot += 1; share += bool(lst[a] & lst[b])
+            return np.bincount(np.minimum(per, 12), minlength=13), gen, nm, share, tot
+
+        def chi2_p(a, b):
+            a, b = np.asarray(a, float), np.asarray(b, float)
+            keep = (a + b) >= 10
+            a, b = np.append(a[keep], a[~keep].sum()), np.append(b[keep], b[~keep].sum())
+            keep = (a + b) > 0
+            a, b = a[keep], b[keep]
+            k1, k2 = np.sqrt(b.sum() / a.sum()), np.sqrt(a.sum() / b.sum())
+            return chi2.sf((((k1 * a - k2 * b) ** 2) / (a + b)).sum(), len(a) - 1)
+        sr, sg = stats(ref), stats(got)
+        assert abs(len(ref) - len(got)) < 5 * np.sqrt(len(ref) + len(got)), (len(ref), len(got), target)
+        for k, name in enumerate(("copies per template", "generation", "substitutions per copy")):
+            assert chi2_p(sr[k], sg[k]) > 1e-3, (cycles, name, sr[k], sg[k])
+        pr, pg = sr[3] / max(1, sr[4]), sg[3] / max(1, sg[4])
+        se = np.sqrt(pr * (1 - pr) / max(1, sr[4]) + pg * (1 - pg) / max(1, sg[4]) + 1e-12)
+        assert abs(pr - pg) < 5 * se + 1e-3, ("shared substitutions among sibling copies", pr, pg)
+        # ids: template id + "." + strictly increasing cycles
+        for md in got[:200]:
+            steps = [int(x) for x in md["id"].split(".")[1:]]
+            assert steps == sorted(set(steps)) and steps and steps[-1] < cycles
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+REF = {"chr1": None, "chr2": None}
+
+
+def _genome(rs):
+    return {f"chr{i + 1}": rs.choice(np.frombuffer(b"ACGT", np.uint8), 60_000).tobytes().decode() for i in range(2)}
+
+
+def _mdf(rs, n, mods=True):
+    lines = []
+    for i in range(n):
+        depth = 1 if rs.rand() < 0.8 else int(rs.randint(2, 4))
+        cm = ["", "tid=ENST7;CB=ACGT;", "z;a=1,2;"][int(rs.randint(0, 3))]
+        lines.append(f"+mol{i}\t{depth}\t{cm}\n")
+        for _ in range(int(rs.randint(1, 5))):
+            ln = int(rs.randint(1, 600))
+            st = int(rs.randint(0, 59_000))
+            md = ",".join(f"{int(rs.randint(0, ln))}{'ACGT'[int(rs.randint(0, 4))]}" for _ in range(int(rs.randint(0, 3)))) if mods else ""
+            lines.append(f"chr{int(rs.randint(1, 3))}\t{st}\t{st + ln}\t{'+-'[int(rs.randint(0, 2))]}\t{md}\n")
+        if rs.rand() < 0.3:
+            pa = "A" * int(rs.randint(1, 30))
+            lines.append(f"{pa}\t0\t{len(pa)}\t+\t\n")
+        if rs.rand() < 0.05:
+            lines.append("chr1\t500\t500\t+\t\n")                       # an empty segment
+    return "".join(lines)
+
+
+@pytest.fixture(scope="module")
+def gseq():
+    from tksm_amd.sequence import Sequencer
+    rs = np.random.RandomState(21)
+    ref = _genome(rs)
+    s = Sequencer(0)
+    for k, v in ref.items():
+        s.add_contig(k, v)
+    yield s, ref
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cycles,eff,er,target,seed", [(3, 0.56, 3e-6, 700, 3), (5, 0.88, 2e-4, 1500, 4), (12, 0.5, 1e-3, 900, 5),
+                                                       (4, 0.9, 5e-3, 100, 6), (0, 0.9, 1e-3, 100, 7)])
+def test_pcr_kernels_match_the_oracle(gseq, mo, cycles, eff, er, target, seed):
+    """tksmseq_pcr -> MDF text == oracle pcr_spec, text for text: ids (unroll suffix + copy path), order (depth first), segments,
+    substitutions in (template, oldest copy first, position) order; (4, .., target 100): more than 2 x target templates."""
+    s, _ = gseq
+    text = _mdf(np.random.RandomState(seed), 400)
+    b = s.batch_from_mdf(text)
+    out = s.pcr(b, cycles, target, error_rate=er, efficiency=eff, seed=seed)
+    got = s.to_mdf_text(out)
+    want = mo.write_mdf(mo.pcr_spec(mo.stream_mdf(text, unroll=True), cycles, eff, er, target, seed))
+    assert got == want
+    assert cycles == 0 or abs(out.n_reads - target) < 6 * np.sqrt(target) + 10
+    out.free(); b.free()
+
+
+@pytest.mark.gpu
+def test_truncation_kernels_match_the_oracle(gseq, mo, tmp_path):
+    """tksmseq_truncate -> MDF text == the oracle's literal truncate() / flip_molecule() sequence (the kernels compute the kept
+    window arithmetically): normal, lognormal, and a KDE model in the format py/truncate_kde.py:298-320 writes, with and
+    without the end-ratio histogram, --always-end, --kde-models-length; comments truncated= / TR= included."""
+    s, _ = gseq
+    text = _mdf(np.random.RandomState(8), 1500)
+    mols = mo.stream_mdf(text, unroll=True)
+    b = s.batch_from_mdf(text)
+    for kw in (dict(normal=(400.0, 150.0)), dict(lognormal=(5.8, 0.6)), dict(normal=(50.0, 10.0)), dict(normal=(5000.0, 1.0))):
+        out = s.truncate(b, seed=17, first_molecule_index=1000, **kw)
+        want = mo.write_mdf([mo.trc_spec(md, 1000 + g, 17, **kw) for g, md in enumerate(mols)])
+        assert s.to_mdf_text(out) == want, kw
+        out.free()
+    # a KDE model: x = truncation lengths, y = molecule sizes, lower-triangular weights; end ratios in [0, 1]
+    rs = np.random.RandomState(3)
+    w, h = 12, 12
+    xl = [int(v) for v in np.arange(1, w + 1) * 150]
+    yl = [int(v) for v in np.arange(1, h + 1) * 150]
+    data = (rs.rand(h, w) + 0.05).ravel().tolist()
+    parts = [dict(name="KDE_mtx", shape=[w, h], data=data, labels=xl + yl),
+             dict(name="end_mtx", shape=[20], data=[int(v) for v in rs.randint(0, 50, 20)], labels=[float(v) for v in np.arange(1, 21) / 20.0])]
+    for with_end, always_end, ml in ((True, False, False), (True, True, True), (False, True, False)):
+        path = tmp_path / f"model_{with_end}_{always_end}.json"
+        path.write_text(json.dumps(parts if with_end else parts[:1]))
+        model = mo.TruncationModel(parts if with_end else parts[:1])
+        out = s.truncate(b, kde_model=path, always_end=always_end, kde_models_length=ml, seed=23)
+        want = mo.write_mdf([mo.trc_spec(md, g, 23, model=model, always_end=always_end, models_length=ml) for g, md in enumerate(mols)])
+        got = s.to_mdf_text(out)
+        assert got == want, (with_end, always_end, ml)
+        out.free()
+    with pytest.raises(Exception):
+        s.truncate(b, kde_model=tmp_path / "model_False_True.json", always_end=False)       # no end_mtx and not --always-end
+    b.free()
+
+
+@pytest.mark.gpu
+def test_config5_pipeline_pcr_truncation_seq_on_device(gseq, mo, po, oracle_models):
+    """BASELINE config 5 in small: PCR (substitution-heavy copies, minus strands, interval ends) -> truncation -> Seq, molecule
+    tables never leaving the device; Seq's records (perfect and Badread with q-scores) equal the oracle's Seq on the oracle's
+    transformed molecules."""
+    from conftest import ERR_MODEL, QS_MODEL
+    s, ref = gseq
+    text = _mdf(np.random.RandomState(31), 300)
+    b0 = s.batch_from_mdf(text)
+    b1 = s.pcr(b0, 8, 1200, error_rate=2.5e-3, efficiency=0.8, seed=2)           # ~ 6 substitutions per kb per copy
+    b2 = s.truncate(b1, lognormal=(6.2, 0.5), seed=3)
+    mols = mo.pcr_spec(mo.stream_mdf(text, unroll=True), 8, 0.8, 2.5e-3, 1200, 2)
+    mols = [mo.trc_spec(md, g, 3, lognormal=(6.2, 0.5)) for g, md in enumerate(mols)]
+    assert s.to_mdf_text(b2) == mo.write_mdf(mols)
+    assert b2.n_mods > 2 * b2.n_reads
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    perfect = s.run(b2, target="perfect", fastq=True, seed=5).records()
+    bad = s.run(b2, target="badread", fastq=True, compute_qual=True, seed=5).records()
+    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    gen = list(po.mdf_generator(mo.write_mdf(mols).splitlines(keepends=True)))
+    assert len(gen) == len(perfect) == len(bad)
+    for i, (mid, ivs) in enumerate(gen):
+        raw = po.splice(ref, ivs)
+        assert perfect[i] == po.perfect_record(True, 5, i, raw, mid), i
+        assert bad[i] == po.badread_record(True, 5, i, raw, ident, oracle_models["em"], oracle_models["qm"], True, mid)[0], i
+    for x in (b2, b1, b0):
+        x.free()
+
+
+@pytest.mark.gpu
+def test_device_batch_writer_reproduces_the_cpp_writer_known_answers(gseq):
+    """tksmseq_batch_to_mdf_text on a parsed batch == the hand-derived output of the C++ reader / writer pair (cases that the
+    Seq grammar, exactly 5 fields per segment line, accepts)"""
+    s, _ = gseq
+    ka = json.load(open(os.path.join(GOLDEN, "mdf_writer_known_answers.json")))
+    for case in ka["cases"]:
+        if not case["seq_grammar"]:
+            continue
+        b = s.batch_from_mdf(case["in"])
+        assert s.to_mdf_text(b) == case["out"], case["name"]
+        b.free()

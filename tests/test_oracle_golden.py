@@ -6,7 +6,9 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ERR_MODEL, QS_MODEL
+import sys
+
+from conftest import GOLDEN, ERR_MODEL, QS_MODEL, MODELS
 
 KA = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
 
@@ -111,48 +113,100 @@ def test_nw_path_is_optimal_and_prefers_query_gaps(po):
     assert po.nw_cigar("AAAA", "AAAAA")[1] == "4=1D" and po.nw_cigar("AB", "BA")[1] == "1D1=1I"
 
 
-@pytest.mark.parametrize("L,n", [(300, 1200), (1000, 700), (3000, 160)])
-def test_stochastic_path_matches_reference_distributions(po, oracle_models, L, n):
-    """Distribution equivalence of the oracle's Badread path with the real reference (seeded fixtures of
-    tests/golden/badread_reference_stats.npz): two-sample KS on per-read statistics.  Gate: KS D below the
-    alpha = 0.001 critical value (the north star's 'p > 0.99' is not a usable threshold: p is uniform under H0)."""
-    from scipy.stats import ks_2samp
-    g = np.load(os.path.join(GOLDEN, "badread_reference_stats.npz"))
-    sel = (g["L"] == L) & g["with_q"]
-    em, qm = oracle_models["em"], oracle_models["qm"]
-    ident = po.Identities(84.0, 5.5, 99.0)
-    rs = np.random.RandomState(L)
-    got = {k: [] for k in ("out_len", "identity", "target", "draws", "noop", "aligns", "X", "I", "D")}
-    qh = np.zeros((3, 94), np.int64)
-    import re
-    for r in range(n):
+# ----------------------------------------------------------------------------- G6: distribution equivalence at scale
+_OW = {}
+
+
+def _oracle_init(model):
+    import pyoracle
+    _OW["po"] = pyoracle
+    _OW["em"] = pyoracle.ErrorModel(os.path.join(MODELS, model + ".error.gz"))
+    _OW["qm"] = pyoracle.QScoreModel(os.path.join(MODELS, model + ".qscore.gz"))
+    _OW["ident"] = pyoracle.Identities(84.0, 5.5, 99.0)
+
+
+def _oracle_reads(job):
+    """a slice of oracle reads of one (length, with-q) class -> per-read statistics + histograms (stats_common)"""
+    sys.path.insert(0, GOLDEN)
+    from stats_common import INS_BINS, POS_BINS, cigar_stats, qscore_hist
+    L, with_q, lo, hi, seed = job
+    po, em, qm, ident = _OW["po"], _OW["em"], _OW["qm"], _OW["ident"]
+    rs = np.random.RandomState((seed * 7919 + lo) % (2 ** 32))
+    cols = {k: [] for k in ("out_len", "identity", "target", "draws", "noop", "aligns", "X", "I", "D")}
+    qh = np.zeros((3, 94), np.int64); ih = np.zeros(INS_BINS, np.int64); ph = np.zeros((3, POS_BINS), np.int64)
+    for r in range(lo, hi):
         raw = bytes(rs.choice(list(b"ACGT"), L).tolist())
-        read = 10_000_000 + L * 100_000 + r
-        tgt = ident.get_identity(99, read)
-        seq, qual, idt, st = po.sequence_fragment(raw, tgt, em, qm, True, 99, read)
-        _, cig = po.nw_cigar(seq, raw)
-        cnt = {"=": 0, "X": 0, "I": 0, "D": 0}
-        pos = 0
-        for m in re.finditer(r"(\d+)([=XID])", cig):
-            k, t = int(m.group(1)), m.group(2)
-            cnt[t] += k
-            if t != "D":
-                np.add.at(qh["=XI".index(t)], np.frombuffer(qual[pos:pos + k], np.uint8) - 33, 1)
-                pos += k
+        read = seed * 10_000_000 + r
+        tgt = ident.get_identity(1234, read)
+        seq, qual, idt, st = po.sequence_fragment(raw, tgt, em, qm, with_q, 1234, read)
+        assert st.band_fail == 0
+        if len(seq):
+            _, cig = po.nw_cigar(seq, raw)
+            cnt, i1, p1 = cigar_stats(cig, L)
+            ih += i1; ph += p1
+            if with_q:
+                qh += qscore_hist(cig, qual)
+        else:
+            cnt = {"X": 0, "I": 0, "D": L}
         for k, v in (("out_len", len(seq)), ("identity", idt), ("target", tgt), ("draws", st.n_draws), ("noop", st.n_noop),
                      ("aligns", st.n_aligns), ("X", cnt["X"]), ("I", cnt["I"]), ("D", cnt["D"])):
-            got[k].append(v)
-        assert st.band_fail == 0
-    m = int(sel.sum())
-    crit = 1.95 * np.sqrt((n + m) / (n * m))          # KS critical value, alpha = 0.001
-    for k in got:
-        d = ks_2samp(got[k], g[k][sel]).statistic
-        assert d < crit, (k, d, crit)
-    # q-score histograms conditioned on the alignment op: total variation distance
-    ref_qh = g[f"qhist_{L}"].astype(float)
-    for row in range(3):
-        a, b = qh[row] / max(1, qh[row].sum()), ref_qh[row] / max(1, ref_qh[row].sum())
-        assert 0.5 * np.abs(a - b).sum() < 0.03, ("qhist", "=XI"[row])
+            cols[k].append(v)
+    return cols, qh, ih, ph
+
+
+@pytest.mark.parametrize("model", ["nanopore2020", "nanopore2018", "pacbio2016"])
+def test_stochastic_path_matches_reference_distributions(model):
+    """Distribution equivalence of the oracle's Badread path with the reference itself, every shipped model, L in {300, 1000,
+    3000}: 20 000 reads with q-scores + 10 000 without per class on BOTH sides (the reference's in
+    tests/golden/badread_reference_stats_<model>.npz, made by make_golden.py from the reference's own sequence_fragment /
+    get_qscores).  Gates: two-sample KS D <= 0.02 on every per-read statistic (the alpha = 0.001 critical value at these
+    sample sizes is 0.0195 / 0.0239: a 1 % shift of identity or length fails); total-variation distance of the q-score
+    histograms per alignment op, of the insertion-run-length histogram and of the per-position substitution / insertion /
+    deletion profiles <= 0.01.  (The north star's "KS p > 0.99" is not a usable gate: p is uniform under H0.)"""
+    from multiprocessing import Pool
+    from scipy.stats import ks_2samp
+    path = os.path.join(GOLDEN, f"badread_reference_stats_{model}.npz")
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: python tests/golden/make_golden.py --only-stochastic --models {model}")
+    g = np.load(path)
+    procs = max(1, min(8, len(os.sched_getaffinity(0))))
+    jobs = []
+    classes = [(L, wq) for L in (300, 1000, 3000) for wq in (True, False)]
+    for ci, (L, wq) in enumerate(classes):
+        n = int(((g["L"] == L) & (g["with_q"] == wq)).sum())
+        assert n >= (20000 if wq else 10000), (L, wq, n)
+        step = max(50, n // (procs * 4))
+        jobs += [(L, wq, lo, min(n, lo + step), 11 + ci) for lo in range(0, n, step)]
+    jobs.sort(key=lambda j: -j[0])                       # long reads first
+    with Pool(procs, initializer=_oracle_init, initargs=(model,)) as pool:
+        res = pool.map(_oracle_reads, jobs, chunksize=1)
+    tv = lambda a, b: 0.5 * np.abs(a / max(1.0, a.sum()) - b / max(1.0, b.sum())).sum()
+    worst = {}
+    for L, wq in classes:
+        sel = (g["L"] == L) & (g["with_q"] == wq)
+        mine = [r for r, j in zip(res, jobs) if j[0] == L and j[1] == wq]
+        tag = f"{L}_{'q' if wq else 'noq'}"
+        for k in ("out_len", "identity", "target", "draws", "noop", "aligns", "X", "I", "D"):
+            got = np.concatenate([np.asarray(c[k], np.float64) for c, _, _, _ in mine])
+            d = ks_2samp(got, g[k][sel].astype(np.float64)).statistic
+            worst[(tag, k)] = d
+            assert d <= 0.02, (model, tag, k, d)
+        ih = np.sum([r[2] for r in mine], axis=0).astype(float); ph = np.sum([r[3] for r in mine], axis=0).astype(float)
+        d = tv(ih, g[f"ins_hist_{tag}"].astype(float)); worst[(tag, "ins_hist")] = d
+        assert d <= 0.01, (model, tag, "insertion run lengths", d)
+        ref_ph = g[f"pos_{tag}"].astype(float)
+        for row, name in enumerate(("sub", "ins", "del")):
+            d = tv(ph[row], ref_ph[row]); worst[(tag, "pos_" + name)] = d
+            assert d <= 0.01, (model, tag, "per-position profile", name, d)
+            # ... and the rates themselves (edits per molecule position), within 2 %
+            ra, rb = ph[row].sum() / (sel.sum() * L), ref_ph[row].sum() / (sel.sum() * L)
+            assert abs(ra - rb) <= 0.02 * rb + 1e-5, (model, tag, name, ra, rb)
+        if wq:
+            qh = np.sum([r[1] for r in mine], axis=0).astype(float)
+            for row in range(3):
+                d = tv(qh[row], g[f"qhist_{L}"][row].astype(float)); worst[(tag, "qhist_" + "=XI"[row])] = d
+                assert d <= 0.01, (model, tag, "qhist", "=XI"[row], d)
+    print(model, "largest distances:", sorted(((v, k) for k, v in worst.items()), reverse=True)[:6])
 
 
 def test_band_never_changes_results_on_test_corpus(po, oracle_models):

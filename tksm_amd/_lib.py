@@ -38,6 +38,19 @@ class TailModelDesc(C.Structure):            # tksmseq_tail_model
 
 
 # every symbol include/tksmseq.h declares (checked by tests/test_abi.py without a GPU)
+class PcrParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("target_count", C.c_uint64), ("cycles", C.c_int32), ("reserved", C.c_int32),
+                ("error_rate", C.c_double), ("efficiency", C.c_double)]
+
+
+class TrcParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_molecule_index", C.c_uint64), ("mode", C.c_int32), ("always_end", C.c_int32),
+                ("kde_models_length", C.c_int32), ("reserved", C.c_int32), ("mu", C.c_double), ("sigma", C.c_double),
+                ("kde_model_path", C.c_char_p)]
+
+
+TRC_NORMAL, TRC_LOGNORMAL, TRC_KDE = 0, 1, 2
+
 SYMBOLS = [
     "tksmseq_create", "tksmseq_destroy", "tksmseq_last_error", "tksmseq_version", "tksmseq_set_stream",
     "tksmseq_synchronize", "tksmseq_reference_add_fasta", "tksmseq_reference_add_contig",
@@ -48,6 +61,7 @@ SYMBOLS = [
     "tksmseq_result_download", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
     "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
     "tksmseq_set_host_threads", "tksmseq_model_available",
+    "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
 ]
 
 _lib = None
@@ -83,6 +97,11 @@ def load():
         "tksmseq_load_tail_model": (C.c_int, [vp, C.c_char_p]),
         "tksmseq_set_tail_model": (C.c_int, [vp, vp]),
         "tksmseq_set_host_threads": (C.c_int, [vp, C.c_int]),
+        "tksmseq_pcr_preset": (C.c_int, [C.c_char_p, P(C.c_double), P(C.c_double)]),
+        "tksmseq_pcr": (C.c_int, [vp, vp, vp, P(vp)]),
+        "tksmseq_truncate": (C.c_int, [vp, vp, vp, P(vp)]),
+        "tksmseq_batch_to_mdf_text": (C.c_int, [vp, vp, P(vp), P(u64)]),
+        "tksmseq_text_free": (None, [vp]),
         "tksmseq_model_available": (C.c_int, [C.c_char_p, C.c_char_p]),
         "tksmseq_set_identity": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "tksmseq_get_error_model": (C.c_int, [vp, P(i32), P(i32), P(i32), vp, vp, vp]),

@@ -11,127 +11,10 @@
 #include <memory>
 #include <string>
 
-#include "host.h"
-#include "kernels.h"
-
-using namespace tkh;
+#include "ctx.h"
 
 static thread_local std::string g_create_error;
 
-#define HIPCHK(ctx, call)                                                                         \
-    do {                                                                                          \
-        hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess) {                                                                   \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
-            return TKSMSEQ_EDEVICE;                                                               \
-        }                                                                                         \
-    } while (0)
-
-namespace {
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    bool owned = true;                     // false: a view of another context's buffer (tksmseq_clone), read-only
-    ~DevBuf() { if (p && owned) (void)hipFree(p); }
-    void borrow(const DevBuf& o) { if (p && owned) (void)hipFree(p); p = o.p; cap = o.cap; owned = false; }
-    hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
-        if (bytes <= cap && owned) return hipSuccess;
-        // a borrowed buffer is never written: the first write access replaces it by a private copy
-        // large work buffers get 1/8 of headroom: consecutive batches of a stream differ by a few percent, and
-        // re-allocating tens of GB costs more than a batch
-        size_t ncap = std::max(bytes > (64u << 20) ? bytes + bytes / 8 : bytes, owned ? cap + cap / 2 : cap);
-        ncap = (ncap + 255) & ~(size_t)255;
-        void* np = nullptr;
-        hipError_t e = hipMalloc(&np, ncap);
-        if (e != hipSuccess) return e;
-        if (keep && p && cap) {
-            e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) { (void)hipFree(np); return e; }
-        }
-        if (p && owned) (void)hipFree(p);
-        p = np; cap = ncap; owned = true;
-        return hipSuccess;
-    }
-    template <class T> T* as() const { return (T*)p; }
-};
-
-}  // namespace
-
-struct tksmseq_batch {
-    uint64_t n_reads = 0, n_intervals = 0, n_mods = 0, n_literals = 0;
-    DevBuf reads, intervals, mods, literals, litpool, ids, idpool;
-    std::vector<uint32_t> raw_len;       // host copy, for sizing
-    std::vector<uint32_t> order;         // reads sorted by raw length (bucketed k_err launches)
-    DevBuf d_order;
-    uint32_t max_raw = 0;
-    uint64_t total_raw = 0;
-    // tail noise: raw_len / max_raw / order describe splice + tail while a tail model applies to the run
-    std::vector<uint32_t> splice_len;    // the spliced lengths (filled the first time a tail is added)
-    DevBuf d_tail;                       // [n_reads] tail lengths of the run keyed below
-    bool tail_on = false;
-    uint64_t tail_key[4] = {};           // seed, first read index, stride, model version
-    // cached scratch sizing, keyed by (k, cap_num, cap_den, cap_add)
-    int cache_k = -1, cache_num = 0, cache_den = 0, cache_add = 0;
-    uint64_t cache_scratch = 0;
-};
-
-struct tksmseq_ctx : ContigLookup {
-    int device = 0;
-    int n_cus = 256;
-    hipStream_t stream = nullptr;
-    // wave-wide kernel for the reads that cannot take the fast pipeline, underneath the rounds: a few streams, each with
-    // its own slice of the per-wave trace buffer, so that launches for reads found in different rounds overlap
-    static constexpr int N_SIDE = 4, SIDE_WAVES = 512;
-    hipStream_t side[N_SIDE] = {};
-    hipEvent_t side_start = nullptr, side_done[N_SIDE] = {};
-    bool side_used[N_SIDE] = {};
-    bool own_stream = false;
-    std::string err;
-
-    // reference
-    std::vector<std::string> contig_names;
-    std::unordered_map<std::string, int> contig_index;
-    std::vector<uint64_t> contigs;        // {gstart, len}
-    uint64_t total_alloc = 0;             // bases allocated in the global coordinate (block aligned)
-    uint64_t total_bases = 0;
-    uint32_t pool_blocks = 0;
-    DevBuf d_packed, d_blocktab, d_pool, d_contigs, d_stage;
-
-    // models
-    ErrorModelHost em; QScoreModelHost qm; IdentityHost idm;
-    bool em_uniform = false, em_alt0 = false;
-    TailModelHost tail; uint64_t tail_version = 0;
-    DevBuf d_tail_lx, d_tail_ly, d_tail_cdf, d_tail_chain;
-    DevBuf d_pself, d_pseg, d_cdf32, d_cdf, d_alts, d_altenc, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
-
-    // per-run work buffers
-    DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
-        w_scratch, w_records, w_istats, w_dstats, w_sums, w_fullpool;
-    unsigned long long full_pool_bytes = 1ull << 30;
-    // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_frag2;
-    bool force_slow = false;
-    uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
-    uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
-    uint32_t n_buckets = 16;
-    int defer_len = 0;          // reads longer than this align for their q-scores after the regular rounds, all together
-    int hbm_state_len = 2304;   // fragments longer than this are edited in HBM instead of being staged in LDS every round
-    std::vector<hipEvent_t> evpool;
-    uint32_t last_rounds = 0, last_slow = 0;
-    void* user_out = nullptr; uint64_t user_out_cap = 0;
-    bool timing = false;
-    int host_threads = 1;       // host threads for MDF parsing (tksmseq_set_host_threads)
-    hipEvent_t ev[6] = {};
-    tksmseq_result last{};
-    bool have_last = false, have_stats = false;
-
-    int find(const std::string& name) const override {
-        auto it = contig_index.find(name);
-        return it == contig_index.end() ? -1 : it->second;
-    }
-};
 
 template <class T>
 static int upload(tksmseq_ctx* ctx, DevBuf& b, const std::vector<T>& v) {
@@ -577,7 +460,20 @@ int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len
     d.n_literals = h.literals.size() / 2; d.literal_bytes = h.literal_pool.size(); d.id_bytes = h.id_pool.size();
     d.reads = h.reads.data(); d.intervals = h.intervals.data(); d.mods = h.mods.data(); d.literals = h.literals.data();
     d.literal_pool = h.literal_pool.data(); d.ids = h.ids.data(); d.id_pool = h.id_pool.data();
-    return batch_from_host(ctx, &d, out);
+    const int rc = batch_from_host(ctx, &d, out);
+    if (rc != TKSMSEQ_OK) return rc;
+    // kept for PCR / truncation / the MDF writer: which reads are copies of a depth > 1 molecule, and the header comments
+    tksmseq_batch* b = *out;
+    bool any_dup = false;
+    for (uint32_t v : h.dup) any_dup |= (v >> 31) != 0;
+    if (any_dup) {
+        b->h_dup = std::move(h.dup);
+        HIPCHK(ctx, b->d_dup.ensure(b->h_dup.size() * 4 + 16));
+        HIPCHK(ctx, hipMemcpyAsync(b->d_dup.p, b->h_dup.data(), b->h_dup.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    b->h_comments = std::move(h.comments); b->h_comment_pool = std::move(h.comment_pool);
+    return TKSMSEQ_OK;
 }
 
 int tksmseq_batch_info(const tksmseq_batch* b, uint64_t* n_reads, uint64_t* n_intervals, uint64_t* n_mods) {

@@ -37,7 +37,22 @@ struct BatchHost {
     std::vector<uint8_t> literal_pool;
     std::vector<uint32_t> ids;         // [n][2]
     std::vector<uint8_t> id_pool;
+    // what the C++ modules of the reference see beyond Seq (PCR, truncation, the MDF writer):
+    std::vector<uint32_t> dup;         // [n] bit 31: copy of a depth > 1 molecule, bits 0..30: its index (unroll naming id_i, src/mdf.h:97-105)
+    std::vector<uint32_t> comments;    // [n][2] {offset, length} of the header's comment field in comment_pool
+    std::vector<char> comment_pool;
 };
+
+// truncation model (src/truncate.cpp:77-227; written by py/truncate_kde.py:298-320): KDE_mtx = 2-D empirical distribution of the
+// truncation length given the molecule's size, end_mtx = histogram of the share of the truncation that hits the 3' end
+struct TrcModelHost {
+    std::vector<long long> xlab, ylab;
+    std::vector<double> cdf;           // [ny][nx + 1] cumulative sums of row i's first min(i + 1, nx) entries, padded with the last value
+    std::vector<int> row_n;            // [ny]
+    bool have_sider = false;
+    std::vector<double> slab, scdf;    // [ns], [ns + 1]
+};
+bool load_trc_model(const std::string& path, TrcModelHost& m, std::string& err);
 
 // tail-noise model (KDE_noise_generator, py/tksm_badread.py:886-962): the length sampler's grid and the base chain
 struct TailModelHost {

@@ -62,7 +62,7 @@ bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, Batc
     const char* p = text; const char* end = text + len;
     bool have = false;
     long long depth = 0;
-    uint32_t ivl_begin = 0, id_off = 0, id_len = 0;
+    uint32_t ivl_begin = 0, id_off = 0, id_len = 0, cm_off = 0, cm_len = 0;
     uint64_t line_no = 0;
     auto flush = [&]() {
         if (!have) return;
@@ -70,6 +70,8 @@ bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, Batc
         for (long long d = 0; d < depth; d++) {
             out.reads.push_back(ivl_begin); out.reads.push_back(cnt);
             out.ids.push_back(id_off); out.ids.push_back(id_len);
+            out.dup.push_back(depth > 1 ? (0x80000000u | (uint32_t)d) : 0u);
+            out.comments.push_back(cm_off); out.comments.push_back(cm_len);
         }
     };
     while (p < end) {
@@ -94,6 +96,8 @@ bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, Batc
             ivl_begin = (uint32_t)(out.intervals.size() / 4);
             id_off = (uint32_t)out.id_pool.size(); id_len = (uint32_t)(fe[0] - f[0] - 1);
             out.id_pool.insert(out.id_pool.end(), f[0] + 1, fe[0]);
+            cm_off = (uint32_t)out.comment_pool.size(); cm_len = nf >= 3 ? (uint32_t)(fe[2] - f[2]) : 0u;
+            if (nf >= 3) out.comment_pool.insert(out.comment_pool.end(), f[2], fe[2]);
         } else {
             if (nf != 5) { err = "MDF line " + std::to_string(line_no) + ": interval lines need exactly 5 tab-separated fields"; return false; }
             if (!have) { err = "MDF line " + std::to_string(line_no) + ": interval before the first molecule header"; return false; }
@@ -194,6 +198,10 @@ bool parse_mdf_mt(const char* text, uint64_t len, const ContigLookup& contigs, B
         const uint32_t ido = (uint32_t)out.id_pool.size();
         for (size_t q = 0; q < b.reads.size(); q += 2) { out.reads.push_back(b.reads[q] + io); out.reads.push_back(b.reads[q + 1]); }
         for (size_t q = 0; q < b.ids.size(); q += 2) { out.ids.push_back(b.ids[q] + ido); out.ids.push_back(b.ids[q + 1]); }
+        const uint32_t cmo = (uint32_t)out.comment_pool.size();
+        for (size_t q = 0; q < b.comments.size(); q += 2) { out.comments.push_back(b.comments[q] + cmo); out.comments.push_back(b.comments[q + 1]); }
+        out.comment_pool.insert(out.comment_pool.end(), b.comment_pool.begin(), b.comment_pool.end());
+        out.dup.insert(out.dup.end(), b.dup.begin(), b.dup.end());
         for (size_t q = 0; q < b.intervals.size(); q += 4) {
             const uint32_t c = b.intervals[q];
             out.intervals.push_back((c >> 31) ? (0x80000000u | ((c & 0x7fffffffu) + lo)) : c);

@@ -458,6 +458,59 @@ bool load_tail_model(const std::string& name_or_path, TailModelHost& m, std::str
 }
 
 // ---------------------------------------------------------------------------------------------
+// truncation model: JSON list [{name: "KDE_mtx", shape: [w, h], data: [...], labels: [x labels..., y labels...]},
+// {name: "end_mtx", data, labels}] (py/truncate_kde.py:298-320), read the way custom_distribution2D / custom_distribution do
+// (src/truncate.cpp:88-101, :163-177): row i of the 2-D model uses the first i + 1 of its w entries; cumulative sums start at 0
+// ---------------------------------------------------------------------------------------------
+bool load_trc_model(const std::string& path, TrcModelHost& m, std::string& err) {
+    std::string text;
+    if (!read_text_file(path, text, err)) return false;
+    JParser jp{text.c_str(), text.c_str() + text.size(), {}};
+    JVal root;
+    if (!jp.value(root, 0) || root.kind != JVal::Arr) { err = "truncation model: not a JSON list" + (jp.err.empty() ? std::string() : " (" + jp.err + ")"); return false; }
+    m = TrcModelHost();
+    bool have_kde = false;
+    for (auto& part : root.arr) {
+        if (part.kind != JVal::Obj) continue;
+        const JVal* name = part.get("name");
+        if (!name || name->kind != JVal::Str) continue;
+        std::vector<double> data, labels;
+        if (!num_list(part.get("data"), data) || !num_list(part.get("labels"), labels)) { err = "truncation model: data / labels missing in " + name->str; return false; }
+        if (name->str == "KDE_mtx" && !have_kde) {
+            std::vector<double> shape;
+            if (!num_list(part.get("shape"), shape) || shape.size() != 2) { err = "truncation model: KDE_mtx needs a 2-entry shape"; return false; }
+            const size_t w = (size_t)shape[0], h = (size_t)shape[1];
+            if (!w || !h || labels.size() < w + h || data.size() < w * h) { err = "truncation model: KDE_mtx shape, labels and data disagree"; return false; }
+            for (size_t i = 0; i < w; i++) m.xlab.push_back((long long)labels[i]);
+            for (size_t i = 0; i < h; i++) m.ylab.push_back((long long)labels[w + i]);
+            m.cdf.assign(h * (w + 1), 0.0);
+            m.row_n.resize(h);
+            for (size_t i = 0; i < h; i++) {
+                const size_t n = std::min(i + 1, w);
+                double sum = 0.0;
+                for (size_t q = 0; q < n; q++) sum += data[i * w + q];
+                double* c = m.cdf.data() + i * (w + 1);
+                c[0] = 0.0;
+                for (size_t q = 0; q < n; q++) c[q + 1] = data[i * w + q] / sum + c[q];
+                for (size_t q = n + 1; q <= w; q++) c[q] = c[n];
+                m.row_n[i] = (int)n;
+            }
+            have_kde = true;
+        } else if (name->str == "end_mtx" && !m.have_sider) {
+            if (data.empty() || labels.size() < data.size()) { err = "truncation model: end_mtx data and labels disagree"; return false; }
+            double sum = 0.0;
+            for (double d : data) sum += d;
+            m.scdf.assign(1, 0.0);
+            for (double d : data) m.scdf.push_back(d / sum + m.scdf.back());
+            m.slab.assign(labels.begin(), labels.begin() + (ptrdiff_t)data.size());
+            m.have_sider = true;
+        }
+    }
+    if (!have_kde) { err = "KDE matrix not found"; return false; }      // src/truncate.cpp:383-386
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // identity distribution: max * Beta(a, b), tabulated as 65537 quantiles
 // ---------------------------------------------------------------------------------------------
 static double betacf(double a, double b, double x) {     // continued fraction of the incomplete beta (Lentz)

@@ -219,6 +219,46 @@ class Sequencer:
         self._chk(self._lib.tksmseq_batch_create(self._ctx, C.byref(d), C.byref(h)))
         return Batch(self, h)
 
+    # ---- molecule-description transforms upstream of Seq (device to device)
+    def pcr(self, batch, cycles, target_count, error_rate=None, efficiency=None, preset=None, seed=42):
+        """PCR::perform (src/pcr.cpp:66-89) on the device; preset: one of the names of src/pcr.cpp:136-140."""
+        if preset is not None:
+            er, ef = C.c_double(), C.c_double()
+            if self._lib.tksmseq_pcr_preset(preset.encode(), C.byref(er), C.byref(ef)):
+                raise ValueError(f"Preset {preset} not found")
+            error_rate = er.value if error_rate is None else error_rate
+            efficiency = ef.value if efficiency is None else efficiency
+        if error_rate is None or efficiency is None:
+            raise ValueError("Error rate is required!" if error_rate is None else "Efficiency is required!")
+        p = L.PcrParams(seed, target_count, cycles, 0, error_rate, efficiency)
+        h = C.c_void_p()
+        self._chk(self._lib.tksmseq_pcr(self._ctx, batch._h, C.byref(p), C.byref(h)))
+        return Batch(self, h)
+
+    def truncate(self, batch, normal=None, lognormal=None, kde_model=None, always_end=False, kde_models_length=False, seed=42,
+                 first_molecule_index=0):
+        """truncate_transformer / truncate_transformer_kde (src/truncate.cpp:322-351) on the device: exactly one of normal=(mu,
+        sigma), lognormal=(mu, sigma), kde_model=path."""
+        if (normal is not None) + (lognormal is not None) + (kde_model is not None) != 1:
+            raise ValueError("One of kde-model, normal or lognormal is required!" if normal is None and lognormal is None and kde_model is None
+                             else "Only one of kde-model, normal or lognormal is allowed!")
+        mode = L.TRC_NORMAL if normal is not None else L.TRC_LOGNORMAL if lognormal is not None else L.TRC_KDE
+        mu, sigma = normal if normal is not None else lognormal if lognormal is not None else (0.0, 0.0)
+        path = str(kde_model).encode() if kde_model is not None else None
+        p = L.TrcParams(seed, first_molecule_index, mode, 1 if always_end else 0, 1 if kde_models_length else 0, 0, mu, sigma, path)
+        h = C.c_void_p()
+        self._chk(self._lib.tksmseq_truncate(self._ctx, batch._h, C.byref(p), C.byref(h)))
+        return Batch(self, h)
+
+    def to_mdf_text(self, batch):
+        """molecule_descriptor::operator<< of every molecule (src/interval.h:898-905)."""
+        t, n = C.c_void_p(), C.c_uint64()
+        self._chk(self._lib.tksmseq_batch_to_mdf_text(self._ctx, batch._h, C.byref(t), C.byref(n)))
+        try:
+            return C.string_at(t, n.value).decode()
+        finally:
+            self._lib.tksmseq_text_free(t)
+
     # ---- the hot path
     def run(self, batch, target="badread", fastq=True, compute_qual=True, seed=42, first_read_index=0, stride=1,
             collect_stats=False, perfect_of_badread=False):
