@@ -130,6 +130,9 @@ typedef struct {
 int tksmseq_batch_create(tksmseq_ctx* ctx, const tksmseq_batch_desc* host_desc, tksmseq_batch** out);
 /* Parses MDF text (whole file or a chunk ending at a molecule boundary) and uploads it. */
 int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out);
+/* The same for the MDF -> MDF modules (tksmseq_pcr, tksmseq_truncate), which the reference runs without a FASTA: contig names
+ * the context does not know stay what they are (the writer prints them back), substitution positions are not checked. */
+int tksmseq_molecules_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out);
 int tksmseq_batch_info(const tksmseq_batch* b, uint64_t* n_reads, uint64_t* n_intervals, uint64_t* n_mods);
 void tksmseq_batch_free(tksmseq_ctx* ctx, tksmseq_batch* b);
 
@@ -251,6 +254,10 @@ int tksmseq_truncate(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_tr
 int tksmseq_batch_to_mdf_text(tksmseq_ctx* ctx, const tksmseq_batch* b, char** text, uint64_t* len);
 void tksmseq_text_free(char* text);
 
+/* The `tksm pcr` and `tksm truncate` modules (PCR_module / Truncate_module: src/pcr.cpp:91-260, src/truncate.cpp:236-451) on
+ * top of the functions above: same flags, MDF file in, MDF file out; argv[0] is the module name. */
+int tksmseq_pcr_main(int argc, char** argv);
+int tksmseq_truncate_main(int argc, char** argv);
 int tksmseq_sequence_main(int argc, char** argv);
 
 #ifdef __cplusplus

@@ -242,3 +242,35 @@ def test_device_batch_writer_reproduces_the_cpp_writer_known_answers(gseq):
         b = s.batch_from_mdf(case["in"])
         assert s.to_mdf_text(b) == case["out"], case["name"]
         b.free()
+
+
+@pytest.mark.gpu
+def test_pcr_and_truncate_modules_on_files(mo, tmp_path):
+    """`tksm pcr` / `tksm truncate` (PCR_module / Truncate_module surface: src/pcr.cpp:91-260, src/truncate.cpp:236-451): MDF
+    file in, MDF file out, no reference needed; outputs equal the oracle; the reference's argument checks and exit codes."""
+    import subprocess
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    text = _mdf(np.random.RandomState(77), 300)
+    src = tmp_path / "in.mdf"
+    src.write_text(text)
+    mols = mo.stream_mdf(text, unroll=True)
+    o1 = tmp_path / "pcr.mdf"
+    r = subprocess.run([exe, "pcr", "-i", str(src), "-o", str(o1), "--cycles", "3", "-x", "T4", "--molecule-count", "500", "-s", "7"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    er, ef = mo.PRESETS["T4"]
+    assert o1.read_text() == mo.write_mdf(mo.pcr_spec(mols, 3, ef, er, 500, 7))
+    o2 = tmp_path / "trc.mdf"
+    r = subprocess.run([exe, "truncate", "-i", str(o1), "-o", str(o2), "--lognormal", "5.5,0.7", "-s", "9"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    pm = mo.stream_mdf(o1.read_text(), unroll=True)
+    assert o2.read_text() == mo.write_mdf([mo.trc_spec(md, g, 9, lognormal=(5.5, 0.7)) for g, md in enumerate(pm)])
+    # argument checks (src/pcr.cpp:148-185, src/truncate.cpp:278-300)
+    r = subprocess.run([exe, "pcr", "-i", str(src), "-o", str(o1), "--cycles", "3", "--molecule-count", "5"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error rate is required!" in r.stderr and "Efficiency is required!" in r.stderr
+    r = subprocess.run([exe, "pcr", "-i", str(src), "-o", str(o1), "--cycles", "3", "--molecule-count", "5", "-x", "Pfu"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Preset Pfu not found" in r.stderr
+    r = subprocess.run([exe, "truncate", "-i", str(src), "-o", str(o2)], capture_output=True, text=True)
+    assert r.returncode == 1 and "One of kde-model, normal or lognormal is required!" in r.stderr
+    r = subprocess.run([exe, "truncate", "-i", str(src), "-o", str(o2), "--normal", "5,1", "--lognormal", "5,1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Only one of kde-model, normal or lognormal is allowed!" in r.stderr

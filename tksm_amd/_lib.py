@@ -62,6 +62,7 @@ SYMBOLS = [
     "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
     "tksmseq_set_host_threads", "tksmseq_model_available",
     "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
+    "tksmseq_molecules_from_mdf_text", "tksmseq_pcr_main", "tksmseq_truncate_main",
 ]
 
 _lib = None
@@ -102,6 +103,7 @@ def load():
         "tksmseq_truncate": (C.c_int, [vp, vp, vp, P(vp)]),
         "tksmseq_batch_to_mdf_text": (C.c_int, [vp, vp, P(vp), P(u64)]),
         "tksmseq_text_free": (None, [vp]),
+        "tksmseq_molecules_from_mdf_text": (C.c_int, [vp, C.c_char_p, u64, P(vp)]),
         "tksmseq_model_available": (C.c_int, [C.c_char_p, C.c_char_p]),
         "tksmseq_set_identity": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "tksmseq_get_error_model": (C.c_int, [vp, P(i32), P(i32), P(i32), vp, vp, vp]),

@@ -372,7 +372,7 @@ int tksmseq_get_identity(const tksmseq_ctx* ctx, int32_t* constant, double* valu
 }
 
 // ------------------------------------------------------------------------------------------- batches
-static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmseq_batch** out) {
+static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmseq_batch** out, bool check_mods = true) {
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (d->n_intervals >= 0x7fffffffull || d->n_mods >= 0x7fffffffull || d->n_reads >= 0xffffffffull) {
@@ -403,7 +403,7 @@ static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmse
         prev_mod = mb;
     }
     // the reference raises IndexError for a modification outside its slice (py/sequence.py:238)
-    for (uint64_t i = 0; i < d->n_intervals; i++) {
+    for (uint64_t i = 0; i < d->n_intervals && check_mods; i++) {
         const uint32_t mb = d->intervals[4 * i + 3] & 0x7fffffffu;
         const uint32_t me = i + 1 < d->n_intervals ? (d->intervals[4 * (i + 1) + 3] & 0x7fffffffu) : (uint32_t)d->n_mods;
         for (uint32_t m = mb; m < me; m++)
@@ -451,7 +451,15 @@ int tksmseq_batch_create(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmseq_
     return batch_from_host(ctx, d, out);
 }
 
-int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out) {
+static int batch_from_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out, bool check_mods);
+
+int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out) { return batch_from_text(ctx, text, len, out, true); }
+
+// For the MDF -> MDF modules (PCR, truncation), which run without a reference: contig names the context does not know are
+// kept as literal names, and substitution positions are not checked against slices that cannot be taken here.
+int tksmseq_molecules_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out) { return batch_from_text(ctx, text, len, out, false); }
+
+static int batch_from_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out, bool check_mods) {
     if (!ctx || (!text && len) || !out) return TKSMSEQ_EINVAL;
     BatchHost h;
     if (!parse_mdf_mt(text, len, *ctx, h, ctx->err, ctx->host_threads)) return TKSMSEQ_EINVAL;
@@ -460,7 +468,7 @@ int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len
     d.n_literals = h.literals.size() / 2; d.literal_bytes = h.literal_pool.size(); d.id_bytes = h.id_pool.size();
     d.reads = h.reads.data(); d.intervals = h.intervals.data(); d.mods = h.mods.data(); d.literals = h.literals.data();
     d.literal_pool = h.literal_pool.data(); d.ids = h.ids.data(); d.id_pool = h.id_pool.data();
-    const int rc = batch_from_host(ctx, &d, out);
+    const int rc = batch_from_host(ctx, &d, out, check_mods);
     if (rc != TKSMSEQ_OK) return rc;
     // kept for PCR / truncation / the MDF writer: which reads are copies of a depth > 1 molecule, and the header comments
     tksmseq_batch* b = *out;
