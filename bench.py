@@ -15,9 +15,17 @@ N>1 (torchrun, one rank per GPU): molecules are sharded round-robin (global read
 RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RCCL gather of the per-rank record
 streams to rank 0 and the device-side interleave into global read order (the FASTQ-order exchange step).
 
-Prints ONE JSON line on rank 0 (contract in the round instructions), including `roofline` (dominant kernel
-k_simulate: algorithmic bytes per launch / its HIP-event duration) and `cpu_baseline` (the CPU oracle on a bounded
-sample of the same workload, all host cores).
+Prints ONE JSON line on rank 0 (contract in the round instructions), including
+  `roofline`      dominant kernel = the largest of k_loop (error loop, one lane per read), k_job (alignment windows packed, one lane
+                  per job) and k_aln (bit-parallel alignments, one lane per alignment) by EXCLUSIVE time: after the timed steps one
+                  more step runs on one context alone (nothing else on the GPU) with HIP events around every launch on its stream;
+                  achieved = algorithmic bytes of a step / that kernel's summed launch durations in that step.  The overlapped
+                  sums measured during the timed steps (three contexts sharing the GPU) are reported next to it.
+                  `traffic` is the PMC figure of the committed profile named in `traffic_source` (same command), or null;
+  `cpu_baseline`  the CPU oracle (oracle/tksm_oracle.c, -O3 -march=native, kind "port") on a bounded sample of the same workload,
+                  all host cores;
+  `e2e_reads_per_s`  (N = 1) the `tksm sequence` binary on files: MDF text in, FASTQ file out, wall time of the whole process --
+                  PCIe and host I/O inclusive, never `value`.
 """
 import argparse
 import json
@@ -79,10 +87,58 @@ def cpu_baseline(n_reads, mean_len, seconds_budget=20.0):
         res = p.map(cpu_baseline_worker, chunks)
     wall = time.time() - t0
     n = sum(r[0] for r in res)
-    return {"value": n / wall, "unit": "reads/s", "cores": cores, "kind": "port",
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"value": n / wall, "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "sample": f"{n} reads of the same synthetic bulk workload (mean {mean_len} b, 24 x 1 Mb host genome), "
-                      f"CPU oracle oracle/tksm_oracle.c on {cores} processes, {wall:.1f} s wall",
+                      f"CPU oracle oracle/tksm_oracle.c (gcc -O3 -march=native) on {cores} processes, {wall:.1f} s wall",
             "gbases_per_s": sum(r[1] for r in res) / wall / 1e9}
+
+
+def e2e_leg(n_molecules):
+    """`tksm sequence` on files, wall time of the whole process (start, device, reference packing, models, MDF parse, PCIe,
+    FASTQ written to a file): a fixed file of n_molecules bulk molecules (blocks of 1 M distinct molecules) on a 4 x 8 Mb genome."""
+    import shutil
+    import subprocess
+    import tempfile
+    from tksm_amd import synthetic
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40e9 else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="tksm_e2e_", dir=base)
+    try:
+        rs = np.random.RandomState(1)
+        lens = [8_000_000] * 4
+        with open(os.path.join(d, "ref.fa"), "w") as f:
+            for c, L in enumerate(lens):
+                s = rs.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes().decode()
+                f.write(f">chr{c + 1}\n")
+                f.write("\n".join(s[i:i + 80] for i in range(0, L, 80)))
+                f.write("\n")
+        block = min(n_molecules, 1_000_000)
+        m = synthetic.make_molecules(rs, lens, block, 1000, 200)
+        text = synthetic.mdf_text(m, [f"chr{c + 1}" for c in range(4)])
+        reps = max(1, n_molecules // block)
+        with open(os.path.join(d, "mols.mdf"), "w") as f:
+            for _ in range(reps):
+                f.write(text)
+        n = block * reps
+        env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+        cores = host_cores()
+        cmd = [exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", os.path.join(d, "out.fastq"),
+               "-t", str(max(1, cores // 2)), "--verbosity", "ERROR"]
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        dt = time.time() - t0
+        if r.returncode:
+            return {"reads_per_s": None, "error": r.stderr[-300:]}
+        return {"reads_per_s": n / dt, "molecules": n, "wall_s": dt, "mdf_bytes": os.path.getsize(os.path.join(d, "mols.mdf")),
+                "fastq_bytes": os.path.getsize(os.path.join(d, "out.fastq")), "files_on": base,
+                "command": "tksm sequence -i mols.mdf -r ref.fa -o out.fastq -t %d (Badread + q-scores, nanopore2020)" % max(1, cores // 2)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -101,6 +157,8 @@ def main():
     ap.add_argument("--perfect", action="store_true", help="bench the integer splice path only (--perfect)")
     ap.add_argument("--lognormal-sigma", type=float, default=0.0, help="transcript-like skewed lengths: lognormal, median --mean-len")
     ap.add_argument("--pipeline", type=int, default=3, help="contexts in flight per GPU (1 = one batch at a time)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg")
+    ap.add_argument("--e2e-molecules", type=int, default=8_000_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,12 +330,18 @@ def main():
     elapsed = time.perf_counter() - t0
     sim_ms = [r.kernel_ms[1] for r in results]
     tot_ms = [r.kernel_ms[4] for r in results]
-    err_ms = [r.kernel_ms[5] for r in results]
-    aln_ms = [r.kernel_ms[6] for r in results]
-    oth_ms = [r.kernel_ms[7] for r in results]
     rec_bytes = sum(r.records_bytes for r in results)
     bases_in = sum(r.bases_in for r in results)
     bases_out = sum(r.bases_out for r in results)
+    overlapped = {"k_loop": float(np.mean([r.kernel_ms[5] for r in results])), "k_aln": float(np.mean([r.kernel_ms[6] for r in results])),
+                  "k_job": float(np.mean([r.kernel_ms[7] for r in results]))}
+    # exclusive per-kernel time: one more step on one context with the GPU to itself (untimed for `value`)
+    fence()
+    rx = run_step(ctxs[0], args.warmup * n_ctx + args.steps)
+    ctxs[0].seqr.synchronize()
+    fence()
+    exclusive = {"k_loop": float(rx.kernel_ms[5]), "k_aln": float(rx.kernel_ms[6]), "k_job": float(rx.kernel_ms[7]),
+                 "simulate_stage_total": float(rx.kernel_ms[1]), "all_kernels": float(rx.kernel_ms[4])}
     if exchange_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -293,27 +357,25 @@ def main():
     reads = args.batch * world * args.steps
     value = reads / elapsed
     alg = synthetic.algorithmic_bytes(m, rec_bytes / args.steps)
-    # dominant kernel: the Badread path is k_err (error loop, one wave per read, launched once per round and length
-    # bucket) + k_aln (bit-parallel alignments); the larger of the two sums is priced; --perfect runs k_perfect alone.
-    # Duration = sum of that kernel's launches in one step (HIP events on the launch stream inside the library).
-    stage = {"k_err": float(np.mean(err_ms)), "k_aln": float(np.mean(aln_ms)), "init_and_stragglers": float(np.mean(oth_ms)),
-             "simulate_stage_total": float(np.mean(sim_ms))}
     if args.perfect:
         # --perfect: one kernel writes the records straight from the packed reference (timed as the emit stage)
-        dom, sim_avg_ms = "k_perfect", float(np.mean([r.kernel_ms[3] for r in results]))
-    elif stage["k_err"] + stage["k_aln"] == 0.0:
-        dom, sim_avg_ms = "k_simulate", float(np.mean(sim_ms))
+        dom, dom_ms = "k_perfect", float(rx.kernel_ms[3])
+        overlapped = {"k_perfect": float(np.mean([r.kernel_ms[3] for r in results]))}
+        exclusive = {"k_perfect": dom_ms, "all_kernels": float(rx.kernel_ms[4])}
+    elif exclusive["k_loop"] + exclusive["k_aln"] == 0.0:
+        dom, dom_ms = "k_simulate", exclusive["simulate_stage_total"]
     else:
-        dom = "k_err" if stage["k_err"] >= stage["k_aln"] else "k_aln"
-        sim_avg_ms = stage[dom]
-    achieved = alg / (sim_avg_ms * 1e-3) / 1e9
-    traffic = None
+        dom = max(("k_loop", "k_aln", "k_job"), key=lambda k: exclusive[k])
+        dom_ms = exclusive[dom]
+    achieved = alg / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("batch") == args.batch and tj.get("kind", "bulk") == args.kind:
+            if tj.get("batch") == args.batch and tj.get("kind", "bulk") == args.kind and not args.perfect:
                 traffic = tj.get("hbm_bytes_per_step", {}).get(dom)
+                traffic_source = f"profiles/{tj.get('profile', 'traffic_latest.json')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
         except Exception:
             traffic = None
     out = {
@@ -330,10 +392,23 @@ def main():
         "gbases_per_s": bases_in_all / elapsed / 1e9,
         "gbases_out_per_s": bases_out_all / elapsed / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
-                     "kernel_ms": sim_avg_ms, "algorithmic_bytes_per_launch": alg,
-                     "all_kernels_ms": float(np.mean(tot_ms)), "stage_ms": stage},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom,
+                     "kernel_ms": dom_ms, "kernel_ms_is": "exclusive: summed launch durations of the kernel in one step run alone on the GPU",
+                     "algorithmic_bytes_per_launch": alg,
+                     "exclusive_ms_per_step": exclusive, "overlapped_ms_per_step": overlapped,
+                     "overlapped_all_kernels_ms": float(np.mean(tot_ms)), "overlapped_simulate_stage_ms": float(np.mean(sim_ms))},
     }
+    if world == 1 and not args.no_e2e and not args.perfect and args.kind == "bulk":
+        # the CLI is another process on the same GPU: release this one's contexts and buffers first
+        for c in reversed(ctxs):
+            c.batch.free()
+            c.seqr.close()
+            c.out_t = c.off_t = None
+        ctxs.clear()
+        torch.cuda.empty_cache()
+        e2e = e2e_leg(args.e2e_molecules)
+        out["e2e_reads_per_s"] = e2e["reads_per_s"]
+        out["e2e"] = e2e
     out["cpu_baseline"] = cpu_base
     sys.stdout.flush()
     os.dup2(json_fd, 1)

@@ -640,7 +640,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
 
     const bool T = ctx->timing;
     O.read_list = nullptr; O.n_work = n;
-    float ms_err = 0, ms_aln = 0, ms_other = 0;
+    float ms_loop = 0, ms_aln = 0, ms_job = 0;
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
     HIPCHK(ctx, hipMemsetAsync(ctx->w_counter.p, 0, 8192, s));
     HIPCHK(ctx, tk::launch_read_lengths(B, R, k, cap_num, cap_den, cap_add, O.tail_len, ctx->w_rawlen.as<uint32_t>(), ctx->w_slotcap.as<uint64_t>(),
@@ -762,7 +762,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (evi >= ctx->evpool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return 1; ctx->evpool.push_back(e); }
             return hipEventRecord(ctx->evpool[evi++], s) == hipSuccess ? 0 : 1;
         };
-        std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other, 1 err, 2 aln, -1 host gap
+        std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other (k_init, k_err, wave-wide kernel), 1 k_loop, 2 k_aln, 3 k_job, -1 host gap
         HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, n * (size_t)lcap * 2, s));
         HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 256, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
@@ -809,6 +809,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, hipMemsetAsync((void*)FB.job_cnt, 0, (size_t)FB.n_ranges * 128, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
+            bool regular = false;
             if (revive) {
                 // the reads whose error loop has ended (all of them by now) build their q-score jobs, or -- without q-scores --
                 // write their output, all in this one round
@@ -839,10 +840,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 // later: the reads of the previous round's jobs), then this round's jobs packed for k_aln, one lane each
                 if (rounds == 0) HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, (uint32_t)n, lcap, 0, 0, 0, s));
                 else HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
+                if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+                kinds.push_back(1);
                 HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
+                regular = true;
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
-            kinds.push_back(1);
+            kinds.push_back(regular ? 3 : 0);
             HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), (const void*)FB.job_cnt, (size_t)FB.n_ranges * 128, hipMemcpyDeviceToHost, s));
             HIPCHK(ctx, hipStreamSynchronize(s));
@@ -937,7 +941,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, hipStreamSynchronize(s));
             for (size_t i = 0; i + 1 < evi && i < kinds.size(); i++) {
                 float ms = 0; (void)hipEventElapsedTime(&ms, ctx->evpool[i], ctx->evpool[i + 1]);
-                if (kinds[i] == 1) ms_err += ms; else if (kinds[i] == 2) ms_aln += ms; else if (kinds[i] == 0) ms_other += ms;
+                if (kinds[i] == 1) ms_loop += ms; else if (kinds[i] == 2) ms_aln += ms; else if (kinds[i] == 3) ms_job += ms;
             }
         }
     }
@@ -988,7 +992,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, hipEventSynchronize(ctx->ev[4]));
         for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&res->kernel_ms[i], ctx->ev[i], ctx->ev[i + 1]);
         (void)hipEventElapsedTime(&res->kernel_ms[4], ctx->ev[0], ctx->ev[4]);
-        res->kernel_ms[5] = ms_err; res->kernel_ms[6] = ms_aln; res->kernel_ms[7] = ms_other;
+        res->kernel_ms[5] = ms_loop; res->kernel_ms[6] = ms_aln; res->kernel_ms[7] = ms_job;
     }
     res->records = records; res->record_offsets = ctx->w_recoff.p; res->records_bytes = total; res->n_reads = n;
     res->bases_in = b->total_raw; res->bases_out = hs[1];

@@ -1,6 +1,8 @@
 """end-to-end (PCIe + host I/O inclusive) rate of the `tksm sequence` CLI on synthetic files"""
 import os, sys, time, subprocess, numpy as np
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 from tksm_amd import synthetic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 extra = sys.argv[2:]                                   # e.g. --in-flight 1 --batch-bytes 16777216

@@ -29,4 +29,4 @@ print('setup %.1f s' % (time.time() - _t0), flush=True)
 for it in range(3):
     t=time.time(); r=s.run(b,target='badread',fastq=True,compute_qual=True,seed=42,first_read_index=it*B); dt=time.time()-t
     faulthandler.cancel_dump_traceback_later(); faulthandler.dump_traceback_later(90, exit=True)
-    print('wall %.1f ms'%(dt*1e3), 'reads/s %.0f'%(B/dt), 'ms: lens %.2f sim %.2f scan %.2f emit %.2f total %.2f | err %.2f aln %.2f other %.2f'%tuple(r.kernel_ms))
+    print('wall %.1f ms'%(dt*1e3), 'reads/s %.0f'%(B/dt), 'ms: lens %.2f sim %.2f scan %.2f emit %.2f total %.2f | loop %.2f aln %.2f job %.2f'%tuple(r.kernel_ms))
