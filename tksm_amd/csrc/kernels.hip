@@ -2018,22 +2018,31 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
     int nmax = act ? n + skip : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-    // fragment planes: five 64-position words sliding with the slot position (W1 holds the current slot: a block is packed up
-    // to ~60 slots after it began, its entering rows lie between the word before the current one and two after), the next in flight
-    const int wbase = base >> 6;
+    // fragment planes as a stream aligned to `base` (word j = positions base + 64 j ..), so that every lane is at the same bit of
+    // its own stream: four words around the current slot (the one before it, its own, two after: a block is packed up to ~60 slots
+    // after it began, and its entering rows lie 33 .. 95 positions ahead of where it began), the next raw word in flight
+    const int wbase = base >> 6, bsh = base & 63;
     const int wlast = FB.fw - 1;
     auto fpw = [&](int w) { return fp[min(max(w, 0), wlast)]; };
-    ulonglong2 W0 = fpw(wbase - 1), W1 = fpw(wbase), W2 = fpw(wbase + 1), W3 = fpw(wbase + 2), W4 = fpw(wbase + 3), Wn = W4;
-    int w0idx = wbase - 1;                                            // word index of W0
-    auto bits32 = [&](int pos, bool hi) -> uint32_t {                 // plane bits [pos, pos + 32), 64 * w0idx <= pos < 64 * (w0idx + 3)
-        const int off = pos - 64 * w0idx, wq = off >> 6;
-        const unsigned long long a0 = hi ? W0.y : W0.x, a1 = hi ? W1.y : W1.x, a2 = hi ? W2.y : W2.x, a3 = hi ? W3.y : W3.x;
+    auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 r; r.x = funnel128(a.x, b.x, bsh); r.y = funnel128(a.y, b.y, bsh); return r; };
+    ulonglong2 Rl, Rn;                                                // the last raw word used, the next one
+    ulonglong2 Wm, W0, W1, W2;                                        // aligned words j - 1, j, j + 1, j + 2 around the current slot's word j
+    {
+        const ulonglong2 r0 = fpw(wbase), r1 = fpw(wbase + 1), r2 = fpw(wbase + 2), r3 = fpw(wbase + 3);
+        Wm = make_ulonglong2(0ull, 0ull);                              // positions before the window's first word are never asked for
+        W0 = aligned(r0, r1); W1 = aligned(r1, r2); W2 = aligned(r2, r3);
+        Rl = r3; Rn = fpw(wbase + 4);
+    }
+    int jcur = 0;                                                     // index of W0 in the stream
+    auto bits32 = [&](int rel, bool hi) -> uint32_t {                 // plane bits [rel, rel + 32) of the stream (rel: position - base)
+        const int off = rel - 64 * (jcur - 1), wq = off >> 6;        // 0 <= off < 224
+        const unsigned long long a0 = hi ? Wm.y : Wm.x, a1 = hi ? W0.y : W0.x, a2 = hi ? W1.y : W1.x, a3 = hi ? W2.y : W2.x;
         const unsigned long long lo = wq == 0 ? a0 : wq == 1 ? a1 : a2, up = wq == 0 ? a1 : wq == 1 ? a2 : a3;
         return lo32(funnel128(lo, up, off & 63));
     };
-    if (act) {                                                        // the first 64 window rows
-        FB.job_win[2ull * job] = funnel128(W1.x, W2.x, p0 & 63);
-        FB.job_win[2ull * job + 1] = funnel128(W1.y, W2.y, p0 & 63);
+    if (act) {                                                        // the first 64 window rows (positions p0 .. p0 + 63)
+        FB.job_win[2ull * job] = funnel128(W0.x, W1.x, skip);
+        FB.job_win[2ull * job + 1] = funnel128(W0.y, W1.y, skip);
     }
     int t = 1, col = 0;                                               // window top after the last column; columns emitted
     int tk = 1, npend = 0, nrec = 0;                                  // top before the first queued column; queued column bytes; records packed
@@ -2047,8 +2056,8 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
         nb4 = (nb4 | (nb4 >> 4)) & 0x00ff00ff00ff00ffull; nb4 = (nb4 | (nb4 >> 8)) & 0x0000ffff0000ffffull; nb4 = nb4 | (nb4 >> 16);
         const uint32_t shw = (uint32_t)nb4, shx = bit_of_bytes(v >> 6), clo = bit_of_bytes(v), chi = bit_of_bytes(v >> 1);
         const int adv = (int)((((v >> 2) & 0x1f1f1f1f1f1f1f1full) * 0x0101010101010101ull) >> 56);
-        const int o = p0 + tk - 1 + 64;                               // the 32 fragment rows after the window at the block's start
-        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), bits32(o, false), bits32(o, true));
+        const int rel = skip + tk - 1 + 64;                           // the 32 fragment rows after the window at the block's start
+        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), bits32(rel, false), bits32(rel, true));
         tk += adv;
         q0 = q1; q1 = q2; q2 = 0ull; npend -= ncols;
         const int tq = nrec++;
@@ -2062,44 +2071,40 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
         const int src = (s0 <= n + skip) ? base + s0 : base;
         const U4a* cp = reinterpret_cast<const U4a*>(gnb + src);
         const U4a c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-        if ((s0 & 63) == 0) Wn = fpw(wbase + (s0 >> 6) + 4);
         const uint32_t cw[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+        const int bit0 = s0 & 32;
 #pragma unroll
         for (int q = 0; q < 32; q++) {
-            const int s = s0 + q, p = s - skip;                       // p: slot within the window
+            const int p = s0 + q - skip;                              // slot within the window
             const bool on = act && p >= 0 && p < n;
             const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-            const int pos = base + s;                                 // fragment position of the slot (in word W1)
-            int len = 0; uint32_t syms = 0u;
-            if (on) {
-                len = code ? (int)((code >> 12) & 7u) : 1;
-                const int bo = pos & 63;
-                syms = code ? code & 0x3ffu : (uint32_t)(((W1.x >> bo) & 1ull) | (((W1.y >> bo) & 1ull) << 1));
-            }
-            uint32_t shb = 0u;                                        // the slot's first column carries the shift of the window top
-            if (len > 0) {
-                const int tn = max(1, p + 1 - 31), sh = tn - t;
-                fail |= sh > 31;
-                t = tn;
-                shb = (uint32_t)(sh & 31) << 2;
-            }
-            // the slot's symbols join the queue (first one: {symbol, shift}; the others: symbol only)
-            int x = 0;
-            while (__ballot(x < len) != 0ull) {
-                if (x < len) {
-                    const uint32_t byte = ((syms >> (2 * x)) & 3u) | (x == 0 ? shb : 0u);
-                    const unsigned long long v = (unsigned long long)byte << (8 * (npend & 7));
-                    const int which = npend >> 3;
-                    q0 |= which == 0 ? v : 0ull; q1 |= which == 1 ? v : 0ull; q2 |= which == 2 ? v : 0ull;
-                    npend++; col++;
-                }
-                x++;
-            }
+            // the slot's symbols, 2 bits each (a pristine slot: its original base, bit (s & 63) of the current plane word)
+            const uint32_t orig = (uint32_t)((W0.x >> (bit0 + q)) & 1ull) | ((uint32_t)((W0.y >> (bit0 + q)) & 1ull) << 1);
+            const int len = on ? (code ? (int)((code >> 12) & 7u) : 1) : 0;
+            const uint32_t syms = code ? code & 0x3ffu : orig;
+            // ... as column bytes: the first one carries the shift of the window top, top = max(1, slot + 1 - 31)
+            const int tn = max(1, p + 1 - 31), sh = len > 0 ? tn - t : 0;
+            fail |= sh > 31;
+            t += sh;
+            unsigned long long v = (unsigned long long)((syms & 0x003u) | ((syms & 0x00cu) << 6) | ((syms & 0x030u) << 12) | ((syms & 0x0c0u) << 18)) |
+                                   ((unsigned long long)(syms & 0x300u) << 24) | (unsigned long long)((uint32_t)(sh & 31) << 2);
+            v &= len >= 8 ? ~0ull : (1ull << (8 * len)) - 1ull;
+            // ... join the queue at byte npend
+            const int which = npend >> 3, bs = 8 * (npend & 7);
+            const unsigned long long lo = v << bs, up = bs > 24 ? v >> (64 - bs) : 0ull;
+            q0 |= which == 0 ? lo : 0ull;
+            q1 |= which == 1 ? lo : (which == 0 ? up : 0ull);
+            q2 |= which == 2 ? lo : (which == 1 ? up : 0ull);
+            npend += len; col += len;
             // every fourth slot a lane packs one block if it has one; a lane whose queue could overflow with the next slot at once
             if ((q & 3) == 3) { if (npend >= 8) pack_block(8); }
             else if (__ballot(npend > 19) != 0ull) { if (npend > 19) pack_block(8); }
-            // the window of plane words follows the slot position
-            if (((pos + 1) & 63) == 0) { W0 = W1; W1 = W2; W2 = W3; W3 = W4; W4 = Wn; w0idx++; }
+        }
+        // the plane words follow the slot position: every lane moves on at the same slot
+        if (bit0) {
+            jcur++;
+            Wm = W0; W0 = W1; W1 = W2; W2 = aligned(Rl, Rn); Rl = Rn;
+            Rn = fpw(wbase + jcur + 4);
         }
     }
     if (!act) return;
