@@ -811,10 +811,15 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             kinds.push_back(-1);
             bool regular = false;
             if (revive) {
-                // the reads whose error loop has ended (all of them by now) build their q-score jobs, or -- without q-scores --
-                // write their output, all in this one round
-                const Bucket& bk = buckets.back();
-                HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, n_deferred, bk.lcap, bk.ncap, 2, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
+                // every read's error loop has ended.  With q-scores: one more alignment job per read, the whole new sequence
+                // against the whole fragment (k_qjobs + k_job, then k_aln below); without: their output, in this one round
+                if (P.compute_q) {
+                    HIPCHK(ctx, tk::launch_qjobs(FB, k, n_deferred, s));
+                    HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
+                } else {
+                    const Bucket& bk = buckets.back();
+                    HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, n_deferred, bk.lcap, bk.ncap, 2, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
+                }
                 revive = false;
             } else if (revived) {
                 // last visits: q-score lookups and output, one wave per q-score job; ranges are chunks of the sorted order,

@@ -199,6 +199,8 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
                       int from_jobs, uint32_t c0, uint32_t c1, int waves_per_wg, bool state_in_hbm, hipStream_t s);
 // this round's alignment jobs (ids below n_jobs; per-range counts in fb.job_cnt) packed into block records, one lane per job
+// q-score jobs for the first `count` reads of fb.defer_list (after the last regular round)
+hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s);
 hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, hipStream_t s);

@@ -1500,7 +1500,6 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     const double target = S.target;
     const int change_count = __builtin_amdgcn_readfirstlane(S.change_count), st_draws = __builtin_amdgcn_readfirstlane(S.st_draws);
     int st_aligns = __builtin_amdgcn_readfirstlane(S.st_aligns);
-    const uint32_t n_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.n_base), aln_no = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.aln_no);
     double identity = 1.0;
 
     // ---- :434-437 trims and the joined sequence (both stages)
@@ -1517,17 +1516,8 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     if (m > jcap) { status |= 1; lo = hi = 0; }
     const int out_len = hi - lo;
     const bool want_q = P.compute_q && m > 0 && !(status & 1);
-    if (S.stage == 3 && want_q) {
-        int m1 = m;
-        const uint32_t job = join_job(FB, 1, r, pos, 1, frag, nb, 0, L, m1, lds_ncap, aux, nullptr, 0, 0, lane);
-        if (job >> 31) { go_slow(FB, r, lane, 2); return; }
-        if (lane == 0) {
-            S.errors = errors; S.change_count = change_count; S.n_base = n_base; S.aln_no = aln_no;
-            S.resume_src = -1; S.pending = 1; S.stage = 1; S.st_draws = st_draws; S.st_aligns = st_aligns; S.job = job;
-            FB.state[r] = S;
-        }
-        return;
-    }
+    // (a read with q-scores comes here twice at most: never in stage 3 -- k_qjobs turned that into stage 1 -- so what follows is
+    // either the last visit after the q-score alignment, or the only visit of a run without q-scores)
     if (want_q) {
         // ---- S5 q-scores from the alignment k_aln left in job_popd (py/tksm_badread.py:607-655)
         const uint32_t mt = S.res_mt, cols = S.res_cols, fail = S.res_fail;
@@ -1986,6 +1976,36 @@ DEV uint32_t range_of_job(const FastBuffers& FB, uint32_t job0) {
     while (rng < hi2) { const uint32_t mid = (rng + hi2 + 1) >> 1; if (FB.base_cur[mid] <= job0) rng = mid; else hi2 = mid - 1; }
     return rng;
 }
+// ---- k_qjobs: after the last regular round every read waits in stage 3; with q-scores each of them gets one more alignment
+// job, its whole new sequence against its whole fragment with the path kept (get_qscores, py/tksm_badread.py:611-613): job ids
+// per range as in k_loop, windows packed by k_job, aligned by k_aln, looked up by the last visit of k_err.
+__global__ __launch_bounds__(64) void k_qjobs(FastBuffers FB, int k, uint32_t count) {
+    const int lane = threadIdx.x;
+    const uint32_t widx = blockIdx.x * 64u + (uint32_t)lane;
+    bool need = widx < count;
+    uint32_t r = 0, rc = 0, job = 0;
+    if (need) { const uint2 e = FB.defer_list[widx]; r = e.x; rc = e.y; }
+    need = need && FB.state[r].stage == 3 && !FB.state[r].slow;
+    const bool mine = need;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t lrc = (uint32_t)__shfl((int)rc, leader, 64);
+        const unsigned long long grp = __ballot(need && rc == lrc);
+        uint32_t base = 0;
+        if (lane == leader) base = FB.base_cur[lrc] + atomicAdd(&FB.job_cnt[lrc * 32u], (uint32_t)__popcll(grp));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (need && rc == lrc) { job = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull)); need = false; }
+        todo &= ~grp;
+    }
+    if (mine) {
+        ReadState* sp = FB.state + r;
+        const uint32_t L = (uint32_t)(sp->raw_len + 2 * k);
+        *reinterpret_cast<uint4*>(FB.job_meta + 4ull * job) = make_uint4(r, 0u, L | 0x80000000u, 0u);
+        sp->resume_src = -1; sp->pending = 1; sp->stage = 1; sp->job = job;
+    }
+}
+
 // ---- k_job: packs the windows of this round's alignment jobs into the block records k_aln reads, one LANE per job.
 // All lanes walk their windows slot by slot in lockstep (slot s of every window in iteration s), so everything a lane
 // reads comes at wave-uniform offsets of its own rows: 32 slot codes (64 bytes) per 32 iterations, one pair of fragment-plane
@@ -2686,6 +2706,11 @@ hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuf
     if (!count) return hipSuccess;
     const int Wl = std::min(loop_lds_words(lcap), fb.fw2);
     hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
+    return hipGetLastError();
+}
+hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_qjobs, dim3((count + 63) / 64), dim3(64), 0, s, fb, k, count);
     return hipGetLastError();
 }
 hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s) {
