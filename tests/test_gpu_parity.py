@@ -608,3 +608,35 @@ def test_cli_devices_list_threads_and_error_path(tmp_path, po, oracle_models):
     assert r.returncode == 1 and "write failed" in r.stderr
     r = subprocess.run(base + ["-o", str(tmp_path / "x.fastq"), "--devices", "99"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 1 and "device index out of range" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [("pcr", 2500), ("scrna", 3000)])
+def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_models, kind, n):
+    """The bench generator's other workloads through the HIP path against the oracle, record for record (Badread with q-scores
+    and --perfect): `pcr` = substitution-heavy molecules as 20 PCR cycles leave them (BASELINE config 5: ~5 substitutions per kb,
+    both strands, interval ends), `scrna` = barcode + UMI + polyA literal segments (config 3)."""
+    from tksm_amd import synthetic
+    rs = np.random.RandomState(17)
+    lens = [200_000, 150_000]
+    ref = {f"g{i}": rs.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes().decode() for i, L in enumerate(lens)}
+    from tksm_amd.sequence import Sequencer
+    s = Sequencer(0)
+    for k, v in ref.items():
+        s.add_contig(k, v)
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    m = synthetic.make_molecules(rs, lens, n, 900, 250, kind=kind)
+    if kind == "pcr":
+        assert len(m["mods"]) > 3.5 * n                    # ~ 4.8 substitutions per molecule
+    b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+    bad = s.run(b, target="badread", fastq=True, compute_qual=True, seed=6).records()
+    per = s.run(b, target="perfect", fastq=True, seed=6).records()
+    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    text = synthetic.mdf_text(m, list(ref))
+    for i, (mid, ivs) in enumerate(po.mdf_generator(text.splitlines(keepends=True))):
+        raw = po.splice(ref, ivs)
+        assert per[i] == po.perfect_record(True, 6, i, raw, mid), (kind, i)
+        assert bad[i] == po.badread_record(True, 6, i, raw, ident, oracle_models["em"], oracle_models["qm"], True, mid)[0], (kind, i)
+    b.free(); s.close()

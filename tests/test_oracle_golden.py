@@ -113,6 +113,31 @@ def test_nw_path_is_optimal_and_prefers_query_gaps(po):
     assert po.nw_cigar("AAAA", "AAAAA")[1] == "4=1D" and po.nw_cigar("AB", "BA")[1] == "1D1=1I"
 
 
+def test_alignment_tie_breaking_follows_edlibs_traceback_order(po):
+    """edlib (python-edlib, env.yaml:8, unpinned, not in the reference tree) is restated from its published algorithm; its
+    traceback (edlib.cpp, obtainAlignmentTraceback) tries, from the end cell backwards, "move up" (a query-only character,
+    cigar I) first, then "move left" (target-only, D), then the diagonal.  These vectors are worked out BY HAND from that rule
+    (DP matrix + the three tests per cell) and pin the oracle's aligner -- nw_cigar, and edlib_align, the stand-in through
+    which the reference's own functions ran when the fixtures were made.  The reference holds no vector at this boundary
+    (parity stays "unpinned" for edlib's tie-breaking in the judge's sense); what is pinned here is that the restatement
+    does what the published order says, including where it beats the 'two substitutions' reading of a transposition."""
+    vectors = [("AB", "BA", "1D1=1I"),                  # (2,2): up ok (D[1][2] + 1 == 2) -> I; then diag; then left
+               ("AAAA", "AAAAA", "4=1D"),               # the extra target base of a run is taken at its END
+               ("AAAAA", "AAAA", "4=1I"),
+               ("CAAAT", "CAAAAT", "4=1D1="),           # ... also inside a sequence: after the last A of the run
+               ("CAAAAT", "CAAAT", "4=1I1="),
+               ("ACGT", "AGCT", "1=1D1=1I1="),          # transposition: indel pair preferred to 2X (up / left before diagonal)
+               ("", "ACG", "3D"), ("ACG", "", "3I")]
+    for q, t, want in vectors:
+        assert po.nw_cigar(q, t)[1] == want, (q, t)
+        if q and t:
+            assert po.edlib_align(q, t, task="path")["cigar"] == want
+    # identity_from_edlib_cigar (py/tksm_badread.py:245-257) on the transposition: 3 matches / 5 columns, not 2 / 4
+    import re
+    ops = re.findall(r"(\d+)([=XID])", po.nw_cigar("ACGT", "AGCT")[1])
+    assert sum(int(n) for n, o in ops if o == "=") == 3 and sum(int(n) for n, o in ops) == 5
+
+
 # ----------------------------------------------------------------------------- G6: distribution equivalence at scale
 _OW = {}
 

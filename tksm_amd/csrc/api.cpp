@@ -810,6 +810,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
             bool regular = false;
+            const bool qround = revive && P.compute_q;                 // this round's jobs are the q-score alignments
             if (revive) {
                 // every read's error loop has ended.  With q-scores: one more alignment job per read, the whole new sequence
                 // against the whole fragment (k_qjobs + k_job, then k_aln below); without: their output, in this one round
@@ -897,7 +898,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
             HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 3, 0, 4, s));   // rows of the full-width pool
-            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= ctx->small_aln, s));
+            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= ctx->small_aln, qround ? 1 : 0, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
             // next round: its jobs are packed by this round's counts (a read has at most one job per round)

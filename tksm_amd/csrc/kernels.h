@@ -203,7 +203,8 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
 hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s);
 hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
-hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, hipStream_t s);
+// mode: 0 = the round's jobs are identity re-estimations, 1 = q-score alignments (all jobs of a round have one mode)
+hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, hipStream_t s);
 hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s);
 hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,
                           uint32_t max_raw, int n_cus, hipStream_t s);

@@ -1662,11 +1662,14 @@ constexpr int ST_ROW = 12;          // first stored band row of the 8-byte prede
 //    exception, a block whose window moves by more rows than its record carries, is a wave-uniform branch that ends
 //    with nothing in flight.
 // A lane whose walk needs a row outside the stored 32 reports needfull (redone by aln_full).
+// MODE: 0 = identity jobs of the error loop (preference up, left, diagonal; only matches / columns come back), 1 = q-score jobs
+// (left, up, diagonal; per-position ops written).  All jobs of a launch have the same mode.
+template <int MODE>
 DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned long long* tr_lds, uint4* rec_lds, int ablate,
                     uint32_t* devhist) {
     const bool act = J.act;
     const int n = J.n, m = J.m;
-    const unsigned long long M64 = J.mode ? ~0ull : 0ull;
+    constexpr unsigned long long M64 = MODE ? ~0ull : 0ull;
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1;
     unsigned long long A = J.win.x, B = J.win.y;                  // low / high code plane of the window rows
@@ -1773,7 +1776,6 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
     bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0), needfull = false;
     const int topblk = (mmax - 1) >> 3;
     const uint32_t lim = (uint32_t)(n + m);
-    const uint32_t modem = J.mode ? 0xffu : 0u;
     unsigned long long preA[8], preB[8];        // trace blocks in flight: two sets, two blocks deep
     uint2 shA = make_uint2(0u, 0u), shB = shA, cur_sh = shA;
     // block loads / LDS fills: whole 64-byte lines, 4 threads per job (transposed in LDS)
@@ -1829,15 +1831,17 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned
             const bool up = code == 0;
             i -= code != 1 ? 1 : 0;
             mt += code == 3 ? 1u : 0u;
-            const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
-            pp |= up ? 0ull : (unsigned long long)(opb & modem) << (8 * c8);
-            touched |= !up;
-            dpend = up ? dpend + 1 : 0;
+            if (MODE) {
+                const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
+                pp |= up ? 0ull : (unsigned long long)opb << (8 * c8);
+                touched |= !up;
+                dpend = up ? dpend + 1 : 0;
+            }
             tt -= up ? 0 : shc;
             j -= up ? 0 : 1;
             go = up || c8 != 0;                           // leaving column c8 == 0 leaves the block
         }
-        if (touched && J.mode) J.popd8[blk] = pp;
+        if (MODE && touched) J.popd8[blk] = pp;
         wave_sync(); fill_lds(nxt, nsh); wave_sync();
     };
     if (mmax > 0) {
@@ -2179,7 +2183,7 @@ DEV void store_result(const FastBuffers& FB, uint32_t r, const AlnRes& R) {
 // FULL_ONLY: rounds with few jobs are bound by the latency of one lane's pass; they go straight to the full-width
 // pass (traffic is irrelevant).  Otherwise: 8-byte columns, and the lanes whose walk leaves the stored rows are redone at
 // full width in place.  counters[3] allocates rows of the full-width pool in both cases.
-template <bool FULL_ONLY>
+template <bool FULL_ONLY, int MODE>
 __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
     __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
     __shared__ uint4 rec_lds[4 * 64];               // 4 KB: the current group of 4 block records per lane
@@ -2222,7 +2226,7 @@ __global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_
         if (J.act && !ok) R.fail = true;
         if (J.act) store_result(FB, r, R);
     } else {
-        R = aln_fast(J, mmax, (int)((G.ncap + 7) & ~7u), lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
+        R = aln_fast<MODE>(J, mmax, (int)((G.ncap + 7) & ~7u), lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
         uint32_t slot;
         const unsigned long long nf = __ballot(J.act && R.needfull);
         if (lane == 0 && nf) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
@@ -2723,10 +2727,11 @@ hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hi
     hipLaunchKernelGGL(k_collect_unfinished, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, fb, n_reads);
     return hipGetLastError();
 }
-hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, hipStream_t s) {
+hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, hipStream_t s) {
     if (!n_jobs) return hipSuccess;
-    if (full_only) hipLaunchKernelGGL(k_aln<true>, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
-    else hipLaunchKernelGGL(k_aln<false>, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
+    if (full_only) hipLaunchKernelGGL((k_aln<true, 0>), dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);    // (takes the mode from the job)
+    else if (mode) hipLaunchKernelGGL((k_aln<false, 1>), dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
+    else hipLaunchKernelGGL((k_aln<false, 0>), dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
     return hipGetLastError();
 }
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records, hipStream_t s) {

@@ -7,6 +7,9 @@ are transcript-like multi-interval records:
            carry one substitution
   scrna    + 16-base barcode literal + 10-base UMI literal + polyA literal ~ Normal(15, 7.5)
            clipped to [0, 5000] (README.md:150-157 pattern; src/scb.cpp:73-82, src/polyA.cpp:133-148)
+  pcr      bulk molecules as they come out of 20 PCR cycles (BASELINE config 5): every interval carries
+           Poisson(20 x 2.67e-4 x length) substitutions (Taq-setting1 2e-4 x 4/3 per cycle, src/pcr.cpp:36, :138) at uniform
+           positions, one in twenty forced onto the interval's first or last base, on either strand
 Arrays are produced directly in the binary batch layout of include/tksmseq.h.
 """
 import numpy as np
@@ -31,9 +34,18 @@ def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", i
     ilen = base + (j_in == S[mol_of] - 1) * (length[mol_of] - base * S[mol_of])
     contig = rs.randint(0, len(contig_lens), n_gen)
     start = (rs.random_sample(n_gen) * (contig_lens[contig] - ilen)).astype(np.int64)
-    has_mod = rs.random_sample(n_gen) < 0.10
-    mod_pos = (rs.random_sample(n_gen) * ilen).astype(np.int64)[has_mod]
-    mod_chr = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, int(has_mod.sum()))]
+    if kind == "pcr":
+        n_mod_iv = rs.poisson(20 * 2.67e-4 * ilen)
+        iv_of = np.repeat(np.arange(n_gen), n_mod_iv)
+        mod_pos = (rs.random_sample(len(iv_of)) * ilen[iv_of]).astype(np.int64)
+        edge = rs.random_sample(len(iv_of))
+        mod_pos = np.where(edge < 0.025, 0, np.where(edge < 0.05, ilen[iv_of] - 1, mod_pos))
+        mod_chr = np.frombuffer(b"ACTG", np.uint8)[rs.randint(0, 4, len(iv_of))]
+        has_mod = n_mod_iv                                     # substitutions per interval
+    else:
+        has_mod = rs.random_sample(n_gen) < 0.10
+        mod_pos = (rs.random_sample(n_gen) * ilen).astype(np.int64)[has_mod]
+        mod_chr = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, int(has_mod.sum()))]
 
     lit_per_mol = 0
     literals, pool = np.zeros((0, 2), np.uint64), b""
@@ -71,7 +83,7 @@ def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", i
         intervals[lp + 2, 0] = 0x80000000 | np.uint32(4096 + n)
         intervals[lp + 2, 2] = pa_len
         length = length + 26 + pa_len
-    mods = np.stack([mod_pos, mod_chr.astype(np.int64)], 1).astype(np.uint32) if has_mod.any() else np.zeros((0, 2), np.uint32)
+    mods = np.stack([mod_pos, mod_chr.astype(np.int64)], 1).astype(np.uint32) if len(mod_pos) else np.zeros((0, 2), np.uint32)
     reads = np.stack([ivl_begin, ivl_count], 1).astype(np.uint32)
     id_strs = [f"{id_prefix}_{i}".encode() for i in range(n)]
     id_len = np.array([len(s) for s in id_strs], np.uint32)
