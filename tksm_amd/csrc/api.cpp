@@ -240,11 +240,14 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
                 int boff = 0;
                 for (int j = 0; j < k; j++) {
                     const uint32_t kc = (uint32_t)(i >> (2 * (k - 1 - j))) & 3u;
-                    if (alt >> 63) { e[j] = (1u << 12) | kc; continue; }          // the k-mer itself
+                    if (alt >> 63) { e[j] = (1u << 12) | (kc & 1u) | ((kc >> 1) << 5); continue; }          // the k-mer itself
                     const uint32_t len = (uint32_t)(alt >> (3 * j)) & 7u;
                     const uint32_t codes = (uint32_t)(alt >> (24 + 2 * boff)) & ((1u << (2 * len)) - 1u);
                     boff += (int)len;
-                    e[j] = ((len == 1 && codes == kc) ? 0u : 0x8000u) | (len << 12) | codes;
+                    // symbols planar: low bits of the (up to 5) symbols in bits 0..4, high bits in bits 5..9 (what k_job queues)
+                    uint32_t planar = 0;
+                    for (uint32_t x = 0; x < len && x < 5; x++) planar |= (((codes >> (2 * x)) & 1u) << x) | (((codes >> (2 * x + 1)) & 1u) << (5 + x));
+                    e[j] = ((len == 1 && codes == kc) ? 0u : 0x8000u) | (len << 12) | planar;
                 }
                 for (int q = 0; q < 4; q++) enc[(i * A + a) * 4 + q] = e[2 * q] | (e[2 * q + 1] << 16);
             }

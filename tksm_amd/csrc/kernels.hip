@@ -1030,7 +1030,8 @@ DEV void finish_read(const BatchView& B, const SimParams& P, const SimBuffers& O
     }
 }
 
-// A draw as the fast pipeline carries it: the alternative's eight 16-bit slot encodings (length << 12 | 2-bit codes; bit
+// A draw as the fast pipeline carries it: the alternative's eight 16-bit slot encodings (length << 12 | symbols, planar: low
+// bits of the up to 5 symbols in bits 0..4, high bits in bits 5..9; bit
 // 15 = the slot differs from the original base), ErrModelView::alts_enc for a model alternative, random_change_enc for
 // add_one_random_change.  A slot is applied if it differs and the position is still pristine (py/tksm_badread.py:378-390).
 DEV uint32_t draw_slot(const uint4& A, int jj) {
@@ -1040,15 +1041,17 @@ DEV uint32_t draw_slot(const uint4& A, int jj) {
 
 // add_one_random_change (py/tksm_badread.py:199-213) on the k-mer with index kidx (first base in the high bits): every
 // slot keeps its base except slot pos: substitution by the r3-th next base, insertion of base4 before / after, deletion
+DEV uint32_t planar1(uint32_t a) { return (a & 1u) | ((a >> 1) << 5); }                                   // one symbol
+DEV uint32_t planar2(uint32_t a, uint32_t b) { return (a & 1u) | ((b & 1u) << 1) | ((a >> 1) << 5) | ((b >> 1) << 6); }   // two symbols
 DEV uint4 random_change_enc(int kidx, int k, uint32_t type, uint32_t pos, uint32_t base4, uint32_t side, uint32_t r3) {
     uint32_t e[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint32_t kc = j < k ? (uint32_t)(kidx >> (2 * (k - 1 - j))) & 3u : 0u;
-        uint32_t v = (1u << 12) | kc;
+        uint32_t v = (1u << 12) | planar1(kc);
         if ((uint32_t)j == pos)
-            v = type == 0 ? 0x8000u | (1u << 12) | ((kc + r3) & 3u)
-              : type == 1 ? 0x8000u | (2u << 12) | (side ? (kc | (base4 << 2)) : (base4 | (kc << 2)))
+            v = type == 0 ? 0x8000u | (1u << 12) | planar1((kc + r3) & 3u)
+              : type == 1 ? 0x8000u | (2u << 12) | (side ? planar2(kc, base4) : planar2(base4, kc))
                           : 0x8000u;
         e[j] = j < k ? v : 0u;
     }
@@ -1121,13 +1124,13 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
             if (sh > 31) fail = true;
             // the slot's symbols, 2 bits each: the original base of a pristine slot, else the stored codes (the fast
             // pipeline stores every symbol explicitly: its fragments are plain ACGT, no original-base markers)
-            const uint32_t syms = code ? code & 0x3ffu : (uint32_t)orig;
-            colb[off] = (uint8_t)((syms & 3u) | ((uint32_t)(sh & 31) << 2));
-            for (int x2 = 1; x2 < len; x2++) colb[off + x2] = (uint8_t)((syms >> (2 * x2)) & 3u);
+            const uint32_t syms = code ? code & 0x3ffu : planar1((uint32_t)orig);
+            colb[off] = (uint8_t)((syms & 1u) | (((syms >> 5) & 1u) << 1) | ((uint32_t)(sh & 31) << 2));
+            for (int x2 = 1; x2 < len; x2++) colb[off + x2] = (uint8_t)(((syms >> x2) & 1u) | (((syms >> (5 + x2)) & 1u) << 1));
         }
         if (out_seq) {
-            const uint32_t syms = code ? code & 0x3ffu : (uint32_t)orig;
-            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = base_char((int)(syms >> (2 * x2))); }
+            const uint32_t syms = code ? code & 0x3ffu : planar1((uint32_t)orig);
+            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = base_char((int)(((syms >> x2) & 1u) | (((syms >> (5 + x2)) & 1u) << 1))); }
         }
         if (ne) last_nonempty = q + 63 - __builtin_clzll(ne);
         base += total;
@@ -2015,12 +2018,17 @@ __global__ __launch_bounds__(64) void k_qjobs(FastBuffers FB, int k, uint32_t co
 // reads comes at wave-uniform offsets of its own rows: 32 slot codes (64 bytes) per 32 iterations, one pair of fragment-plane
 // words per 64 -- unconditional, prefetched loads.  What differs between lanes is how many columns a slot emits (0 .. 5
 // symbols), i.e. when a block of 8 columns is complete; since in every iteration SOME lane completes one, the lanes do not
-// pack a block the moment it is full: column bytes {symbol, window shift} queue up in three registers and every fourth slot
-// each lane packs at most one block (the queue holds 24; a lane that falls behind packs at once, rarely).  Records are
-// kept in registers and stored four at a time (one 64-byte line).  Record layout: FastBuffers::job_cols; the shift of a
-// slot's first column = rows the window top moves, top = max(1, slot + 1 - 31) (the guided band).
+// pack a block the moment it is full: a slot's columns join per-lane bit queues -- one queue per record field (low / high
+// symbol bit, low 4 bits / bit 4 of the window shift), which is why slot codes keep their symbols planar -- and every fourth
+// slot each lane packs at most one block, i.e. shifts 8 columns out of its queues (they hold 32; a lane that falls behind
+// packs at once, rarely).  The kernel is bound by its vector instructions: a record costs ~40 of them here (byte-wise column
+// queues and multiplicative bit gathers: ~125).  Plane words and finished records pass through LDS (dynamic per-lane
+// indexing without selects); records leave four at a time (one 64-byte line).  Record layout: FastBuffers::job_cols; the
+// shift of a slot's first column = rows the window top moves, top = max(1, slot + 1 - 31) (the guided band).
 struct __attribute__((packed, aligned(4))) U4a { uint32_t x, y, z, w; };
 __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
+    __shared__ unsigned long long pl[4 * 2 * 64];                      // aligned plane words: [stream word & 3][plane][lane]
+    __shared__ uint4 rs[4 * 64];                                       // finished records: [record & 3][lane]
     const int lane = threadIdx.x;
     const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
     const uint32_t rng = range_of_job(FB, job0);
@@ -2043,51 +2051,47 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
     // fragment planes as a stream aligned to `base` (word j = positions base + 64 j ..), so that every lane is at the same bit of
-    // its own stream: four words around the current slot (the one before it, its own, two after: a block is packed up to ~60 slots
-    // after it began, and its entering rows lie 33 .. 95 positions ahead of where it began), the next raw word in flight
+    // its own stream.  LDS keeps the words j - 1 .. j + 2 around the current slot's word j (a block is packed up to ~60 slots
+    // after it began, and its entering rows lie 33 .. 95 positions ahead of where it began); the next raw word is in flight.
     const int wbase = base >> 6, bsh = base & 63;
     const int wlast = FB.fw - 1;
     auto fpw = [&](int w) { return fp[min(max(w, 0), wlast)]; };
-    auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 r; r.x = funnel128(a.x, b.x, bsh); r.y = funnel128(a.y, b.y, bsh); return r; };
-    ulonglong2 Rl, Rn;                                                // the last raw word used, the next one
-    ulonglong2 Wm, W0, W1, W2;                                        // aligned words j - 1, j, j + 1, j + 2 around the current slot's word j
+    auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 v; v.x = funnel128(a.x, b.x, bsh); v.y = funnel128(a.y, b.y, bsh); return v; };
+    auto put_word = [&](int j, const ulonglong2& v) { pl[((j & 3) * 2 + 0) * 64 + lane] = v.x; pl[((j & 3) * 2 + 1) * 64 + lane] = v.y; };
+    ulonglong2 Rl, Rn, W0;                                            // last raw word used, next raw word; the current aligned word
     {
         const ulonglong2 r0 = fpw(wbase), r1 = fpw(wbase + 1), r2 = fpw(wbase + 2), r3 = fpw(wbase + 3);
-        Wm = make_ulonglong2(0ull, 0ull);                              // positions before the window's first word are never asked for
-        W0 = aligned(r0, r1); W1 = aligned(r1, r2); W2 = aligned(r2, r3);
+        W0 = aligned(r0, r1);
+        put_word(-1, make_ulonglong2(0ull, 0ull)); put_word(0, W0); put_word(1, aligned(r1, r2)); put_word(2, aligned(r2, r3));
         Rl = r3; Rn = fpw(wbase + 4);
     }
-    int jcur = 0;                                                     // index of W0 in the stream
-    auto bits32 = [&](int rel, bool hi) -> uint32_t {                 // plane bits [rel, rel + 32) of the stream (rel: position - base)
-        const int off = rel - 64 * (jcur - 1), wq = off >> 6;        // 0 <= off < 224
-        const unsigned long long a0 = hi ? Wm.y : Wm.x, a1 = hi ? W0.y : W0.x, a2 = hi ? W1.y : W1.x, a3 = hi ? W2.y : W2.x;
-        const unsigned long long lo = wq == 0 ? a0 : wq == 1 ? a1 : a2, up = wq == 0 ? a1 : wq == 1 ? a2 : a3;
-        return lo32(funnel128(lo, up, off & 63));
+    int jcur = 0;                                                     // stream index of the current slot's word
+    auto bits32 = [&](int rel, int plane) -> uint32_t {               // plane bits [rel, rel + 32) of the stream (rel: position - base)
+        const int jw = rel >> 6;
+        return lo32(funnel128(pl[((jw & 3) * 2 + plane) * 64 + lane], pl[(((jw + 1) & 3) * 2 + plane) * 64 + lane], rel & 63));
     };
     if (act) {                                                        // the first 64 window rows (positions p0 .. p0 + 63)
-        FB.job_win[2ull * job] = funnel128(W0.x, W1.x, skip);
-        FB.job_win[2ull * job + 1] = funnel128(W0.y, W1.y, skip);
+        FB.job_win[2ull * job] = funnel128(pl[(0 * 2 + 0) * 64 + lane], pl[(1 * 2 + 0) * 64 + lane], skip);
+        FB.job_win[2ull * job + 1] = funnel128(pl[(0 * 2 + 1) * 64 + lane], pl[(1 * 2 + 1) * 64 + lane], skip);
     }
     int t = 1, col = 0;                                               // window top after the last column; columns emitted
-    int tk = 1, npend = 0, nrec = 0;                                  // top before the first queued column; queued column bytes; records packed
-    unsigned long long q0 = 0ull, q1 = 0ull, q2 = 0ull;               // the queue: {bits 0-1 symbol, bits 2-6 shift} per column
-    uint4 rb0 = make_uint4(0u, 0u, 0u, 0u), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+    int tk = 1, npend = 0, nrec = 0;                                  // top before the first queued column; queued columns; records packed
+    uint32_t qlo = 0u, qhi = 0u, qsx = 0u;                            // queues, one bit per column: symbol low / high bit, bit 4 of the shift
+    uint32_t qn0 = 0u, qn1 = 0u, qn2 = 0u, qn3 = 0u;                  // low 4 bits of the shift, 8 columns per word
     bool fail = false;
-    auto bit_of_bytes = [](unsigned long long x) { return (uint32_t)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); };
     auto pack_block = [&](int ncols) {                                // the first (up to 8) queued columns -> one record
-        const unsigned long long v = q0;
-        unsigned long long nb4 = (v >> 2) & 0x0f0f0f0f0f0f0f0full;
-        nb4 = (nb4 | (nb4 >> 4)) & 0x00ff00ff00ff00ffull; nb4 = (nb4 | (nb4 >> 8)) & 0x0000ffff0000ffffull; nb4 = nb4 | (nb4 >> 16);
-        const uint32_t shw = (uint32_t)nb4, shx = bit_of_bytes(v >> 6), clo = bit_of_bytes(v), chi = bit_of_bytes(v >> 1);
-        const int adv = (int)((((v >> 2) & 0x1f1f1f1f1f1f1f1full) * 0x0101010101010101ull) >> 56);
+        const uint32_t shw = qn0, clo = qlo & 0xffu, chi = qhi & 0xffu, shx = qsx & 0xffu;
+        uint32_t a4 = (shw & 0x0f0f0f0fu) + ((shw >> 4) & 0x0f0f0f0fu);
+        a4 += a4 >> 16;
+        const int adv = (int)((a4 + (a4 >> 8)) & 0xffu) + 16 * __popc(shx);
         const int rel = skip + tk - 1 + 64;                           // the 32 fragment rows after the window at the block's start
-        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), bits32(rel, false), bits32(rel, true));
+        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), bits32(rel, 0), bits32(rel, 1));
         tk += adv;
-        q0 = q1; q1 = q2; q2 = 0ull; npend -= ncols;
+        qlo >>= 8; qhi >>= 8; qsx >>= 8; qn0 = qn1; qn1 = qn2; qn2 = qn3; qn3 = 0u; npend -= ncols;
         const int tq = nrec++;
         if (8 * tq < ncap_l) {
-            if ((tq & 3) == 0) rb0 = rec; else if ((tq & 3) == 1) rb1 = rec; else if ((tq & 3) == 2) rb2 = rec;
-            else { rb3 = rec; uint4* d = jc + (tq & ~3); d[0] = rb0; d[1] = rb1; d[2] = rb2; d[3] = rb3; }
+            rs[(tq & 3) * 64 + lane] = rec;
+            if ((tq & 3) == 3) { uint4* d = jc + (tq & ~3); d[0] = rs[lane]; d[1] = rs[64 + lane]; d[2] = rs[128 + lane]; d[3] = rs[192 + lane]; }
         }
     };
     for (int s0 = 0; s0 < nmax; s0 += 32) {
@@ -2097,37 +2101,36 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
         const U4a c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
         const uint32_t cw[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
         const int bit0 = s0 & 32;
+        const uint32_t olo = (uint32_t)(W0.x >> bit0), ohi = (uint32_t)(W0.y >> bit0);      // the chunk's 32 original bases
 #pragma unroll
         for (int q = 0; q < 32; q++) {
             const int p = s0 + q - skip;                              // slot within the window
             const bool on = act && p >= 0 && p < n;
             const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-            // the slot's symbols, 2 bits each (a pristine slot: its original base, bit (s & 63) of the current plane word)
-            const uint32_t orig = (uint32_t)((W0.x >> (bit0 + q)) & 1ull) | ((uint32_t)((W0.y >> (bit0 + q)) & 1ull) << 1);
             const int len = on ? (code ? (int)((code >> 12) & 7u) : 1) : 0;
-            const uint32_t syms = code ? code & 0x3ffu : orig;
-            // ... as column bytes: the first one carries the shift of the window top, top = max(1, slot + 1 - 31)
+            const uint32_t m5 = (1u << len) - 1u;
+            // the slot's symbols (a pristine slot: its original base) join the queues; its first column carries the shift of the
+            // window top, top = max(1, slot + 1 - 31)
+            const uint32_t lo5 = (code ? code & 31u : (olo >> q) & 1u) & m5, hi5 = (code ? (code >> 5) & 31u : (ohi >> q) & 1u) & m5;
             const int tn = max(1, p + 1 - 31), sh = len > 0 ? tn - t : 0;
             fail |= sh > 31;
             t += sh;
-            unsigned long long v = (unsigned long long)((syms & 0x003u) | ((syms & 0x00cu) << 6) | ((syms & 0x030u) << 12) | ((syms & 0x0c0u) << 18)) |
-                                   ((unsigned long long)(syms & 0x300u) << 24) | (unsigned long long)((uint32_t)(sh & 31) << 2);
-            v &= len >= 8 ? ~0ull : (1ull << (8 * len)) - 1ull;
-            // ... join the queue at byte npend
-            const int which = npend >> 3, bs = 8 * (npend & 7);
-            const unsigned long long lo = v << bs, up = bs > 24 ? v >> (64 - bs) : 0ull;
-            q0 |= which == 0 ? lo : 0ull;
-            q1 |= which == 1 ? lo : (which == 0 ? up : 0ull);
-            q2 |= which == 2 ? lo : (which == 1 ? up : 0ull);
+            qlo |= lo5 << npend; qhi |= hi5 << npend; qsx |= (uint32_t)(sh >> 4) << npend;
+            const uint32_t nib = (uint32_t)(sh & 15) << (4 * (npend & 7));
+            const int which = npend >> 3;
+            qn0 |= which == 0 ? nib : 0u; qn1 |= which == 1 ? nib : 0u; qn2 |= which == 2 ? nib : 0u; qn3 |= which == 3 ? nib : 0u;
             npend += len; col += len;
-            // every fourth slot a lane packs one block if it has one; a lane whose queue could overflow with the next slot at once
+            // every fourth slot a lane packs one block if it has one; a lane whose queues could overflow with the next slot at once
             if ((q & 3) == 3) { if (npend >= 8) pack_block(8); }
-            else if (__ballot(npend > 19) != 0ull) { if (npend > 19) pack_block(8); }
+            else if (__ballot(npend > 27) != 0ull) { if (npend > 27) pack_block(8); }
         }
         // the plane words follow the slot position: every lane moves on at the same slot
         if (bit0) {
             jcur++;
-            Wm = W0; W0 = W1; W1 = W2; W2 = aligned(Rl, Rn); Rl = Rn;
+            const ulonglong2 nw = aligned(Rl, Rn);
+            W0.x = pl[((jcur & 3) * 2 + 0) * 64 + lane]; W0.y = pl[((jcur & 3) * 2 + 1) * 64 + lane];
+            put_word(jcur + 2, nw);
+            Rl = Rn;
             Rn = fpw(wbase + jcur + 4);
         }
     }
@@ -2136,12 +2139,12 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
     while (npend >= 8) pack_block(8);
     if (npend > 0) pack_block(npend);                                 // the last, partial block
     if (m <= ncap_l) {
-        // the complete records still in registers
+        // the complete records still in LDS
         const int cnt = nrec & 3;
         uint4* d = jc + (nrec & ~3);
-        if (cnt > 0) d[0] = rb0;
-        if (cnt > 1) d[1] = rb1;
-        if (cnt > 2) d[2] = rb2;
+        if (cnt > 0) d[0] = rs[lane];
+        if (cnt > 1) d[1] = rs[64 + lane];
+        if (cnt > 2) d[2] = rs[128 + lane];
     }
     FB.job_meta[4ull * job + 3] = (uint32_t)(m > ncap_l ? 0 : m);
     if (m > ncap_l) {
@@ -2183,8 +2186,11 @@ DEV void store_result(const FastBuffers& FB, uint32_t r, const AlnRes& R) {
 // FULL_ONLY: rounds with few jobs are bound by the latency of one lane's pass; they go straight to the full-width
 // pass (traffic is irrelevant).  Otherwise: 8-byte columns, and the lanes whose walk leaves the stored rows are redone at
 // full width in place.  counters[3] allocates rows of the full-width pool in both cases.
+#ifndef ALN_WAVES
+#define ALN_WAVES 4
+#endif
 template <bool FULL_ONLY, int MODE>
-__global__ __launch_bounds__(64) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
+__global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
     __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
     __shared__ uint4 rec_lds[4 * 64];               // 4 KB: the current group of 4 block records per lane
     const int lane = threadIdx.x;

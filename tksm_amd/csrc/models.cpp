@@ -182,7 +182,7 @@ bool load_error_model(const std::string& name_or_path, ErrorModelHost& m, std::s
             if (!align_kmers(row.kmer, kv[0], slots)) { err = "cannot align alternative " + kv[0] + " to " + row.kmer; return false; }
             uint64_t v = 0; int nbases = 0;
             for (size_t j = 0; j < slots.size(); j++) {
-                if (slots[j].size() > 7) { err = "alternative slot too long"; return false; }
+                if (slots[j].size() > 5) { err = "alternative slot longer than 5 bases (the slot codes hold 5 symbols)"; return false; }
                 v |= (uint64_t)slots[j].size() << (3 * j);
                 for (char ch : slots[j]) {
                     int c = base_code(ch);
