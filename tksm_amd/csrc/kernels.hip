@@ -1334,16 +1334,6 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
             }
             alt[b] = EM.alts_enc[at];
         }
-        uint32_t cur[LOOP_B][8];
-#pragma unroll
-        for (int b = 0; b < LOOP_B; b++) {
-            const bool odd = di[b] & 1;
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const uint32_t e0 = (nbw[b].v[jj >> 1] >> (16 * (jj & 1))) & 0xffffu, e1 = (nbw[b].v[(jj + 1) >> 1] >> (16 * ((jj + 1) & 1))) & 0xffffu;
-                cur[b][jj] = odd ? e1 : e0;
-            }
-        }
         // ---- apply in order
         uint32_t wrote = 0u;                                  // draws of this batch that wrote slots
 #pragma unroll
@@ -1357,35 +1347,47 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                 if ((long long)n + 1 > loop_limit) { st = DONE; st_draws = (int)loop_limit; break; }
             }
             if (cls[b] != 0) {
-                uint4 A = (cls[b] == 2) ? make_uint4(0u, 0u, 0u, 0u) : alt[b];
-                if (cls[b] == 2) {                            // add_one_random_change (:199-213)
+                uint4 A = alt[b];
+                if (cls[b] == 2) {
+                    // add_one_random_change (:199-213): one slot of the k-mer changes -- substitution by the r3-th next base,
+                    // insertion of base4 before / after, deletion; the other slots keep their base (encoding 0: never applied)
                     const uint32_t type = __umulhi(dz[b], 3u), pos = __umulhi(dv[b], (uint32_t)k);
                     const uint32_t base4 = dv[b] & 3u, side = (dv[b] >> 2) & 1u;
                     const uint32_t r3 = (((dz[b] & 0xffffu) * 3u) >> 16) + 1u;
-                    A = random_change_enc(kidx[b], k, type, pos, base4, side, r3);
+                    const uint32_t kc = ((uint32_t)kidx[b] >> (2 * (k - 1 - (int)pos))) & 3u;
+                    const uint32_t v = type == 0 ? 0x8000u | (1u << 12) | planar1((kc + r3) & 3u)
+                                     : type == 1 ? 0x8000u | (2u << 12) | (side ? planar2(kc, base4) : planar2(base4, kc))
+                                                 : 0x8000u;
+                    const uint32_t w = v << (16 * (pos & 1u)), which = pos >> 1;
+                    A = make_uint4(which == 0 ? w : 0u, which == 1 ? w : 0u, which == 2 ? w : 0u, which == 3 ? w : 0u);
                 }
-                if ((A.x | A.y | A.z | A.w) & 0x80008000u) {
+                // the slots that differ from the original base (bit 15 of their encodings), from the resume point on
+                uint32_t dm = ((A.x >> 15) & 1u) | ((A.x >> 31) << 1) | (((A.y >> 15) & 1u) << 2) | ((A.y >> 31) << 3) |
+                              (((A.z >> 15) & 1u) << 4) | ((A.z >> 31) << 5) | (((A.w >> 15) & 1u) << 6) | ((A.w >> 31) << 7);
+                dm &= ((1u << k) - 1u) & ~((1u << resume_j) - 1u);
+                if (dm) {
                     // slot codes read before an overlapping earlier draw of this batch wrote: read them again (rare)
                     bool stale = false;
 #pragma unroll
                     for (int b2 = 0; b2 < LOOP_B; b2++) if (b2 < b) stale |= ((wrote >> b2) & 1u) && abs(di[b] - di[b2]) < k;
-                    if (stale) {
-#pragma unroll
-                        for (int jj = 0; jj < 8; jj++) if (jj < k) cur[b][jj] = (uint32_t)gnb[di[b] + jj];
-                    }
-                    // slots in order (:378-403): applied if the slot differs from the original base and the position is pristine
+                    if (stale) nbw[b] = *reinterpret_cast<const W5*>(gnb + (di[b] & ~1));
+                    // in slot order (:378-403): applied if the position is still pristine
                     const double f15 = est * sqrt_inrange(est);
+                    const int odd = di[b] & 1;
                     int stop_at = -1;
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) {
-                        const uint32_t e = draw_slot(A, jj);
-                        if (jj < k && jj >= resume_j && (e >> 15) && cur[b][jj] == 0u && stop_at < 0) {
+                    while (dm) {
+                        const int jj = __builtin_ctz(dm);
+                        dm &= dm - 1u;
+                        const int ent = jj + odd, wi = ent >> 1;
+                        const uint32_t cw2 = wi == 0 ? nbw[b].v[0] : wi == 1 ? nbw[b].v[1] : wi == 2 ? nbw[b].v[2] : wi == 3 ? nbw[b].v[3] : nbw[b].v[4];
+                        if (((cw2 >> (16 * (ent & 1))) & 0xffffu) == 0u) {
+                            const uint32_t e = draw_slot(A, jj);
                             gnb[di[b] + jj] = (uint16_t)(e | 0x8000u);
                             wrote |= 1u << b;
                             change_count++;
                             const int len_j = (int)((e >> 12) & 7u);
                             errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
-                            if (++cc25 == 25) { cc25 = 0; stop_at = jj; }       // ALIGNMENT_INTERVAL
+                            if (++cc25 == 25) { cc25 = 0; stop_at = jj; dm = 0u; }       // ALIGNMENT_INTERVAL
                         }
                     }
                     if (stop_at >= 0) {
