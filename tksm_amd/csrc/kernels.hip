@@ -1200,7 +1200,7 @@ DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos
 // slot codes stay in HBM (read and written only by the draws that change something).
 // A read that stops at a re-estimation point asks k_err for an alignment job (pending = 2); one whose loop has ended goes on
 // to its trims / q-score job / output there (stage 4).  k_err walks the same list of reads right after this kernel.
-constexpr int LOOP_B = 6;
+constexpr int LOOP_B = 4;
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
                                               uint32_t begin, uint32_t count, int Wl, int from_jobs, uint32_t c0, uint32_t c1) {
     uint32_t* lf = reinterpret_cast<uint32_t*>(lds_raw);      // [Wl][64]: word w of lane l at w * 64 + l (conflict-free)
@@ -2709,9 +2709,10 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
                        lds_ncap, from_jobs, c0, c1);
     return hipGetLastError();
 }
-// fragment words per lane kept in LDS: the whole padded fragment of the longest read, at most LOOP_WL_MAX words (1280
-// bases, 20 KB per wave: 8 waves per CU); the words beyond come from HBM
-constexpr int LOOP_WL_MAX = 80;
+// fragment words per lane kept in LDS: at most LOOP_WL_MAX words (512 bases, 8 KB per wave); the words beyond come from HBM
+// (L2).  Measured with three batches in flight (bench.py): 80 words / 6 draws at a time (20 KB, 228 VGPRs: 2 waves per SIMD)
+// 8.11 M reads/s; 48 / 4: 8.29 M; 32 / 4 (164 VGPRs: 3 waves per SIMD): 8.42 M; no LDS at all: 8.25 M; 2 draws at a time: 6.8 M
+constexpr int LOOP_WL_MAX = 32;
 int loop_lds_words(int lcap) { return std::min(LOOP_WL_MAX, (((lcap + 15) / 16 + 1) + 3) & ~3); }
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
