@@ -338,18 +338,21 @@ def test_edge_cases_empty_short_constant_identity_and_limits(po, oracle_models):
     # documented limit: a molecule beyond the LDS-resident working set
     s_big = rs.choice(np.frombuffer(b"ACGT", np.uint8), 80_000).tobytes().decode()
     s.add_contig("big", s_big.encode())
-    with pytest.raises(TksmSeqError) as e:
-        s.run(s.batch_from_mdf("+huge\t1\t\nbig\t0\t70000\t+\t\n"), target="badread")
-    assert e.value.code == 6
-    # between the two limits (18 k: the exact wave-wide kernel, 43 k: the fast pipeline) a plain ACGT molecule runs,
-    # bit-exact with the oracle; one that needs the wave-wide kernel (an N) is refused, by name
+    # Badread mode has no practical length limit any more (100 kb; the reference has none): a 60 kb ACGT molecule takes the fast
+    # pipeline, a 30 kb one with N's (real genomes have N runs) the exact wave-wide kernel with its working set in HBM -- next to
+    # ordinary molecules in the same batch, all bit-exact with the oracle
     em, qm = oracle_models["em"], oracle_models["qm"]
-    long_ivs = [("big", 100, 30100, "+", "")]
-    got = s.run(s.batch_from_mdf("+long\t1\t\nbig\t100\t30100\t+\t\n"), target="badread", seed=SEED).records()[0]
-    assert got == po.badread_record(True, SEED, 0, po.splice({"big": s_big}, long_ivs), ident, em, qm, True, "long")[0]
+    mdf = ("+long60\t1\t\nbig\t100\t60100\t+\t\n" "+n30\t1\t\nbig\t5000\t35000\t-\t200N,201N,202N,15000N,29999N\n"
+           "+short\t1\t\nbig\t7\t907\t+\t\n" "+n_short\t1\t\nbig\t40000\t41000\t+\t500N\n")
+    ivs = [("long60", [("big", 100, 60100, "+", "")]), ("n30", [("big", 5000, 35000, "-", "200N,201N,202N,15000N,29999N")]),
+           ("short", [("big", 7, 907, "+", "")]), ("n_short", [("big", 40000, 41000, "+", "500N")])]
+    got = s.run(s.batch_from_mdf(mdf), target="badread", seed=SEED).records()
+    for i, (mid, iv) in enumerate(ivs):
+        assert got[i] == po.badread_record(True, SEED, i, po.splice({"big": s_big}, iv), ident, em, qm, True, mid)[0], mid
+    s.add_contig("huge", "".join(np.random.RandomState(6).choice(list("ACGT"), 120_000)))
     with pytest.raises(TksmSeqError) as e:
-        s.run(s.batch_from_mdf("+long\t1\t\nbig\t100\t30100\t+\t200N\n"), target="badread", seed=SEED)
-    assert e.value.code == 6 and "wave-wide kernel" in str(e.value)
+        s.run(s.batch_from_mdf("+huge\t1\t\nhuge\t0\t110000\t+\t\n"), target="badread")
+    assert e.value.code == 6 and "100 000" in str(e.value)
     # ... which the --perfect path does not have
     big = s.run(s.batch_from_mdf("+huge\t1\t\nbig\t5\t70005\t-\t17C\n"), target="perfect", seed=3).records()[0]
     assert big == po.perfect_record(True, 3, 0, po.splice({"big": s_big}, [("big", 5, 70005, "-", "17C")]), "huge")

@@ -580,8 +580,9 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     int wpw = tk::WAVES_PER_WG;
     while (wpw > 1 && tk::simulate_lds_bytes(s_lcap, s_ncap, wpw) > 160 * 1024) wpw >>= 1;
     const int lds = tk::simulate_lds_bytes(s_lcap, s_ncap, wpw);
-    if (!direct && (lds > 160 * 1024 || ncap >= 65000 || lcap >= 65000)) {
-        ctx->err = "molecule of " + std::to_string(b->max_raw) + " bases exceeds the LDS-resident limit of this build";
+    // Badread mode: the fast pipeline keeps one joined window (1.5 x the fragment) of a read's last visit in LDS: ~100 kb
+    if (!direct && (lds > 160 * 1024 || (badread && !ctx->force_slow ? lcap > 100000 : (ncap >= 65000 || lcap >= 65000)))) {
+        ctx->err = "molecule of " + std::to_string(b->max_raw) + " bases exceeds the limit of this build (Badread mode: 100 000 bases)";
         return TKSMSEQ_ELIMIT;
     }
     int wgs_per_cu = std::min(std::min(32 / wpw, 16), std::max(1, (160 * 1024) / std::max(lds, 1)));
@@ -955,16 +956,17 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         }
     }
     if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    HIPCHK(ctx, tk::launch_scan(ctx->w_reclen.as<uint64_t>(), ctx->w_recoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
     unsigned long long* sums = ctx->w_sums.as<unsigned long long>();
-    HIPCHK(ctx, tk::launch_sum_u32(ctx->w_status.as<uint32_t>(), n, sums, s));
-    HIPCHK(ctx, tk::launch_sum_u32(ctx->w_outlen.as<uint32_t>(), n, sums + 1, s));
-    if (T) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     unsigned long long hs[2] = {0, 0}; uint64_t total = 0;
-    HIPCHK(ctx, hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipMemcpyAsync(&total, ctx->w_recoff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    if (hs[0]) {
+    for (int pass = 0;; pass++) {
+        HIPCHK(ctx, tk::launch_scan(ctx->w_reclen.as<uint64_t>(), ctx->w_recoff.as<uint64_t>(), n, ctx->w_scan.p, ctx->w_scan.cap, s));
+        HIPCHK(ctx, tk::launch_sum_u32(ctx->w_status.as<uint32_t>(), n, sums, s));
+        HIPCHK(ctx, tk::launch_sum_u32(ctx->w_outlen.as<uint32_t>(), n, sums + 1, s));
+        if (T && pass == 0) HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+        HIPCHK(ctx, hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(&total, ctx->w_recoff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        if (!hs[0]) break;
         std::vector<uint32_t> st(n);
         HIPCHK(ctx, hipMemcpy(st.data(), ctx->w_status.p, n * 4, hipMemcpyDeviceToHost));
         uint32_t any = 0; uint64_t first = 0;
@@ -977,14 +979,35 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         }
         if (any & 2) { ctx->err = "modification position outside its interval at read " + std::to_string(first); return TKSMSEQ_EINVAL; }
         if (any & 4) { ctx->err = "out of memory for the unbanded alignment fallback at read " + std::to_string(first) + " (TKSMSEQ_FULL_POOL_MB)"; return TKSMSEQ_ENOMEM; }
+        if ((any & 8) && pass == 0 && badread) {
+            // molecules that need the exact wave-wide kernel (a non-ACGT byte, an alignment outside the band representation)
+            // and are longer than its LDS-resident working set: the same kernel with the working sets in HBM, then the
+            // sums and record offsets once more
+            std::vector<uint32_t> big;
+            for (uint64_t i = 0; i < n; i++) if (st[i] & 8) big.push_back((uint32_t)i);
+            const int n_waves = (int)std::min<size_t>(big.size(), 64);
+            const size_t per_wave = tk::simulate_big_bytes(lcap, ncap);
+            HIPCHK(ctx, ctx->w_biglist.ensure(big.size() * 4 + 16));
+            HIPCHK(ctx, ctx->w_bigscratch.ensure(per_wave * n_waves + 64));
+            HIPCHK(ctx, ctx->w_bigtrace.ensure((size_t)n_waves * 2 * (ncap + 2) * 8 + 64));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->w_biglist.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(ctx, hipMemsetAsync(ctx->w_counter.p, 0, 8, s));
+            tk::SimBuffers O3 = O;
+            O3.read_list = ctx->w_biglist.as<uint32_t>(); O3.n_work = big.size();
+            O3.work_counter = ctx->w_counter.as<unsigned long long>();
+            O3.big_scratch = ctx->w_bigscratch.as<uint8_t>(); O3.big_per_wave = per_wave; O3.big_trace = ctx->w_bigtrace.as<unsigned long long>();
+            HIPCHK(ctx, tk::launch_simulate_big(B, R, EM, QM, IM, P, O3, n_waves, s));
+            if (getenv("TKSMSEQ_VERBOSE")) fprintf(stderr, "[tksmseq] %zu molecules beyond the LDS-resident limit took the exact kernel with HBM working sets\n", big.size());
+            continue;
+        }
         if (any & 8) {
             uint64_t f8 = 0;
             for (uint64_t i = 0; i < n; i++) if (st[i] & 8) { f8 = i; break; }
-            ctx->err = "read " + std::to_string(f8) + " (" + std::to_string(b->raw_len[f8]) + " bases) needs the exact wave-wide kernel (non-ACGT bytes or an alignment outside "
-                       "the band representation), which is limited to molecules of " + std::to_string(s_lcap - 2 * k) + " bases";
+            ctx->err = "read " + std::to_string(f8) + " (" + std::to_string(b->raw_len[f8]) + " bases) exceeds the limits of the exact wave-wide kernel";
             return TKSMSEQ_ELIMIT;
         }
         if (any & 1) { *overflow = true; return TKSMSEQ_OK; }
+        break;
     }
     uint8_t* records;
     if (ctx->user_out) {

@@ -105,7 +105,7 @@ struct tksmseq_ctx : ContigLookup {
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,
-        w_scratch, w_records, w_istats, w_dstats, w_sums, w_fullpool;
+        w_scratch, w_records, w_istats, w_dstats, w_sums, w_fullpool, w_biglist, w_bigscratch, w_bigtrace;
     unsigned long long full_pool_bytes = 1ull << 30;
     // fast Badread pipeline state (see kernels.h FastBuffers)
     DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_frag2;

@@ -105,6 +105,8 @@ struct SimBuffers {
     uint8_t* full_pool; unsigned long long full_pool_bytes; unsigned long long* full_pool_used;
     const uint32_t* tail_len;    // optional [n_reads]: tail-noise bases at the end of the read's raw_len (else none)
     const TailChain* tail_chain;
+    // k_simulate<BIG> only: per-wave working sets and final-alignment masks in HBM (molecules beyond the LDS-resident limit)
+    uint8_t* big_scratch; size_t big_per_wave; unsigned long long* big_trace;
     const uint32_t* read_list;   // k_simulate only: optional list of reads to process (slow path), else all
     uint64_t n_work;             // k_simulate only: number of work items (list length or n_reads)
 };
@@ -187,6 +189,9 @@ hipError_t launch_tail_lengths(const BatchView& B, const RefView& R, const TailV
 hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
                            const IdentView& im, const SimParams& p, const SimBuffers& o, int n_wgs,
                            int waves_per_wg, hipStream_t s);
+size_t simulate_big_bytes(int lcap, int ncap);
+hipError_t launch_simulate_big(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
+                               const IdentView& im, const SimParams& p, const SimBuffers& o, int n_waves, hipStream_t s);
 hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView& em, const IdentView& im, const SimParams& p,
                        const SimBuffers& o, const FastBuffers& fb, int waves_per_wg, hipStream_t s);
 int err_lds_bytes(int lcap, int ncap, int waves_per_wg, bool state_in_hbm);

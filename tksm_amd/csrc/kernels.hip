@@ -342,8 +342,8 @@ __global__ void k_read_lengths(BatchView B, RefView R, int k, int cap_num, int c
 // ------------------------------------------------------------------------------------------------
 struct AlnOut { int dist; uint32_t stat; };
 
-template <int MODE, bool TRACE>
-DEV AlnOut band_align(const uint8_t* F, int n, const uint8_t* N, const uint16_t* owner, int m, int lane,
+template <int MODE, bool TRACE, class OT>
+DEV AlnOut band_align(const uint8_t* F, int n, const uint8_t* N, const OT* owner, int m, int lane,
                       unsigned long long* trace) {
     int tp = 1;
     int H = 1 + lane;                         // column 0: H[i][0] = i
@@ -486,7 +486,8 @@ DEV bool full_align_wave(const uint8_t* F, int n, const uint8_t* N, int m, int l
 
 // joins slots [p0, p0+n) into N, owner[j] = window-relative slot of joined base j; returns the joined length
 // (may exceed ncap: nothing is written past ncap and the caller flags the overflow).
-DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint8_t* N, uint16_t* owner, int ncap, int lane) {
+template <class OT>
+DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint8_t* N, OT* owner, int ncap, int lane) {
     int base = 0;
     for (int q = 0; q < n; q += 64) {
         const int p = q + lane;
@@ -495,7 +496,7 @@ DEV int join_window(const uint8_t* frag, const uint16_t* nb, int p0, int n, uint
         int total;
         const int off = base + prefix_small(len, total);
         if (off + len <= ncap)
-            for (int x2 = 0; x2 < len; x2++) { N[off + x2] = slot_sym(code, x2, orig); owner[off + x2] = (uint16_t)p; }
+            for (int x2 = 0; x2 < len; x2++) { N[off + x2] = slot_sym(code, x2, orig); owner[off + x2] = (OT)p; }
         base += total;
     }
     return base;
@@ -524,18 +525,25 @@ DEV int ndigits(unsigned long long v) { int d = 1; while (v >= 10) { v /= 10; d+
 // ------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 
+// BIG: the working set (and the final alignment's masks) of a wave live in HBM instead of LDS -- for the rare molecule that
+// needs this exact kernel (a non-ACGT byte, an alignment outside the band representation) and is longer than LDS holds
+// (~18 kb); slot indices are 32-bit there.
+template <bool BIG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, RefView R, ErrModelView EM,
                                                                  QsModelView QM, IdentView IM, SimParams P,
                                                                  SimBuffers O) {
+    using OT = typename std::conditional<BIG, uint32_t, uint16_t>::type;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per_wave = P.s_lcap * 3 + P.s_ncap * 4;
+    const int glc = BIG ? P.lcap : P.s_lcap, gnc = BIG ? P.ncap : P.s_ncap;      // capacity for the padded fragment / the joined sequence
     const int wpw = blockDim.x >> 6;
-    uint8_t* frag = lds_raw + (size_t)wave * per_wave;
-    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + P.s_lcap);
-    uint8_t* N = frag + 3 * (size_t)P.s_lcap;
-    uint8_t* popd = N + P.s_ncap;
-    uint16_t* owner = reinterpret_cast<uint16_t*>(popd + P.s_ncap);
-    unsigned long long* trace = reinterpret_cast<unsigned long long*>(O.trace) + ((size_t)blockIdx.x * wpw + wave) * (size_t)(P.trace_words / 2);
+    const size_t wave_id = (size_t)blockIdx.x * wpw + wave;
+    uint8_t* frag = BIG ? O.big_scratch + wave_id * O.big_per_wave : lds_raw + (size_t)wave * (glc * 3 + gnc * 4);
+    uint16_t* nb = reinterpret_cast<uint16_t*>(frag + glc);
+    uint8_t* N = frag + 3 * (size_t)glc;
+    uint8_t* popd = N + gnc;
+    OT* owner = reinterpret_cast<OT*>(popd + gnc);
+    unsigned long long* trace = BIG ? O.big_trace + wave_id * (size_t)(2 * (gnc + 2))
+                                    : reinterpret_cast<unsigned long long*>(O.trace) + wave_id * (size_t)(P.trace_words / 2);
     const int k = EM.k;
 
     for (;;) {
@@ -553,7 +561,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
         uint8_t* out_seq = O.scratch + slot;
         uint8_t* out_qual = out_seq + cap;
         uint32_t status = 0;
-        if (L > P.s_lcap) {
+        if (BIG && lane == 0) O.status[r] &= ~8u;          // (this launch takes the reads the LDS-resident one flagged)
+        if (L > glc) {
             // longer than this kernel's LDS-resident working set allows (the fast pipeline takes such reads as long as
             // they are plain ACGT): reported to the host
             if (lane == 0) { O.status[r] |= 8u; O.out_len[r] = 0; O.rec_len[r] = 0; O.identity[r] = 0.0; }
@@ -702,9 +711,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                                 p0 = (int)__umulhi(w, (uint32_t)(L - 1000 + 1));
                                 nrows = 1000;
                             }
-                            const int m = join_window(frag, nb, p0, nrows, N, owner, P.s_ncap, lane);
+                            const int m = join_window(frag, nb, p0, nrows, N, owner, gnc, lane);
                             wave_sync();
-                            if (m > P.s_ncap) status |= 1;
+                            if (m > gnc) status |= 1;
                             else {
                                 const AlnOut a = band_align<0, false>(frag + p0, nrows, N, owner, m, lane, nullptr);
                                 int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
@@ -740,12 +749,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
                 start_trim = __shfl(scan_add_incl(v1, lane), 63, 64);
                 end_trim = __shfl(scan_add_incl(v2, lane), 63, 64);
             }
-            const int m = join_window(frag, nb, 0, L, N, owner, min(P.s_ncap, cap), lane);
+            const int m = join_window(frag, nb, 0, L, N, owner, min(gnc, cap), lane);
             wave_sync();
             st_newlen = m; st_strim = start_trim; st_etrim = end_trim;
             int lo = start_trim, hi = end_trim == 0 ? 0 : m - end_trim;   // seq[start_trim:-end_trim]
             lo = min(lo, m); hi = max(hi, lo);
-            if (m > min(P.s_ncap, cap)) { status |= 1; lo = hi = 0; }
+            if (m > min(gnc, cap)) { status |= 1; lo = hi = 0; }
             out_len = hi - lo;
             if (P.compute_q && m > 0 && !(status & 1)) {
                 // ---- S5 q-scores (py/tksm_badread.py:607-655): align read vs fragment with path
@@ -2682,9 +2691,17 @@ hipError_t launch_simulate(const BatchView& b, const RefView& r, const ErrModelV
                            const IdentView& im, const SimParams& p, const SimBuffers& o, int n_wgs, int wpw, hipStream_t s) {
     if (!b.n_reads) return hipSuccess;
     const int lds = simulate_lds_bytes(p.s_lcap, p.s_ncap, wpw);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_simulate), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_simulate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_simulate, dim3(n_wgs), dim3(64 * wpw), lds, s, b, r, em, qm, im, p, o);
+    hipLaunchKernelGGL(k_simulate<false>, dim3(n_wgs), dim3(64 * wpw), lds, s, b, r, em, qm, im, p, o);
+    return hipGetLastError();
+}
+// the same with the waves' working sets in o.big_scratch / o.big_trace (molecules beyond the LDS-resident limit); one wave per workgroup
+size_t simulate_big_bytes(int lcap, int ncap) { return ((size_t)lcap * 3 + (size_t)ncap * 6 + 255) & ~(size_t)255; }
+hipError_t launch_simulate_big(const BatchView& b, const RefView& r, const ErrModelView& em, const QsModelView& qm,
+                               const IdentView& im, const SimParams& p, const SimBuffers& o, int n_waves, hipStream_t s) {
+    if (!b.n_reads || !n_waves) return hipSuccess;
+    hipLaunchKernelGGL(k_simulate<true>, dim3(n_waves), dim3(64), 0, s, b, r, em, qm, im, p, o);
     return hipGetLastError();
 }
 hipError_t launch_init(const BatchView& b, const RefView& r, const ErrModelView& em, const IdentView& im, const SimParams& p,
