@@ -235,52 +235,50 @@ def main():
                                        id_prefix=f"m{rank}", lognormal_sigma=args.lognormal_sigma or None)
         c.batch = c.seqr.batch_from_arrays(c.m["reads"], c.m["intervals"], c.m["mods"], c.m["literals"], c.m["literal_pool"],
                                            c.m["ids"], c.m["id_pool"])
-        c.out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+        # with the ordering exchange (N > 1) a context has two output buffers: it computes its next step into one while the other
+        # is being gathered
+        c.n_out = 2 if exchange_on else 1
+        c.out_ts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(c.n_out)]
+        c.off_ts = [torch.empty(args.batch + 1, dtype=torch.int64, device=dev) for _ in range(c.n_out)]
+        c.turn = 0
+        c.out_t = c.out_ts[0]
         c.seqr.set_output_buffer(c.out_t.data_ptr(), cap)
-        c.off_t = torch.empty(args.batch + 1, dtype=torch.int64, device=dev)
         c.seqr.set_timing(True)
-        c.free = threading.Semaphore(1)          # the context's output buffer may be overwritten
+        c.free = threading.Semaphore(c.n_out)    # output buffers of the context that may be overwritten
     m = ctxs[0].m
 
     gathered = None
+    xstream = torch.cuda.Stream(device=dev) if exchange_on else None
 
     def run_step(c, t):
         return c.seqr.run(c.batch, target=target, fastq=True, compute_qual=compute_q, seed=42,
                           first_read_index=t * args.batch * world + rank, stride=world)
 
-    def exchange(c, res):
-        """FASTQ ordering (N > 1): sizes -> padded gather of record bytes + offsets to rank 0 -> interleave on device."""
+    xseq = first.seqr.clone() if exchange_on else None       # its own context (stream, work buffers) for the interleave on rank 0
+
+    def exchange(out_t, off_t):
+        """FASTQ ordering (N > 1): gather of the per-rank record streams (fixed width: a rank's output capacity) and their record
+        offsets to rank 0 over RCCL, then the device-side interleave into global read order -- on the exchange thread, on its
+        own stream and context, while the compute contexts run their next steps."""
         nonlocal gathered
-        res.copy_to_device(None, c.off_t.data_ptr())
-        c.seqr.synchronize()
-        nbytes = torch.tensor([res.records_bytes], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, nbytes)
-        mx = int(max(int(x.item()) for x in sizes))
-        if rank == 0:
-            if gathered is None or gathered[0][0].numel() < mx:
-                gathered = ([torch.empty(mx + mx // 8, dtype=torch.uint8, device=dev) for _ in range(world)],
+        with torch.cuda.stream(xstream):
+            if rank == 0 and gathered is None:
+                gathered = ([torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)],
                             [torch.empty(args.batch + 1, dtype=torch.int64, device=dev) for _ in range(world)],
                             torch.empty(int(cap * world), dtype=torch.uint8, device=dev))
-            width = gathered[0][0].numel()
-        else:
-            width = 0
-        wt = torch.tensor([width], dtype=torch.int64, device=dev)
-        dist.broadcast(wt, 0)
-        width = int(wt.item())
-        dist.gather(c.out_t[:width], gathered[0] if rank == 0 else None, dst=0)
-        dist.gather(c.off_t, gathered[1] if rank == 0 else None, dst=0)
-        if rank == 0:
-            torch.cuda.current_stream().synchronize()
-            c.seqr.interleave_records([g.data_ptr() for g in gathered[0]], [g.data_ptr() for g in gathered[1]],
-                                      [args.batch] * world, gathered[2].data_ptr(), gathered[2].numel())
-            c.seqr.synchronize()
-        torch.cuda.current_stream().synchronize()
+            dist.gather(out_t, gathered[0] if rank == 0 else None, dst=0)
+            dist.gather(off_t, gathered[1] if rank == 0 else None, dst=0)
+            xstream.synchronize()
+            if rank == 0:
+                xseq.interleave_records([g.data_ptr() for g in gathered[0]], [g.data_ptr() for g in gathered[1]],
+                                        [args.batch] * world, gathered[2].data_ptr(), gathered[2].numel())
+                xseq.synchronize()
 
     def run_steps(first, count):
         """steps first .. first+count-1: context t mod n_ctx runs step t on its own thread; with N > 1 the main thread
         performs the ordering exchange of every step in step order while the other context keeps computing."""
         results = [None] * count
+        handed = [None] * count
         done = [threading.Event() for _ in range(count)]
         errors = []
 
@@ -293,6 +291,14 @@ def main():
                     results[j] = run_step(c, first + j)
                     if not exchange_on:
                         c.free.release()
+                    else:
+                        # offsets next to the records, then the next step of this context goes to its other buffer
+                        off_t = c.off_ts[c.turn]
+                        results[j].copy_to_device(None, off_t.data_ptr())
+                        c.seqr.synchronize()
+                        handed[j] = (c.out_ts[c.turn], off_t)
+                        c.turn = (c.turn + 1) % c.n_out
+                        c.seqr.set_output_buffer(c.out_ts[c.turn].data_ptr(), cap)
                     done[j].set()
             except Exception as e:      # surface in the main thread
                 errors.append(e)
@@ -307,7 +313,7 @@ def main():
                 if errors:
                     break
                 c = ctxs[j % n_ctx]
-                exchange(c, results[j])
+                exchange(*handed[j])
                 c.free.release()
         for x in th:
             x.join()
@@ -352,6 +358,10 @@ def main():
     else:
         bases_in_all, bases_out_all = float(bases_in), float(bases_out)
     if rank != 0:
+        if xseq is not None:
+            xseq.close()
+        for c in reversed(ctxs):
+            c.seqr.close()
         dist.destroy_process_group()
         return
     reads = args.batch * world * args.steps
@@ -400,10 +410,13 @@ def main():
     }
     if world == 1 and not args.no_e2e and not args.perfect and args.kind == "bulk":
         # the CLI is another process on the same GPU: release this one's contexts and buffers first
+        if xseq is not None:
+            xseq.close()
+            xseq = None
         for c in reversed(ctxs):
             c.batch.free()
             c.seqr.close()
-            c.out_t = c.off_t = None
+            c.out_t = c.out_ts = c.off_ts = None
         ctxs.clear()
         torch.cuda.empty_cache()
         e2e = e2e_leg(args.e2e_molecules)
@@ -414,6 +427,8 @@ def main():
     os.dup2(json_fd, 1)
     print(json.dumps(out), flush=True)
     os.dup2(2, 1)
+    if xseq is not None:
+        xseq.close()
     for c in reversed(ctxs):
         c.seqr.close()
     if exchange_on:
