@@ -7,17 +7,21 @@ R=$PWD
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $out/bench.json 2> $out/bench.err
+python $R/bench.py --no-e2e > $out/bench.json 2> $out/bench.err
 echo bench done >> $out/progress.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python $R/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python $R/bench.py --no-cpu-baseline --no-e2e > $out/bench_under_rocprof.json 2> $out/stats.err
 echo stats done >> $out/progress.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1
+# one context at a time: every kernel has the GPU to itself, so total duration / steps is the exclusive time bench.py reports as kernel_ms
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python $R/bench.py --no-cpu-baseline --no-e2e --pipeline 1 --steps 4 > $out/bench_single_ctx_under_rocprof.json 2> $out/stats1.err
+echo single-context stats done >> $out/progress.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $out/fetch.log 2>&1
 echo fetch done >> $out/progress.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $out/write.log 2>&1
 echo write done >> $out/progress.log
 cd $R
-python tools/make_traffic_json.py $out 6 1310720 > $out/hbm_traffic.json   # 3 timed steps + 1 warm-up step per context
+python tools/make_traffic_json.py $out 7 1310720 $tag > $out/hbm_traffic.json   # 3 warm-up + 3 timed steps + the exclusive step
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
-rm -rf $out/stats $out/fetch/*/*agent_info.csv
+cp $out/stats1/*/*kernel_stats.csv $out/single_ctx_kernel_stats.csv
+rm -rf $out/stats $out/stats1 $out/fetch/*/*agent_info.csv
 ls -la $out
 cat $out/bench.json
