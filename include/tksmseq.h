@@ -219,7 +219,7 @@ int tksmseq_interleave_records(tksmseq_ctx* ctx, int n_ranks, const void* const*
  * molecule present with probability `efficiency`; a copy gets floor(4/3 error_rate x size) (+1 with the fractional
  * probability) substitutions at distinct positions, bases uniform in "ACTG", on top of its template's; each copy is
  * written with probability target_count / ((1 + efficiency)^cycles x molecules); id = template id + "." + cycle.
- * More than 2 x target_count input molecules: 2 x target_count of them are used (:226-229). */
+ * More than 2 x target_count input molecules: 2 x target_count of them are used (:217-220). */
 typedef struct {
     uint64_t seed;
     uint64_t target_count;        /* --molecule-count */

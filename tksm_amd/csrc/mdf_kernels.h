@@ -26,7 +26,7 @@ struct MolView {
     BatchView B;
     const uint32_t* dup;                  // [n_reads] bit 31: the molecule had depth > 1, bits 0..30: its index among the copies (MDF unroll, src/mdf.h:97-105); may be null
     uint64_t n_intervals, n_mods;
-    const uint32_t* keep;                 // optional [n_kept] molecule indices to amplify (more than 2 x target molecules: src/pcr.cpp:226-229)
+    const uint32_t* keep;                 // optional [n_kept] molecule indices to amplify (more than 2 x target molecules: src/pcr.cpp:217-220)
     uint64_t n_kept;
 };
 

@@ -149,7 +149,7 @@ int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_par
     if (!(p->efficiency >= 0.0) || !(p->error_rate >= 0.0)) { ctx->err = "PCR: efficiency and error rate must be non-negative"; return TKSMSEQ_EINVAL; }
     hipStream_t s = ctx->stream;
     const uint64_t n = in->n_reads;
-    // templates: every (depth-unrolled) molecule, or 2 x target of them when there are more (src/pcr.cpp:226-229 shuffles and
+    // templates: every (depth-unrolled) molecule, or 2 x target of them when there are more (src/pcr.cpp:217-220 shuffles and
     // cuts; here: the 2 x target molecules with the smallest Philox keys, in input order)
     std::vector<uint32_t> keep;
     uint64_t n_kept = n;
