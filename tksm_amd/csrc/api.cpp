@@ -666,12 +666,14 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         const uint64_t jcap = (uint64_t)FB.n_ranges * FB.rs;     // job slots (>= n)
         // rows of a range's jobs are sized by the range's longest read
         std::vector<uint32_t> r_ncap(FB.n_ranges), r_cw(FB.n_ranges);
+        std::vector<uint32_t> r_tg(FB.n_ranges);              // 64-byte lines of predecessor codes per job (16 columns each, one spare)
         uint64_t tot_trace = 0, tot_jc = 0, tot_popd = 0;
         for (uint32_t c = 0; c < FB.n_ranges; c++) {
             const uint64_t last = std::min<uint64_t>((uint64_t)(c + 1) * FB.rs, n) - 1;
             r_ncap[c] = (uint32_t)capf(b->raw_len[b->order[last]]);
             r_cw[c] = (r_ncap[c] / 8 + 8 + 3) & ~3u;
-            tot_trace += (uint64_t)FB.rs * (r_ncap[c] + 16); tot_jc += (uint64_t)FB.rs * r_cw[c]; tot_popd += (uint64_t)FB.rs * r_ncap[c];
+            r_tg[c] = ((r_ncap[c] + 31) & ~31u) / 16 + 1;
+            tot_trace += (uint64_t)FB.rs * r_tg[c]; tot_jc += (uint64_t)FB.rs * r_cw[c]; tot_popd += (uint64_t)FB.rs * r_ncap[c];
         }
         HIPCHK(ctx, ctx->f_state.ensure(n * sizeof(tk::ReadState) + 64));
         HIPCHK(ctx, ctx->f_frag.ensure(n * (size_t)lcap + 64));
@@ -688,23 +690,29 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         }
         HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
         HIPCHK(ctx, ctx->f_geo.ensure((size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo) + 64));
-        HIPCHK(ctx, ctx->f_wsh.ensure(tot_jc * 8 + 64));
-        HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 8 + 64));
+        // predecessor codes: pass 1's lines, then the pool of pass 2 (32 stored rows: 8 columns per line) for an eighth of the job
+        // slots at most (its waves loop over their list), 2 GB at most
+        FB.pool_tg = (((uint32_t)ncap + 31) & ~31u) / 8 + 1;
+        FB.pool_jobs = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(jcap / 8, (2ull << 30) / ((uint64_t)FB.pool_tg * 64)) & ~63ull);
+        HIPCHK(ctx, ctx->f_trace.ensure((tot_trace + (uint64_t)FB.pool_jobs * FB.pool_tg) * 64 + 64));
+        HIPCHK(ctx, ctx->f_redo.ensure(jcap * 8 + 64));
         // pool of full-width rows: as many as a round can ask for, at most 4 GB (homopolymer-rich batches need many)
-        FB.full_rows = (uint32_t)std::min<uint64_t>(jcap, (4ull << 30) / ((uint64_t)(ncap + 16) * 16));
-        HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * (size_t)(ncap + 16) * 16 + 64));
-        HIPCHK(ctx, ctx->f_counters.ensure(256));
+        FB.full_tg = (((uint32_t)ncap + 31) & ~31u) / 4 + 1;
+        FB.full_rows = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(jcap, (4ull << 30) / ((uint64_t)FB.full_tg * 64)) & ~63ull);
+        HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * FB.full_tg * 64 + 64));
+        HIPCHK(ctx, ctx->f_counters.ensure(1024));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.st_frag2 = ctx->f_frag2.as<uint32_t>();
-        FB.trace = ctx->f_trace.p; FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
+        FB.trace = ctx->f_trace.p; FB.trace_pool = ctx->f_trace.as<uint8_t>() + tot_trace * 64;
+        FB.redo_list = ctx->f_redo.as<uint32_t>(); FB.redo_list2 = FB.redo_list + jcap;
+        FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         HIPCHK(ctx, ctx->f_defer.ensure(n * 8 + 64));
         HIPCHK(ctx, ctx->f_defercnt.ensure((size_t)FB.n_ranges * 128 + 64));
         FB.defer_list = ctx->f_defer.as<uint2>(); FB.defer_cnt = ctx->f_defercnt.as<uint32_t>(); FB.defer_len = ctx->defer_len;
         HIPCHK(ctx, hipMemsetAsync(ctx->f_defercnt.p, 0, (size_t)FB.n_ranges * 128, s));
         FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
-        FB.walk_sh = ctx->f_wsh.as<uint32_t>();
         FB.geo_cur = ctx->f_geo.as<tk::RangeGeo>(); FB.geo_prev = FB.geo_cur + FB.n_ranges;
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
@@ -729,8 +737,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 hrg[FB.n_ranges + c] = hrg[c];
                 const uint64_t slots = hbase_cur[c + 1] - hbase_cur[c];
                 tk::RangeGeo g{};
-                g.trace_off = ot; g.jc_off = oj; g.popd_off = op; g.wsh_off = oj;
-                g.tstride = r_ncap[c] + 16; g.cw = r_cw[c]; g.ncap = r_ncap[c];
+                g.trace_off = ot; g.jc_off = oj; g.popd_off = op;
+                g.tstride = r_tg[c]; g.cw = r_cw[c]; g.ncap = r_ncap[c];
                 hrg[c] = g;
                 ot += slots * g.tstride; oj += slots * g.cw; op += slots * g.ncap;
             }
@@ -768,7 +776,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         };
         std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other (k_init, k_err, wave-wide kernel), 1 k_loop, 2 k_aln, 3 k_job, -1 host gap
         HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, n * (size_t)lcap * 2, s));
-        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 256, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 1024, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, lcap * tk::WAVES_PER_WG <= 150 * 1024 ? tk::WAVES_PER_WG : (lcap * 2 <= 150 * 1024 ? 2 : 1), s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
@@ -902,6 +910,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
             HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 3, 0, 4, s));   // rows of the full-width pool
+            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 10, 0, 8, s));  // jobs handed to the second and third alignment pass
             HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= ctx->small_aln, qround ? 1 : 0, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
@@ -920,18 +929,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, hipMemcpy(cc, ctx->f_counters.p, 64, hipMemcpyDeviceToHost));
             fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
                     (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);
-#ifdef TKSM_ABLATE
-            {
-                uint32_t hh[64];
-                HIPCHK(ctx, hipMemcpy(hh, ctx->f_counters.p, 256, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[tksmseq] full-width walks, lowest band row visited (bins of 4):");
-                for (int q = 0; q < 16; q++) fprintf(stderr, " %u", hh[16 + q]);
-                fprintf(stderr, "\n[tksmseq] full-width walks, highest band row visited (bins of 4):");
-                for (int q = 0; q < 16; q++) fprintf(stderr, " %u", hh[32 + q]);
-                fprintf(stderr, "\n");
-            }
-            fprintf(stderr, "[tksmseq] walk deviation from the generative row: <=3 %u, <=5 %u, <=7 %u, <=9 %u, <=11 %u, more %u\n", cc[10], cc[11], cc[12], cc[13], cc[14], cc[15]);
-#endif
         }
         for (int k2 = 0; k2 < tksmseq_ctx::N_SIDE; k2++)
             if (ctx->side_used[k2]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_done[k2], 0));

@@ -108,7 +108,7 @@ struct tksmseq_ctx : ContigLookup {
         w_scratch, w_records, w_istats, w_dstats, w_sums, w_fullpool, w_biglist, w_bigscratch, w_bigtrace;
     unsigned long long full_pool_bytes = 1ull << 30;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_wsh, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_frag2;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_redo, f_jpopd[2], f_prefix, f_trace, f_tracefull, f_geo, f_counters, f_slow, f_defer, f_defercnt, f_jobcnt[2], f_frag2;
     bool force_slow = false;
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t small_round = 16384, small_aln = 4096;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment

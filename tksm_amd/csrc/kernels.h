@@ -130,11 +130,11 @@ struct ReadState {
 // Where the jobs of one range of the sorted read order live in this round's job set.  Rows are as long as the longest
 // read of the range needs (a batch's longest read is twice its mean), and ranges are packed one after the other.
 struct RangeGeo {
-    uint64_t trace_off;   // u64 words into trace
+    uint64_t trace_off;   // 64-byte lines into trace
     uint64_t jc_off;      // records into job_cols
     uint64_t popd_off;    // bytes into job_popd
-    uint64_t wsh_off;     // uint2 entries into walk_sh
-    uint32_t tstride;     // ncap + 16: predecessor columns per job row
+    uint64_t unused;
+    uint32_t tstride;     // lines of predecessor codes per job (16 columns each; the last one is spare)
     uint32_t cw;          // block records per job row
     uint32_t ncap;        // joined-window capacity of the range (multiple of 16)
     uint32_t pad;
@@ -154,12 +154,16 @@ struct FastBuffers {
     // the window at the start of the block}: k_aln never touches the per-read fragment planes again
     uint4* job_cols;
     unsigned long long* job_win;      // [n_reads][2] code planes of the first 64 window rows
-    uint32_t* walk_sh;                // [n_groups][cw][64][2] shift words per block and lane, written by the forward pass
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
-    void* trace;                      // [n_jobs][ncap + 16] 8-byte predecessor columns (rows 12..43 of the band)
-    void* trace_full;                 // [full_rows][ncap + 16] 16-byte columns: pool for full-width passes, counters[3] allocates
-    uint32_t full_rows;
-    uint32_t* counters;               // [16]: [2] reads on the slow list, [3] rows taken from the full-width pool, [4..] diagnostics
+    void* trace;                      // predecessor codes of the first alignment pass (16 band rows, 4 bytes per column): 64-byte lines of 16
+                                      // columns, per range [wave][line][lane] (RangeGeo::trace_off / tstride)
+    uint8_t* trace_pool;              // ... of the second pass (32 rows, 8 columns per line): [wave of the launch][pool_tg lines][lane]
+    uint32_t pool_jobs, pool_tg;      // jobs the pool holds (multiple of 64), lines per job
+    uint32_t* redo_list;              // jobs whose path left the stored rows of pass 1 (counters[10] of them) ...
+    uint32_t* redo_list2;             // ... and of pass 2 (counters[11]): full-width pass
+    void* trace_full;                 // pool of the passes that store all 64 rows (16 bytes per column, 4 columns per line): [wave][full_tg lines][lane]; counters[3] allocates
+    uint32_t full_rows, full_tg;      // jobs the full-width pool holds (multiple of 64), lines per job (4 columns each)
+    uint32_t* counters;               // [2] reads on the slow list, [3] rows taken from the full-width pool, [4..9] diagnostics, [10] / [11] jobs on redo_list / redo_list2
     uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
     uint32_t rs, n_ranges;
     // previous round's job set (double buffered): its jobs are the list of reads that are still running

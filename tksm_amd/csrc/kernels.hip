@@ -16,6 +16,7 @@
 // Integer/byte work throughout: no MFMA.  fp64 is used only for the scalar identity bookkeeping
 // and is compiled with -ffp-contract=off so it matches the CPU oracle bit for bit.
 #include "kernels.h"
+#include <type_traits>
 
 namespace tk {
 
@@ -1651,339 +1652,253 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
 struct AlnJob {
     bool act; int p0, n, m, mode;
     const unsigned long long* fp;    // fragment planes of the read, {lo, hi} word pairs (blocks flagged in their record only)
-    const uint4* jc;                 // the job's block records
-    const uint4* jc0;                // records of the wave's first job
-    int cw;                          // records per job
+    const uint4* jcl;                // the job's block records: 64-byte lines of 4 records (32 columns), the lines of a wave's 64 jobs
+                                     // interleaved -- record b at jcl[(b >> 2) * 256 + (b & 3)]
     ulonglong2 win;                  // code planes of the first 64 window rows
-    uint2* wsh0;                     // the wave's [block][lane] shift words for the walk
-    unsigned long long* trace;       // per-job region of (ncap + 16) 16-byte columns
-    unsigned long long* trace0;      // region of the wave's first job
-    size_t tstride;                  // u64 words between consecutive jobs
+    unsigned long long* trace;       // full-width pass: the job's row of (ncap + 16) 16-byte columns
     unsigned long long* popd8;
 };
+DEV const uint4* job_rec_ptr(const AlnJob& J, int b) { return J.jcl + (size_t)(b >> 2) * 256 + (b & 3); }
 struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
-constexpr int ST_ROW = 12;          // first stored band row of the 8-byte predecessor columns (rows ST_ROW .. ST_ROW + 31)
 
-// ---- the common case: 8 bytes of predecessor codes per column (rows 12..43 of the band; the path practically
-// never leaves them).  Written for the vector ALU and for the memory system:
-//  * every per-column shift is by 0..31, so the 64-bit words are moved with v_alignbit on their halves; the fragment
-//    window slides, fed by the 32 entering rows each block record carries, instead of being re-extracted from the
-//    per-read planes (330 k concurrent jobs each touching its own plane and record lines thrash the L2);
-//  * everything a lane reads or writes in HBM moves as whole 64-byte lines, 4 threads per job, transposed through
-//    LDS: block records one group of 32 columns ahead, predecessor codes per 8 columns;
-//  * the loop body is branch-free and every memory operation is unconditional, so the waits on the prefetches do
-//    not have to drain the trace stores (gfx9 counts loads and stores in one counter, in issue order); the one
-//    exception, a block whose window moves by more rows than its record carries, is a wave-uniform branch that ends
-//    with nothing in flight.
-// A lane whose walk needs a row outside the stored 32 reports needfull (redone by aln_full).
+// ---- the common case: the predecessor codes of a few band rows around the generative row per column -- the path practically
+// never leaves them: 16 rows (4 bytes per column: pass 1; 1 % of bulk and 5 % of polyA-tailed jobs leave them and are redone
+// with 32 rows (8 bytes, pass 2, from a list; 0.02 % / 0.14 % leave those and go to the full-width pass).  The kernel is bound by
+// HBM traffic first (records 2 B per column in, codes 4 B out and 4 + 2 B in again for the walk) and vector instructions second
+// (~72 per column forward, ~24 in the walk), so:
+//  * everything a lane moves is a whole 64-byte line of its own -- 4 block records (32 columns), 16 columns of codes -- and the lines
+//    of a wave's 64 jobs are neighbours in memory (4 KB per wave and line index): no transposition through LDS, no partial lines,
+//    DRAM pages are used in whole;
+//  * every per-column shift is by 0..31, so the 64-bit words are moved with v_alignbit on their halves; the fragment window slides,
+//    fed by the 32 entering rows each block record carries, instead of being re-extracted from the per-read planes;
+//  * the loop body is branch-free and every memory operation is unconditional (a lane past its job's end writes a spare line), so
+//    the waits on the prefetches do not have to drain the stores (gfx9 counts loads and stores in one counter, in issue order); the
+//    one exception, a block whose window moves by more rows than its record carries, is a wave-uniform branch that ends with nothing
+//    in flight.
+// A lane whose walk needs a row outside the stored ones reports needfull.
 // MODE: 0 = identity jobs of the error loop (preference up, left, diagonal; only matches / columns come back), 1 = q-score jobs
 // (left, up, diagonal; per-position ops written).  All jobs of a launch have the same mode.
-template <int MODE>
-DEV AlnRes aln_fast(const AlnJob& J, int mmax, int spare_col, int lane, unsigned long long* tr_lds, uint4* rec_lds, int ablate,
-                    uint32_t* devhist) {
+// trl: the lane's line of column group 0; group q at trl + ls q (uint4 units; ls = 4 x the jobs whose lines are interleaved, 256 as a
+// rule); tg groups per job, the last one spare.
+template <int MODE, int ROWS>
+DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, int ablate) {
+    constexpr int NC = ROWS == 16 ? 16 : (ROWS == 32 ? 8 : 4);    // columns per line of codes
+    constexpr int ST = ROWS == 16 ? 23 : (ROWS == 32 ? 12 : 0);   // first stored band row once the window moves
+    constexpr int RAMP0 = 31 - ST;
     const bool act = J.act;
-    const int n = J.n, m = J.m;
+    const int n = J.n, m = act ? J.m : 0;
     constexpr unsigned long long M64 = MODE ? ~0ull : 0ull;
     unsigned long long Pv = ~0ull, Mv = 0ull;
-    int t = 1;
-    unsigned long long A = J.win.x, B = J.win.y;                  // low / high code plane of the window rows
-    int mjq[4];                                                   // lengths of the jobs this lane moves lines for
-#pragma unroll
-    for (int q = 0; q < 4; q++) mjq[q] = __shfl(act ? m : 0, q * 16 + (lane >> 2), 64);
-    // Job records travel in groups of 4 (32 columns, one 64-byte line per job): whole lines are loaded by 4 threads
-    // per job one group ahead and handed to the owning lanes through LDS
-    // (four named registers, not an array: the array was kept in scratch memory, which also made every group load wait)
-    uint4 rg0, rg1, rg2, rg3;
-    const uint4* jrow = J.jc0 + (size_t)(lane >> 2) * J.cw + (lane & 3);
-    const size_t jq = (size_t)16 * J.cw;
-    auto load_group = [&](int g) {
-        rg0 = jrow[4 * g]; rg1 = jrow[jq + 4 * g]; rg2 = jrow[2 * jq + 4 * g]; rg3 = jrow[3 * jq + 4 * g];
-    };
-    auto stage_group = [&]() {
-        uint4* d = rec_lds + (lane & 3) * 64 + (lane >> 2);
-        d[0] = rg0; d[16] = rg1; d[32] = rg2; d[48] = rg3;
-    };
-    load_group(0); stage_group(); wave_sync();
-    for (int c0 = 0; c0 < mmax; c0 += 32) {
-        load_group((c0 >> 5) + 1);
-#pragma unroll
-        for (int bq = 0; bq < 4; bq++) {
-            const int cb = c0 + 8 * bq;
-            uint4 rec = rec_lds[bq * 64 + lane];
-            if (!(act && cb < m)) { rec.x = 0u; rec.y = 0u; rec.z = 0u; rec.w = 0u; }
-            const uint32_t shw = rec.x, nbits = rec.y;
-            uint32_t EA = rec.z, EB = rec.w;                      // the 32 rows after the window
-            const bool esc = (nbits >> 24) & 1u;                  // ... are not enough in this block (rare)
-            const bool esc_any = __ballot(esc) != 0ull;
-            // shift words for the walk, coalesced lines per block: {bits 0-3 of the 8 shifts, bit 4 of the 8 shifts}
-            J.wsh0[(size_t)(cb >> 3) * 64 + lane] = make_uint2(shw, (nbits >> 16) & 0xffu);
-#pragma unroll
-            for (int x = 0; x < 8; x++) {
-                const uint32_t sh = ((shw >> (4 * x)) & 15u) | (((nbits >> (16 + x)) & 1u) << 4);
-                t += (int)sh;
-                const bool g = t > 1;
-                // window moves down by sh rows: entering rows take vertical delta +1
-                Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh));
-                Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh));
-                const unsigned long long f = (sh == 0u && g) ? 1ull : 0ull;   // window did not move: top row only from the left
-                Pv &= ~f; Mv |= f;
-                A = mk64(alignbit(EA, hi32(A), sh), alignbit(hi32(A), lo32(A), sh)); EA >>= sh;
-                B = mk64(alignbit(EB, hi32(B), sh), alignbit(hi32(B), lo32(B), sh)); EB >>= sh;
-                if (esc_any) {
-                    if (esc) {
-                        const int o = J.p0 + t - 1, w = o >> 6;
-                        const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w);
-                        const ulonglong2 q1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 2);
-                        A = funnel128(q0.x, q1.x, o & 63); B = funnel128(q0.y, q1.y, o & 63);
-                    }
-                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this rare path stays in flight (exact waits elsewhere)
-                }
-                const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
-                const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
-                // rows below the fragment (i > n) are not masked: they never feed a row above them
-                const unsigned long long Eq = ~((A ^ mk64(cl, cl)) | (B ^ mk64(ch, ch)));
-                const unsigned long long Xv = Eq | Mv;
-                const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-                const unsigned long long Ph = Mv | ~(Xh | Pv);
-                const unsigned long long Mh = Pv & Xh;
-                const unsigned long long D0 = Xh | Mv;
-                const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
-                const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
-                Pv = Mhs | ~(Xv | Phs);
-                Mv = Phs & Xv;
-                const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
-                // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal
-                const unsigned long long w1 = ~(upv | Ph);
-                const unsigned long long w0 = (Ph & (~upv | M64)) | (w1 & D0);
-                // stored rows: 32 around the generative row, which sits at bit 31 once the window moves (t > 1) and
-                // climbs from bit 0 with the column index while the window is still clamped at row 1.  19 rows above it
-                // and 12 below: co-optimal paths take the deletions of a homopolymer run at its end, i.e. run above the
-                // generative row (measured: rows 12..43 miss 0.02 % of bulk and 0.14 % of polyA-tailed jobs, 16..47 0.36 %)
-                const uint32_t st = g ? (uint32_t)ST_ROW : (uint32_t)max(0, min(ST_ROW, cb + x - (31 - ST_ROW)));
-                tr_lds[x * 64 + lane] = mk64(alignbit(hi32(w1), lo32(w1), st), alignbit(hi32(w0), lo32(w0), st));
-            }
-            wave_sync();
-            // 64 bytes per job, written as whole lines: 4 threads cover one job's 8 columns (transpose through LDS);
-            // lines of jobs that have already ended go to the spare columns at the end of the job's own region
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int jl = q * 16 + (lane >> 2), part = lane & 3;
-                ulonglong2 v;
-                v.x = tr_lds[(2 * part) * 64 + jl]; v.y = tr_lds[(2 * part + 1) * 64 + jl];
-                const int col = cb < mjq[q] ? cb : spare_col;
+    int t = 1, t32 = 1;
+    // the window rows' code planes are kept COMPLEMENTED: Eq = (~A ^ cl) & (~B ^ ch) saves the two inversions per column
+    unsigned long long A = ~J.win.x, B = ~J.win.y;
+    const uint4* rcl = J.jcl;
+    const size_t spare = (size_t)(tg - 1) * ls;
+    uint4 rn0 = rcl[0], rn1 = rcl[1], rn2 = rcl[2], rn3 = rcl[3];
+    uint32_t tw[16];                                              // codes on their way out (16 rows: half a line, else a line)
+    auto put_line = [&](int q, int half) {                        // half: -1 whole line, 0 / 1 its first / second 32 bytes
 #ifdef TKSM_ABLATE
-                if (ablate == 12 || ablate == 14) { if (v.x == 0x1234567ull) J.trace0[0] = v.y; } else
+        if (ablate == 12 || ablate == 14) { if (tw[0] == 0x1234567u) trl[spare] = make_uint4(tw[1], tw[2], tw[3], tw[4]); return; }
 #endif
-                *reinterpret_cast<ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)col + 2 * part) = v;
-            }
-            wave_sync();
+        uint4* d = trl + (q * NC < m ? (size_t)q * ls : spare);
+        if (half < 0) {
+            d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
+            d[2] = make_uint4(tw[8], tw[9], tw[10], tw[11]); d[3] = make_uint4(tw[12], tw[13], tw[14], tw[15]);
+        } else {
+            d[2 * half] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[2 * half + 1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
         }
-        stage_group(); wave_sync();
-    }
-#ifdef TKSM_ABLATE
-    if (ablate >= 11 && ablate <= 19) { AlnRes R0; R0.mt = (uint32_t)(Pv ^ Mv); R0.cols = (uint32_t)t; R0.fail = false; R0.needfull = false; return R0; }
-#endif
-    // ---- walk back from (n, m), block by block (uniform block index; every lane walks its own job)
-    int i = n, j = m, tt = t;
-    uint32_t mt = 0, cols = 0;
-    int dpend = 0;
-    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0), needfull = false;
-    const int topblk = (mmax - 1) >> 3;
-    const uint32_t lim = (uint32_t)(n + m);
-    unsigned long long preA[8], preB[8];        // trace blocks in flight: two sets, two blocks deep
-    uint2 shA = make_uint2(0u, 0u), shB = shA, cur_sh = shA;
-    // block loads / LDS fills: whole 64-byte lines, 4 threads per job (transposed in LDS)
-    auto load_block = [&](int blk2, unsigned long long* pre, uint2& psh) {
-        blk2 = max(blk2, 0);
+    };
+    auto fwd_block = [&](int c0, int bq, uint4 rec) {
+        const int cb = c0 + 8 * bq;
+        if (!(cb < m)) { rec.x = 0u; rec.y = 0u; rec.z = 0u; rec.w = 0u; }
+        const uint32_t shw = rec.x, nbits = rec.y;
+        uint32_t EA = ~rec.z, EB = ~rec.w;                        // the 32 rows after the window (complemented, like A and B)
+        const bool esc = (nbits >> 24) & 1u;                      // ... are not enough in this block (rare)
+        const bool esc_any = __ballot(esc) != 0ull;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int jl = q * 16 + (lane >> 2), part = lane & 3;
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(J.trace0 + (size_t)jl * J.tstride + (size_t)blk2 * 8 + 2 * part);
-            pre[2 * q] = v.x; pre[2 * q + 1] = v.y;
-        }
-        psh = J.wsh0[(size_t)blk2 * 64 + lane];
-    };
-    auto fill_lds = [&](const unsigned long long* pre, uint2 psh) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int jl = q * 16 + (lane >> 2), part = lane & 3;
-            tr_lds[(2 * part) * 64 + jl] = pre[2 * q]; tr_lds[(2 * part + 1) * 64 + jl] = pre[2 * q + 1];
-        }
-        cur_sh = psh;
-    };
-#ifdef TKSM_ABLATE
-    int maxdev = 0;
-#endif
-    // one block: the set `nxt` (block blk - 1) was requested while the previous block was walked; `far` is requested now
-    auto walk_block = [&](int blk, unsigned long long* nxt, uint2& nsh, unsigned long long* far, uint2& fsh) {
-        load_block(blk - 2, far, fsh);
-        unsigned long long pp = 0ull;          // op bytes of this group of 8 columns
-        bool touched = false;
-        bool go = act && !fail && !needfull && j > 0 && ((j - 1) >> 3) == blk;
-        while (go) {
-            const int c8 = (j - 1) & 7;
-            const unsigned long long e = tr_lds[c8 * 64 + lane];
-            const int shc = (int)(((cur_sh.x >> (4 * c8)) & 15u) | (((cur_sh.y >> c8) & 1u) << 4));   // this column's shift
-            const int st = tt > 1 ? ST_ROW : max(0, min(ST_ROW, j - 1 - (31 - ST_ROW)));
-            const int b = i - tt, bs = b - st;
-            int code = (int)((lo32(e) >> (bs & 31)) & 1u) | (int)(((hi32(e) >> (bs & 31)) & 1u) << 1);
-            code = b > 63 ? 0 : code;                     // virtual cell below the window: up
-            code = i == 0 ? 1 : code;                     // row 0: only left
-            const bool bad = (i > 0 && b < 0) || cols > lim;
-            const bool out = i > 0 && b >= 0 && b <= 63 && (uint32_t)bs > 31u;
-#ifdef TKSM_ABLATE
-            if (ablate == 21 && out && !bad) {      // where does the walk leave the stored rows? [0]: j < 64, [1]: j > m - 64, [2]: elsewhere; [3]: above, [4]: below
-                atomicAdd(&devhist[j < 64 ? 0 : (j > m - 64 ? 1 : 2)], 1u);
-                atomicAdd(&devhist[bs < 0 ? 3 : 4], 1u);
-            }
-#endif
-            if (bad || out) { fail |= bad; needfull |= out && !bad; break; }
-#ifdef TKSM_ABLATE
-            if (tt > 1) maxdev = max(maxdev, abs(bs - (31 - ST_ROW)));
-#endif
-            cols++;
-            const bool up = code == 0;
-            i -= code != 1 ? 1 : 0;
-            mt += code == 3 ? 1u : 0u;
-            if (MODE) {
-                const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
-                pp |= up ? 0ull : (unsigned long long)opb << (8 * c8);
-                touched |= !up;
-                dpend = up ? dpend + 1 : 0;
-            }
-            tt -= up ? 0 : shc;
-            j -= up ? 0 : 1;
-            go = up || c8 != 0;                           // leaving column c8 == 0 leaves the block
-        }
-        if (MODE && touched) J.popd8[blk] = pp;
-        wave_sync(); fill_lds(nxt, nsh); wave_sync();
-    };
-    if (mmax > 0) {
-        load_block(topblk, preA, shA);
-        load_block(topblk - 1, preB, shB);
-        fill_lds(preA, shA); wave_sync();
-        for (int blk = topblk; blk >= 0; blk -= 2) {
-            walk_block(blk, preB, shB, preA, shA);
-            if (blk > 0) walk_block(blk - 1, preA, shA, preB, shB);
-        }
-    }
-    if (act && !fail && !needfull && i > 0) { cols += (uint32_t)i; i = 0; }   // column 0: only fragment-only moves remain
-#ifdef TKSM_ABLATE
-    if (ablate == 20 && act) atomicAdd(&devhist[maxdev <= 3 ? 0 : maxdev <= 5 ? 1 : maxdev <= 7 ? 2 : maxdev <= 9 ? 3 : maxdev <= 11 ? 4 : 5], 1u);
-#endif
-    AlnRes R;
-    R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = needfull;
-    return R;
-}
-
-// ---- full-width redo (rare): all 64 rows of every column, 16 bytes per column, 4 columns per LDS block
-DEV AlnRes aln_full(const AlnJob& J, bool act, int mmax, int lane, unsigned long long* tr_lds, uint32_t* hist = nullptr) {
-    const int n = J.n, m = J.m, mode = J.mode;
-    const unsigned long long M64 = mode ? ~0ull : 0ull;
-    unsigned long long Pv = ~0ull, Mv = 0ull;
-    int t = 1;
-    unsigned long long A = J.win.x, B = J.win.y;
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 rec = zero4, recn = (act && m > 0) ? J.jc[0] : zero4;
-    uint32_t EA = 0u, EB = 0u;
-    for (int c = 0; c < mmax; c++) {
-        if (act && c < m) {
-            if ((c & 7) == 0) { rec = recn; EA = rec.z; EB = rec.w; recn = c + 8 < m ? J.jc[(c >> 3) + 1] : zero4; }
-            const uint32_t sh = ((rec.x >> (4 * (c & 7))) & 15u) | (((rec.y >> (16 + (c & 7))) & 1u) << 4);
+        for (int x = 0; x < 8; x++) {
+            const uint32_t sh = ((shw >> (4 * x)) & 15u) | (((nbits >> (16 + x)) & 1u) << 4);
             t += (int)sh;
             const bool g = t > 1;
-            Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh));
-            Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh));
-            const unsigned long long f = (sh == 0u && g) ? 1ull : 0ull;
-            Pv &= ~f; Mv |= f;
+            // window moves down by sh rows: entering rows take vertical delta +1
+            const uint32_t f = (sh == 0u && g) ? 1u : 0u;         // window did not move: top row only from the left
+            Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh) & ~f);
+            Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh) | f);
             A = mk64(alignbit(EA, hi32(A), sh), alignbit(hi32(A), lo32(A), sh)); EA >>= sh;
             B = mk64(alignbit(EB, hi32(B), sh), alignbit(hi32(B), lo32(B), sh)); EB >>= sh;
-            if ((rec.y >> 24) & 1u) {                                 // more entering rows than the record carries
-                const int o = J.p0 + t - 1, w = o >> 6;
-                A = funnel128(J.fp[2 * w], J.fp[2 * w + 2], o & 63); B = funnel128(J.fp[2 * w + 1], J.fp[2 * w + 3], o & 63);
+            if (esc_any) {
+                if (esc) {
+                    const int o = J.p0 + t - 1, w = o >> 6;
+                    const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w);
+                    const ulonglong2 q1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 2);
+                    A = ~funnel128(q0.x, q1.x, o & 63); B = ~funnel128(q0.y, q1.y, o & 63);
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this rare path stays in flight (exact waits elsewhere)
             }
-            const uint32_t cl = 0u - ((rec.y >> (c & 7)) & 1u), ch = 0u - ((rec.y >> (8 + (c & 7))) & 1u);
-            const unsigned long long Eq = ~((A ^ mk64(cl, cl)) | (B ^ mk64(ch, ch)));
+            const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
+            const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
+            // rows below the fragment (i > n) are not masked: they never feed a row above them
+            const unsigned long long Eq = (A ^ mk64(cl, cl)) & (B ^ mk64(ch, ch));
             const unsigned long long Xv = Eq | Mv;
             const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             const unsigned long long Ph = Mv | ~(Xh | Pv);
             const unsigned long long Mh = Pv & Xh;
             const unsigned long long D0 = Xh | Mv;
-            const unsigned long long Phs = (Ph << 1) | 1ull, Mhs = Mh << 1;
+            const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
+            const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
             Pv = Mhs | ~(Xv | Phs);
             Mv = Phs & Xv;
             const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
-            ulonglong2 w;
-            w.y = ~(upv | Ph);                                    // diagonal
-            w.x = (Ph & (~upv | M64)) | (w.y & D0);               // left | diagonal match
-            *reinterpret_cast<ulonglong2*>(J.trace + 2 * (size_t)c) = w;
+            // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal
+            const unsigned long long w1 = ~(upv | Ph);
+            const unsigned long long w0 = (Ph & (~upv | M64)) | (w1 & D0);
+            // stored rows: ROWS around the generative row, which sits at bit 31 once the window moves (t > 1) and climbs from
+            // bit 0 with the column index while the window is still clamped at row 1: band rows st .. st + ROWS - 1,
+            // st = clamp(column - (31 - ST), 0, ST), a function of the column alone (scalar here, a constant in the walk).
+            // More rows above the generative row than below: co-optimal paths take the deletions of a homopolymer run at
+            // its end, i.e. run above the generative row (measured on 1-kb bulk / polyA-tailed jobs: rows 23..38 miss
+            // 0.9 % / 5 %, rows 12..43 0.02 % / 0.14 %)
+            if constexpr (ROWS == 64) {
+                tw[4 * (x & 3)] = lo32(w0); tw[4 * (x & 3) + 1] = hi32(w0); tw[4 * (x & 3) + 2] = lo32(w1); tw[4 * (x & 3) + 3] = hi32(w1);
+                if ((x & 3) == 3) put_line((cb + x) >> 2, -1);
+            } else {
+                const uint32_t st = (uint32_t)(min(max(cb + x, RAMP0), 31) - RAMP0);
+                const uint32_t s0 = alignbit(hi32(w0), lo32(w0), st), s1 = alignbit(hi32(w1), lo32(w1), st);
+                if constexpr (ROWS == 16) tw[x] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);      // w1 rows in the high half
+                else { tw[2 * x] = s0; tw[2 * x + 1] = s1; }
+            }
         }
-    }
-    // walk back: every lane on its own job, 4 columns (64 bytes) per block, next block requested one block ahead
-#ifdef TKSM_ABLATE
-    int minb = 63, maxb = -1;
-#endif
-    int i = n, j = m, tt = t;
-    uint32_t mt = 0, cols = 0;
-    int dpend = 0;
-    bool fail = act && m > 0 && (n - tt > 63 || n - tt < 0);
-    const int topblk = (mmax - 1) >> 2;
-    const uint32_t modem = mode ? 0xffu : 0u;
-    unsigned long long pp = 0ull;
-    bool touched = false;
-    uint2 cur_sh = make_uint2(0u, 0u), pre_sh = cur_sh;
-    unsigned long long pre[8];
-    auto loadb = [&](int blk2) {
-        const bool have = act && blk2 >= 0 && blk2 * 4 < m;
-#pragma unroll
-        for (int x = 0; x < 8; x++) pre[x] = have ? J.trace[(size_t)blk2 * 8 + x] : 0ull;
-        if (have) { const uint4 q4 = J.jc[blk2 >> 1]; pre_sh = make_uint2(q4.x, (q4.y >> 16) & 0xffu); } else pre_sh = make_uint2(0u, 0u);
+        if constexpr (ROWS == 16) put_line(cb >> 4, bq & 1);
+        if constexpr (ROWS == 32) put_line(cb >> 3, -1);
     };
-    wave_sync();
-    loadb(topblk);
-    for (int blk = topblk; blk >= 0 && mmax > 0; blk--) {
-        wave_sync();
-#pragma unroll
-        for (int x = 0; x < 8; x++) tr_lds[((x >> 1) * 64 + lane) * 2 + (x & 1)] = pre[x];
-        cur_sh = pre_sh;
-        wave_sync();
-        loadb(blk - 1);
-        bool go = act && !fail && j > 0 && ((j - 1) >> 2) == blk;
-        while (go) {
-            const int c8 = (j - 1) & 7, cb = (j - 1) & 3;
-            const int b = i - tt;
-            const unsigned long long w0 = tr_lds[(cb * 64 + lane) * 2], w1 = tr_lds[(cb * 64 + lane) * 2 + 1];
-            int code = (int)((w0 >> (b & 63)) & 1ull) | ((int)((w1 >> (b & 63)) & 1ull) << 1);
-            code = b > 63 ? 0 : code;
-            code = i == 0 ? 1 : code;
-            if ((i > 0 && b < 0) || cols > (uint32_t)(n + m)) { fail = true; break; }
+    for (int c0 = 0; c0 < mmax; c0 += 32) {
+        // every record is requested again as soon as its block is done: 24 columns ahead of its use (a row has 8 spare records)
+        const uint4* nx = rcl + (size_t)((c0 >> 5) + 1) * 256;
+        fwd_block(c0, 0, rn0); rn0 = nx[0];
+        fwd_block(c0, 1, rn1); rn1 = nx[1];
+        fwd_block(c0, 2, rn2); rn2 = nx[2];
+        fwd_block(c0, 3, rn3); rn3 = nx[3];
+        if (c0 == 0) t32 = t;                                     // window position of column 31 (the walk's clamped start)
+    }
 #ifdef TKSM_ABLATE
-            if (tt > 1 && i > 0 && b <= 63) { minb = min(minb, b); maxb = max(maxb, b); }
+    if (ablate >= 11 && ablate <= 19) { AlnRes R0; R0.mt = (uint32_t)(Pv ^ Mv); R0.cols = (uint32_t)t; R0.fail = false; R0.needfull = false; return R0; }
 #endif
-            cols++;
-            const bool up = code == 0;
-            i -= code != 1 ? 1 : 0;
-            mt += code == 3 ? 1u : 0u;
-            const uint32_t opb = (uint32_t)((code == 1 ? 2 : (code == 3 ? 0 : 1)) | (min(dpend, 63) << 2));
-            pp |= up ? 0ull : (unsigned long long)(opb & modem) << (8 * c8);
-            touched |= !up;
-            dpend = up ? dpend + 1 : 0;
-            tt -= up ? 0 : (int)(((cur_sh.x >> (4 * c8)) & 15u) | (((cur_sh.y >> c8) & 1u) << 4));
-            j -= up ? 0 : 1;
-            go = up || cb != 0;
+    // ---- walk back from (n, m).  Every column is left exactly once (by a left or a diagonal move), so all lanes of the wave
+    // walk in LOCKSTEP: line and column are wave-uniform (registers and shift fields are compile-time picks), a lane joins at its
+    // own last column.  Inside a column the run of up moves is counted with one find-first-bit on the column's "not up" bits, so
+    // a column costs ~24 vector instructions, branch-free.  Nothing but the stored-row index `bs` of the current cell is
+    // tracked in columns >= 32 (st = ST there): matches and diagonal moves are counted, columns = n + m - diagonals.  A path
+    // that leaves the stored rows sets needfull (with all 64 rows stored: a cell below the band is virtual, the path moves up
+    // from it; one above the band fails the job).  Columns < 32 (window possibly clamped at row 1, st ramps) track row and window
+    // position as well: there the path may reach row 0, after which only left moves remain.
+    bool fail = act && m > 0 && (n - t > 63 || n - t < 0), needfull = false;
+    bool live = act && !fail && m > 0;
+    uint32_t mt = 0, dg = 0;
+    int bs = n - t - (min(max(m - 1, RAMP0), 31) - RAMP0);
+    int i = n, tt = t;                                            // used below column 32 only
+    // one column; RAMP: columns < 32.  lo / hi: the column's codes (u32, or u64 with all rows stored)
+    auto walk_col = [&](int col, auto ramp, auto lo, auto hi, uint2 shw, unsigned long long& pp, bool& touched) {
+        constexpr bool RAMP = decltype(ramp)::value;
+        const int c8 = col & 7;
+        if (live && col < m) {
+            const uint32_t shc = ((shw.x >> (4 * c8)) & 15u) | (((shw.y >> (16 + c8)) & 1u) << 4);   // this column's shift
+            if (RAMP) bs = i - tt - (min(max(col, RAMP0), 31) - RAMP0);
+            uint32_t extra = 0u;
+            if constexpr (ROWS == 64) { extra = (uint32_t)max(bs - 63, 0); bs -= (int)extra; }      // virtual cells below the band: up
+            // run of up moves from the current cell: bits of neither plane set, from bit bs downwards
+            uint32_t run;
+            if constexpr (ROWS == 64) {
+                const unsigned long long y = (lo | hi) << ((63 - bs) & 63);
+                run = y ? (uint32_t)__builtin_clzll(y) : 64u;
+            } else {
+                const uint32_t y = (lo | hi) << ((31 - bs) & 31); // (16 rows: hi = lo >> 16, the halves above bit 15 are shifted out)
+                run = y ? (uint32_t)__builtin_clz(y) : 32u;
+            }
+            bool ok = (uint32_t)bs < (uint32_t)ROWS;
+            bool zero = false;
+            if (RAMP) {
+                run = min(run, (uint32_t)(bs + 1));               // (the shift filled the word with "up" bits below bit 0)
+                if (i == 0) { run = 0u; extra = 0u; }
+                zero = (uint32_t)i == run + extra || i == 0;      // the path reaches (or is in) row 0: this column and all before it are left moves
+                ok |= i == 0;
+            }
+            const int bs2 = bs - (int)run;
+            ok &= bs2 >= 0 || zero;
+            const uint32_t lb = zero ? 1u : (uint32_t)(lo >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;
+            const uint32_t hb = zero ? 0u : (uint32_t)(hi >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;     // lb | hb << 1: 1 left, 2 diagonal mismatch, 3 diagonal match
+            needfull |= !ok;
+            live = ok && !zero;
+            mt += hb & lb;
+            dg += hb;
+            if (MODE) {
+                const uint32_t op = hb ? (lb ^ 1u) : 2u;          // 0 match, 1 mismatch, 2 read-only base; the run = fragment-only bases in front
+                pp |= (unsigned long long)(op | (min(run + extra, 63u) << 2)) << (8 * c8);
+                touched = true;
+                if (zero) {
+                    // only left moves remain: the rest of this group and every group before it
+                    pp |= 0x0202020202020202ull & ((1ull << (8 * c8)) - 1ull);
+                    for (int b2 = (col >> 3) - 1; b2 >= 0; b2--) J.popd8[b2] = 0x0202020202020202ull;
+                }
+            }
+            if (RAMP) { i -= (int)(run + extra + hb); tt -= (int)shc; }
+            else bs = bs2 - (int)hb + (int)shc;
         }
-        // the op bytes of a group of 8 columns are complete when the walk leaves its lower block
-        if ((blk & 1) == 0) {
-            if (touched && mode) J.popd8[blk >> 1] = pp;
-            pp = 0ull; touched = false;
+    };
+    // lines in flight: two register sets, one line ahead
+    uint4 la0, la1, la2, la3, lb0, lb1, lb2, lb3;
+    uint2 sa0, sa1, sb0, sb1;
+    auto load_line = [&](int q, uint4& l0, uint4& l1, uint4& l2, uint4& l3, uint2& s0, uint2& s1) {
+        q = max(q, 0);
+        const uint4* p = trl + (q * NC < m ? (size_t)q * ls : spare);
+        l0 = p[0]; l1 = p[1]; l2 = p[2]; l3 = p[3];
+        const int b = q * NC / 8;                                 // shift fields of the line's columns: the first 8 bytes of their block records
+        s0 = *reinterpret_cast<const uint2*>(job_rec_ptr(J, b));
+        if (ROWS == 16) s1 = *reinterpret_cast<const uint2*>(job_rec_ptr(J, b + 1)); else s1 = s0;
+    };
+    unsigned long long ppk = 0ull;                                // (all rows stored: a group of 8 columns spans two lines)
+    bool tk = false;
+    auto walk_line = [&](int q, const uint4& l0, const uint4& l1, const uint4& l2, const uint4& l3, uint2 s0, uint2 s1) {
+        const uint32_t w[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+        unsigned long long pp0 = 0ull, pp1 = 0ull;                // op bytes of the line's one or two groups of 8 columns
+        bool touched0 = false, touched1 = false;
+        const int cq = q * NC;
+        auto cols_of_line = [&](auto ramp) {
+#pragma unroll
+            for (int c = NC - 1; c >= 0; c--) {
+                if constexpr (ROWS == 16) walk_col(cq + c, ramp, w[c], w[c] >> 16, c >= 8 ? s1 : s0, c >= 8 ? pp1 : pp0, c >= 8 ? touched1 : touched0);
+                else if constexpr (ROWS == 32) walk_col(cq + c, ramp, w[2 * c], w[2 * c + 1], s0, pp0, touched0);
+                else walk_col(cq + c, ramp, mk64(w[4 * c + 1], w[4 * c]), mk64(w[4 * c + 3], w[4 * c + 2]), s0, ppk, tk);
+            }
+        };
+        if (cq >= 32) cols_of_line(std::false_type{});
+        else {
+            if (cq == 32 - NC && m > 32) { tt = t32; i = bs + t32 + ST; }      // leaving the columns where only bs is tracked
+            cols_of_line(std::true_type{});
+        }
+        if (MODE) {
+            if constexpr (ROWS == 64) {
+                if ((q & 1) == 0) { if (tk) J.popd8[cq >> 3] = ppk; ppk = 0ull; tk = false; }
+            } else {
+                if (touched0) J.popd8[cq >> 3] = pp0;
+                if (ROWS == 16 && touched1) J.popd8[(cq >> 3) + 1] = pp1;
+            }
+        }
+    };
+    if (mmax > 0) {
+        const int topq = (mmax - 1) / NC;
+        load_line(topq, la0, la1, la2, la3, sa0, sa1);
+        for (int q = topq; q >= 0; q -= 2) {
+            load_line(q - 1, lb0, lb1, lb2, lb3, sb0, sb1);
+            walk_line(q, la0, la1, la2, la3, sa0, sa1);
+            if (q > 0) {
+                load_line(q - 2, la0, la1, la2, la3, sa0, sa1);
+                walk_line(q - 1, lb0, lb1, lb2, lb3, sb0, sb1);
+            }
         }
     }
-    if (act && !fail && i > 0) { cols += (uint32_t)i; i = 0; }
-#ifdef TKSM_ABLATE
-    if (hist && act && !fail && maxb >= 0) { atomicAdd(&hist[16 + minb / 4], 1u); atomicAdd(&hist[32 + maxb / 4], 1u); }
-#endif
     AlnRes R;
-    R.mt = mt; R.cols = cols; R.fail = fail; R.needfull = false;
+    R.mt = mt; R.cols = (uint32_t)(n + m) - dg;
+    R.fail = fail || (ROWS == 64 && needfull); R.needfull = ROWS != 64 && needfull;
     return R;
 }
 
@@ -2052,7 +1967,9 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
     const uint32_t r = meta.x;
     const int p0 = (int)meta.y, n = (int)(meta.z & 0x7fffffffu);
     const RangeGeo G = FB.geo_cur[rng];
-    uint4* jc = FB.job_cols + G.jc_off + (size_t)(job - rbase) * G.cw;
+    // records leave as 64-byte lines of 4 (32 columns); the lines of the wave's 64 jobs are interleaved, so that k_aln's lanes read
+    // (and this kernel's lanes write) neighbouring lines: 4 KB per wave and group of 32 columns
+    uint4* jc = FB.job_cols + G.jc_off + (size_t)(job0 - rbase) * G.cw + (size_t)lane * 4;
     const int ncap_l = (int)G.ncap;
     const uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
     const ulonglong2* fp = reinterpret_cast<const ulonglong2*>(FB.st_fplanes + (size_t)r * 2 * FB.fw);   // {lo, hi} per 64 positions
@@ -2102,7 +2019,7 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
         const int tq = nrec++;
         if (8 * tq < ncap_l) {
             rs[(tq & 3) * 64 + lane] = rec;
-            if ((tq & 3) == 3) { uint4* d = jc + (tq & ~3); d[0] = rs[lane]; d[1] = rs[64 + lane]; d[2] = rs[128 + lane]; d[3] = rs[192 + lane]; }
+            if ((tq & 3) == 3) { uint4* d = jc + (size_t)(tq >> 2) * 256; d[0] = rs[lane]; d[1] = rs[64 + lane]; d[2] = rs[128 + lane]; d[3] = rs[192 + lane]; }
         }
     };
     for (int s0 = 0; s0 < nmax; s0 += 32) {
@@ -2152,7 +2069,7 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
     if (m <= ncap_l) {
         // the complete records still in LDS
         const int cnt = nrec & 3;
-        uint4* d = jc + (nrec & ~3);
+        uint4* d = jc + (size_t)(nrec >> 2) * 256;
         if (cnt > 0) d[0] = rs[lane];
         if (cnt > 1) d[1] = rs[64 + lane];
         if (cnt > 2) d[2] = rs[128 + lane];
@@ -2179,13 +2096,11 @@ DEV void load_job(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act, A
         r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
     }
     const RangeGeo G = FB.geo_cur[rng];
-    const uint32_t rel = job - FB.base_cur[rng];
-    J.cw = (int)G.cw;
+    const uint32_t rel = job - FB.base_cur[rng];                      // (range bases are multiples of 64: rel & 63 = the job's lane in k_job)
     J.fp = FB.st_fplanes + (size_t)r * 2 * FB.fw;
-    J.jc = FB.job_cols + G.jc_off + (size_t)rel * G.cw;
+    J.jcl = FB.job_cols + G.jc_off + (size_t)(rel & ~63u) * G.cw + (size_t)(rel & 63u) * 4;
     J.win.x = 0ull; J.win.y = 0ull;
     if (act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
-    J.tstride = (size_t)G.tstride;                                  // 8-byte predecessor columns
     J.trace = nullptr;                                               // full-width rows come from a small pool
     J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + G.popd_off + (size_t)rel * G.ncap);
 }
@@ -2193,72 +2108,92 @@ DEV void store_result(const FastBuffers& FB, uint32_t r, const AlnRes& R) {
     ReadState* st = FB.state + r;
     st->res_mt = R.mt; st->res_cols = R.cols; st->res_fail = (R.fail || R.needfull) ? 1u : 0u;
 }
+DEV int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// the lanes that want it append their job to a list (wave-aggregated)
+DEV void list_append(uint32_t* list, uint32_t* counter, bool want, uint32_t job, int lane) {
+    const unsigned long long wm = __ballot(want);
+    if (!wm) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(counter, (uint32_t)__popcll(wm));
+    base = __shfl(base, 0, 64);
+    if (want) list[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = job;
+}
 
-// FULL_ONLY: rounds with few jobs are bound by the latency of one lane's pass; they go straight to the full-width
-// pass (traffic is irrelevant).  Otherwise: 8-byte columns, and the lanes whose walk leaves the stored rows are redone at
-// full width in place.  counters[3] allocates rows of the full-width pool in both cases.
+// Alignment passes of a round (launch_aln): pass 1 = every job with 16 stored rows; pass 2 = the jobs whose path left them
+// (counters[10] of them in redo_list), 32 stored rows, lines in a pool behind pass 1's; pass 3 = what is left (counters[11] in
+// redo_list2), all 64 rows, lines in the full-width pool.  Passes 2 and 3 loop over their list with a fixed grid, each wave on its
+// own pool lines.  Rounds with few jobs are bound by the latency of one lane's pass: all their jobs go straight to the 64-row
+// version (ROWS 64, LIST false; traffic is irrelevant; counters[3] allocates pool lines per wave).
 #ifndef ALN_WAVES
 #define ALN_WAVES 4
 #endif
-template <bool FULL_ONLY, int MODE>
+template <int MODE, int ROWS, bool LIST>
 __global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
-    __shared__ unsigned long long tr_lds[8 * 64];   // 4 KB: 8 columns x 8 B or 4 columns x 16 B per lane
-    __shared__ uint4 rec_lds[4 * 64];               // 4 KB: the current group of 4 block records per lane
     const int lane = threadIdx.x;
-    const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
-    // job ids of a range start at its wave-aligned base (this round's bases are the packed counts of the previous round)
-    const uint32_t rng = range_of_job(FB, job0);
-    const uint32_t rbase = FB.base_cur[rng];
-    const uint32_t in_rng = FB.job_cnt[rng * 32u];
-    if (in_rng <= job0 - rbase) return;                               // whole wave beyond the range's job count
-    AlnJob J;
-    uint32_t r;
-    load_job(FB, job, rng, job < n_jobs && job - rbase < in_rng, J, r);
-    const RangeGeo G = FB.geo_cur[rng];
-    const uint32_t rel0 = job0 - rbase;                              // the wave's first job within its range
-    J.jc0 = FB.job_cols + G.jc_off + (size_t)rel0 * G.cw;
-    J.wsh0 = reinterpret_cast<uint2*>(FB.walk_sh) + G.wsh_off + (size_t)rel0 * G.cw;
-    J.trace0 = reinterpret_cast<unsigned long long*>(FB.trace) + G.trace_off + (size_t)rel0 * J.tstride;
-    // a row of the full-width pool for every lane that wants one (wave-aggregated allocation)
-    auto pool_row = [&](bool want, uint32_t& slot) -> bool {
-        const unsigned long long wm = __ballot(want);
-        uint32_t base = 0;
-        if (lane == 0 && wm) base = atomicAdd(&FB.counters[3], (uint32_t)__popcll(wm));
-        base = __shfl(base, 0, 64);
-        slot = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
-        return want && slot < FB.full_rows;
-    };
-    int mmax = J.m;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
-#ifdef TKSM_ABLATE
-    if (P.ablate == 10) return;
-#endif
-    AlnRes R;
-    if (FULL_ONLY) {
-        uint32_t slot;
-        const bool ok = pool_row(J.act, slot);
-        if (ok) J.trace = reinterpret_cast<unsigned long long*>(FB.trace_full) + (size_t)slot * (size_t)(P.ncap + 16) * 2;
-        R = aln_full(J, ok, mmax, lane, tr_lds, P.ablate == 23 ? FB.counters : nullptr);
-        if (J.act && !ok) R.fail = true;
-        if (J.act) store_result(FB, r, R);
-    } else {
-        R = aln_fast<MODE>(J, mmax, (int)((G.ncap + 7) & ~7u), lane, tr_lds, rec_lds, P.ablate, FB.counters + 10);
-        uint32_t slot;
-        const unsigned long long nf = __ballot(J.act && R.needfull);
-        if (lane == 0 && nf) { atomicAdd(&FB.counters[8], (uint32_t)__popcll(nf)); atomicAdd(&FB.counters[9], 1u); }   // diagnostics
-        const bool redo = pool_row(J.act && R.needfull, slot);
-        // the few lanes whose walk left the stored rows are redone at full width here, underneath the other waves of the
-        // launch (handing them to a packed follow-up launch was tried: its latency costs more per round than it saves)
-        if (__ballot(redo)) {
-            if (redo) J.trace = reinterpret_cast<unsigned long long*>(FB.trace_full) + (size_t)slot * (size_t)(P.ncap + 16) * 2;
-            int mm2 = redo ? J.m : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mm2 = max(mm2, __shfl_xor(mm2, o, 64));
-            const AlnRes R2 = aln_full(J, redo, mm2, lane, tr_lds);
-            if (redo) R = R2;                                         // without a row needfull stays set: reported as a failure
+    uint32_t* next_list = ROWS == 16 ? FB.redo_list : FB.redo_list2;
+    uint32_t* next_cnt = FB.counters + (ROWS == 16 ? 10 : 11);
+    if (!LIST) {
+        const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
+        // job ids of a range start at its wave-aligned base (this round's bases are the packed counts of the previous round)
+        const uint32_t rng = range_of_job(FB, job0);
+        const uint32_t rbase = FB.base_cur[rng];
+        const uint32_t in_rng = FB.job_cnt[rng * 32u];
+        if (in_rng <= job0 - rbase) return;                           // whole wave beyond the range's job count
+        AlnJob J;
+        uint32_t r;
+        bool act = job < n_jobs && job - rbase < in_rng;
+        uint4* trl;
+        int tg;
+        bool norow = false;
+        uint32_t ls = 256u;
+        if (ROWS == 64) {
+            // pool lines for the wave's jobs only (long molecules: a job's lines are megabytes)
+            const unsigned long long wm = __ballot(act);
+            const uint32_t na = (uint32_t)__popcll(wm);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&FB.counters[3], na);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + na > FB.full_rows) { norow = act; act = false; base = 0; }    // no pool lines left: reported as failures (the wave-wide kernel takes the reads)
+            tg = (int)FB.full_tg;
+            ls = 4u * max(na, 1u);
+            trl = reinterpret_cast<uint4*>(FB.trace_full) + ((size_t)base * FB.full_tg + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull)) % max(na, 1u)) * 4;
+        } else {
+            const RangeGeo G = FB.geo_cur[rng];
+            const uint32_t rel = job - rbase;
+            tg = (int)G.tstride;
+            trl = reinterpret_cast<uint4*>(FB.trace) + (G.trace_off + (size_t)(rel >> 6) * G.tstride * 64 + (rel & 63u)) * 4;
         }
-        if (J.act) store_result(FB, r, R);
+        load_job(FB, job, rng, act || norow, J, r);
+        J.act = act;
+#ifdef TKSM_ABLATE
+        if (P.ablate == 10) return;
+#endif
+        AlnRes R = aln_fast<MODE, ROWS>(J, wave_max(act ? J.m : 0), trl, tg, ls, P.ablate);
+        if (norow) { R.fail = true; R.needfull = false; }
+        if (ROWS != 64) list_append(next_list, next_cnt, act && R.needfull, job, lane);
+        if ((act || norow) && !R.needfull) store_result(FB, r, R);
+    } else {
+        const uint32_t n_list = FB.counters[ROWS == 32 ? 10 : 11];
+        if (ROWS == 64 && lane == 0 && blockIdx.x == 0 && n_list) { atomicAdd(&FB.counters[8], n_list); atomicAdd(&FB.counters[9], (n_list + 63u) / 64u); }   // diagnostics
+        const uint32_t* list = ROWS == 32 ? FB.redo_list : FB.redo_list2;
+        const int tg = (int)(ROWS == 32 ? FB.pool_tg : FB.full_tg);
+        uint4* trl = reinterpret_cast<uint4*>(ROWS == 32 ? FB.trace_pool : reinterpret_cast<uint8_t*>(FB.trace_full)) + ((size_t)blockIdx.x * tg * 64 + (uint32_t)lane) * 4;
+        for (uint32_t base = blockIdx.x * 64u; base < n_list; base += gridDim.x * 64u) {     // wave-uniform: every wave ends
+            const uint32_t idx = base + (uint32_t)lane;
+            const bool act = idx < n_list;
+            const uint32_t job = list[min(idx, n_list - 1u)];                               // (idle lanes shadow the last job)
+            const uint32_t rng = range_of_job(FB, job);
+            AlnJob J;
+            uint32_t r;
+            load_job(FB, job, rng, act, J, r);
+            const AlnRes R = aln_fast<MODE, ROWS>(J, wave_max(act ? J.m : 0), trl, tg, 256u, P.ablate);
+            if (ROWS != 64) list_append(next_list, next_cnt, act && R.needfull, job, lane);
+            if (act && !R.needfull) store_result(FB, r, R);
+        }
     }
 }
 
@@ -2755,9 +2690,24 @@ hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hi
 }
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, hipStream_t s) {
     if (!n_jobs) return hipSuccess;
-    if (full_only) hipLaunchKernelGGL((k_aln<true, 0>), dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);    // (takes the mode from the job)
-    else if (mode) hipLaunchKernelGGL((k_aln<false, 1>), dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
-    else hipLaunchKernelGGL((k_aln<false, 0>), dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, n_jobs);
+    const uint32_t waves = (n_jobs + 63) / 64;
+    if (full_only) {
+        if (mode) hipLaunchKernelGGL((k_aln<1, 64, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
+        else hipLaunchKernelGGL((k_aln<0, 64, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
+        return hipGetLastError();
+    }
+    // pass 2 and 3 grids: an eighth / a sixty-fourth of the jobs per sweep (their waves loop over what the lists hold), within their pools
+    const uint32_t g2 = std::max<uint32_t>(1u, std::min<uint32_t>((waves + 7) / 8, fb.pool_jobs / 64));
+    const uint32_t g3 = std::max<uint32_t>(1u, std::min<uint32_t>((waves + 63) / 64, std::max<uint32_t>(1u, fb.full_rows / 64)));
+    if (mode) {
+        hipLaunchKernelGGL((k_aln<1, 16, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
+        hipLaunchKernelGGL((k_aln<1, 32, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
+        hipLaunchKernelGGL((k_aln<1, 64, true>), dim3(g3), dim3(64), 0, s, p, fb, n_jobs);
+    } else {
+        hipLaunchKernelGGL((k_aln<0, 16, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
+        hipLaunchKernelGGL((k_aln<0, 32, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
+        hipLaunchKernelGGL((k_aln<0, 64, true>), dim3(g3), dim3(64), 0, s, p, fb, n_jobs);
+    }
     return hipGetLastError();
 }
 hipError_t launch_emit(const BatchView& b, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records, hipStream_t s) {
