@@ -683,9 +683,12 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_frag2.ensure(n * (size_t)FB.fw2 * 4 + 64));
         for (int z = 0; z < 2; z++) {
             HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
-            HIPCHK(ctx, ctx->f_jcols[z].ensure(tot_jc * 16 + 64));
-            HIPCHK(ctx, ctx->f_jwin[z].ensure(jcap * 16 + 64));
-            HIPCHK(ctx, ctx->f_jpopd[z].ensure(tot_popd + 64));
+            if (z == 0) {
+                // (one set: only the meta records and the counts of the previous round are read again)
+                HIPCHK(ctx, ctx->f_jcols[z].ensure(tot_jc * 16 + 64));
+                HIPCHK(ctx, ctx->f_jwin[z].ensure(jcap * 16 + 64));
+                HIPCHK(ctx, ctx->f_jpopd[z].ensure(tot_popd + 64));
+            }
             HIPCHK(ctx, ctx->f_jobcnt[z].ensure((size_t)FB.n_ranges * 128 + 64));
         }
         HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
@@ -716,9 +719,9 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.geo_cur = ctx->f_geo.as<tk::RangeGeo>(); FB.geo_prev = FB.geo_cur + FB.n_ranges;
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
-            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[z].as<uint4>(); FB.job_win = ctx->f_jwin[z].as<unsigned long long>();
-            FB.job_popd = ctx->f_jpopd[z].as<uint8_t>(); FB.job_cnt = ctx->f_jobcnt[z].as<uint32_t>();
-            FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[y].as<uint8_t>();
+            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[0].as<uint4>(); FB.job_win = ctx->f_jwin[0].as<unsigned long long>();
+            FB.job_popd = ctx->f_jpopd[0].as<uint8_t>(); FB.job_cnt = ctx->f_jobcnt[z].as<uint32_t>();
+            FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[0].as<uint8_t>();
         };
         select_set(0);
         // host copy of {prefix, base_prev, base_cur}, uploaded before every round

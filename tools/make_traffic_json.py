@@ -6,7 +6,7 @@ gathers (k_loop's table reads) are counted as one 64-byte sector each (factor 1)
 import csv, glob, collections, json, re, sys
 
 d, nsteps = sys.argv[1], int(sys.argv[2])
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1310720
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1703936
 tag = sys.argv[4] if len(sys.argv) > 4 else ""
 FETCH_FACTOR = {"k_aln": 1 / 0.542, "k_job": 1 / 0.606, "k_loop": 1.0, "k_qjobs": 1.0, "k_err": 2.0, "k_init": 2.0, "k_emit": 2.0, "k_perfect": 2.0,
                 "k_pack": 2.0, "k_simulate": 1.0}

@@ -19,7 +19,7 @@ echo fetch done >> $out/progress.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $out/write.log 2>&1
 echo write done >> $out/progress.log
 cd $R
-python tools/make_traffic_json.py $out 7 1310720 $tag > $out/hbm_traffic.json   # 3 warm-up + 3 timed steps + the exclusive step
+python tools/make_traffic_json.py $out 7 1703936 $tag > $out/hbm_traffic.json   # 3 warm-up + 3 timed steps + the exclusive step
 cp $out/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 cp $out/stats1/*/*kernel_stats.csv $out/single_ctx_kernel_stats.csv
 rm -rf $out/stats $out/stats1 $out/fetch/*/*agent_info.csv
