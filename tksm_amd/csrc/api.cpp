@@ -43,6 +43,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_TAIL_CUT")) c->tail_cut = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ROUND")) c->small_round = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
+    if (const char* tc = getenv("TKSMSEQ_WAVE_LOOP")) c->wave_loop = (uint32_t)atoi(tc);
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
     if (const char* fp = getenv("TKSMSEQ_FULL_POOL_MB")) c->full_pool_bytes = (unsigned long long)atoll(fp) << 20;
@@ -860,6 +861,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 // the error loops of all reads that are still running, one lane each (round 0: every read, in sorted order;
                 // later: the reads of the previous round's jobs), then this round's jobs packed for k_aln, one lane each
                 if (rounds == 0) HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, (uint32_t)n, lcap, 0, 0, 0, s));
+                else if (hprefix[FB.n_ranges] <= ctx->wave_loop && lcap <= 32768)        // few reads left: a wave each (latency)
+                    HIPCHK(ctx, tk::launch_loopw(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
                 else HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
                 if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
                 kinds.push_back(1);

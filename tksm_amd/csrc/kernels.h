@@ -202,6 +202,9 @@ int err_lds_bytes(int lcap, int ncap, int waves_per_wg, bool state_in_hbm);
 // error loop, one lane per read: reads order[begin .. begin+count) (from_jobs = 0) or the reads of the previous round's jobs
 // of ranges [c0, c1) (from_jobs = 1); words = fragment words per lane held in LDS (0: fragments stay in HBM)
 int loop_lds_words(int lcap);
+// the same visit with one wave per read (rounds with few reads left; the read's slot codes are staged in LDS: lcap <= 32768)
+hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
+                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,

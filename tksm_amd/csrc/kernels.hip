@@ -1455,6 +1455,194 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     }
 }
 
+// ---- k_loopw: the same visit of the error loop as k_loop, one WAVE per read -- for the rounds in which few reads are left.
+// A lane-per-read visit is a chain of ~40 batches of dependent table reads (1 - 2 ms whatever the number of reads); here the 64
+// lanes take 64 consecutive draws at once (generator, k-mer, thresholds, alternative: three rounds of loads for all of them), and
+// the draws that change something (~12 of 64) are then applied in draw order by the whole wave, on the read's slot codes staged
+// in LDS (every applied slot is also written through to HBM).  What follows a stop (re-estimation point, end of the loop) is
+// dropped and drawn again on the next visit, exactly as in k_loop: same draws, same order, same state records.
+__global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
+                                               uint32_t begin, uint32_t count, int from_jobs, uint32_t c0, uint32_t c1) {
+    uint16_t* nbl = reinterpret_cast<uint16_t*>(lds_raw);     // [lcap] slot codes of the read
+    const int lane = threadIdx.x;
+    const uint32_t widx = blockIdx.x;
+    if (widx >= count) return;
+    uint32_t r, rc;                                           // the read and its range of the sorted order (wave-uniform)
+    if (!from_jobs) { r = order[begin + widx]; rc = (begin + widx) / FB.rs; }
+    else {
+        const uint32_t target = FB.prefix[c0] + widx;
+        uint32_t lo2 = c0, hi2 = c1 - 1;
+        while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2 + 1) >> 1; if (FB.prefix[mid] <= target) lo2 = mid; else hi2 = mid - 1; }
+        r = FB.prev_meta[4ull * (FB.base_prev[lo2] + (target - FB.prefix[lo2]))];
+        rc = lo2;
+    }
+    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r); rc = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc);
+    ReadState* sp = FB.state + r;
+    const ReadState S = *sp;
+    if (S.stage != 0 || S.slow) return;
+    const int k = EM.k;
+    const int L = S.raw_len + 2 * k;
+    const uint32_t* f2 = FB.st_frag2 + (size_t)r * FB.fw2;
+    uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
+    for (int t = 2 * lane; t < L; t += 128) *reinterpret_cast<uint32_t*>(nbl + t) = *reinterpret_cast<const uint32_t*>(gnb + t);   // (rows are padded to 8 slots)
+    wave_sync();
+    const uint64_t g = P.first_read + (uint64_t)r * P.stride;
+    const double frag_len = (double)L, target = S.target;
+    const double rcp_len = rcp_refined(frag_len);
+    double errors = S.errors;
+    int change_count = S.change_count;
+    uint32_t n = S.n_base, aln_no = S.aln_no;
+    int resume_j = S.resume_j, st_draws = S.st_draws;
+    double est_keep = S.est;
+    if (S.pending == 1) {                                      // apply the re-estimation result (py/tksm_badread.py:412-432)
+        if (S.res_fail) {
+            // the alignment left the band representation: the read takes the byte-exact wave-wide kernel
+            if (lane == 0) {
+                sp->slow = 1;
+                atomicAdd(&FB.counters[4], 1u);
+                FB.slow_list[atomicAdd(&FB.counters[2], 1u)] = r;
+            }
+            return;
+        }
+        const uint32_t mt = S.res_mt, cols = S.res_cols;
+        const double ident = cols ? (double)mt / (double)cols : 0.0;
+        if (L <= 1000) errors = (1.0 - ident) * frag_len;
+        else {
+            const double estimated = (1.0 - ident) * frag_len;
+            const double weight = 1000.0 / frag_len;
+            errors = estimated * weight + errors * (1.0 - weight);
+        }
+        aln_no++;
+    }
+    const uint32_t kmer_range = (uint32_t)(L - k);            // max_kmer_index + 1
+    const long long loop_limit = 100ll * L;
+    const uint32_t kmask = (1u << (2 * k)) - 1u;
+    int cc25 = change_count % 25;
+    enum { RUN = 0, NEED_ALN = 1, DONE = 2 };
+    int st = RUN;
+    while (st == RUN) {
+        double est_cur = est_keep;
+        if (resume_j == 0) {
+            // stop rules at the top of an iteration (:353-367)
+            est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
+            if ((double)change_count > 0.9 * frag_len || est_cur <= target) { st = DONE; st_draws = (int)n; break; }
+        }
+        // ---- 64 draws: lane l takes draw n + l
+        const uint32_t nl = n + (uint32_t)lane;
+        const bool live = (long long)nl + 1 <= loop_limit;
+        const Ph4 d = philox(P.seed, g, ST_DRAW, nl);
+        const int di = (int)__umulhi(d.x, kmer_range);
+        const int w = di >> 4, o = di & 15;
+        const int kidx = (int)((uint32_t)(mk64(f2[w], f2[w + 1]) >> (64 - 2 * o - 2 * k)) & kmask);
+        const uint4 seg = EM.pseg[kidx];
+        const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
+        int cls = EM.type == 0 ? 2 : (d.y < seg.x ? (EM.alt0_noop ? 0 : 3) : 1);     // 0 no-op, 1 alternative a, 2 random change, 3 alternative 0
+        const int sbase = 8 * ((d.y < seg.y ? 0 : 1) + (d.y < seg.z ? 0 : 1) + (d.y < seg.w ? 0 : 1));
+        const uint4* c4 = reinterpret_cast<const uint4*>(EM.cdf32 + (cls == 1 ? (size_t)kidx * 32 + sbase : (size_t)0));
+        const uint4 th0 = c4[0], th1 = c4[1];
+        size_t at = 0;
+        if (cls == 1 || cls == 3) {
+            int a = 0;
+            if (cls == 1) {
+                const uint32_t wv = d.y;
+                a = sbase;
+                a += !(wv < th0.x) ? 1 : 0; a += !(wv < th0.y) ? 1 : 0; a += !(wv < th0.z) ? 1 : 0; a += !(wv < th0.w) ? 1 : 0;
+                a += !(wv < th1.x) ? 1 : 0; a += !(wv < th1.y) ? 1 : 0; a += !(wv < th1.z) ? 1 : 0; a += !(wv < th1.w) ? 1 : 0;
+                a = min(a, na);
+            }
+            if (a == na) cls = 2;                             // residual mass: add_one_random_change
+            else if (a == 0 && EM.alt0_noop) cls = 0;
+            else at = (size_t)kidx * EM.max_alts + a;
+        }
+        uint4 A = EM.alts_enc[at];
+        if (cls == 2) {
+            // add_one_random_change (:199-213), as in k_loop
+            const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
+            const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
+            const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
+            const uint32_t kc = ((uint32_t)kidx >> (2 * (k - 1 - (int)pos))) & 3u;
+            const uint32_t v = type == 0 ? 0x8000u | (1u << 12) | planar1((kc + r3) & 3u)
+                             : type == 1 ? 0x8000u | (2u << 12) | (side ? planar2(kc, base4) : planar2(base4, kc))
+                                         : 0x8000u;
+            const uint32_t wv = v << (16 * (pos & 1u)), which = pos >> 1;
+            A = make_uint4(which == 0 ? wv : 0u, which == 1 ? wv : 0u, which == 2 ? wv : 0u, which == 3 ? wv : 0u);
+        }
+        // the slots that differ from the original base (bit 15 of their encodings)
+        uint32_t dm = ((A.x >> 15) & 1u) | ((A.x >> 31) << 1) | (((A.y >> 15) & 1u) << 2) | ((A.y >> 31) << 3) |
+                      (((A.z >> 15) & 1u) << 4) | ((A.z >> 31) << 5) | (((A.w >> 15) & 1u) << 6) | ((A.w >> 31) << 7);
+        dm &= (1u << k) - 1u;
+        if (!live || cls == 0) dm = 0u;
+        unsigned long long mask = __ballot(dm != 0u);
+        const unsigned long long dead = __ballot(!live);
+        // ---- the draws that may change something, in draw order
+        while (mask) {
+            const int src = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int ai = __builtin_amdgcn_readlane(di, src);
+            uint4 As;
+            As.x = (uint32_t)__builtin_amdgcn_readlane((int)A.x, src); As.y = (uint32_t)__builtin_amdgcn_readlane((int)A.y, src);
+            As.z = (uint32_t)__builtin_amdgcn_readlane((int)A.z, src); As.w = (uint32_t)__builtin_amdgcn_readlane((int)A.w, src);
+            uint32_t dms = (uint32_t)__builtin_amdgcn_readlane((int)dm, src);
+            double est = est_cur;
+            if (resume_j > 0) { dms &= ~((1u << resume_j) - 1u); est = est_keep; }      // (the first draw of the visit: lane 0)
+            // in slot order (:378-403): applied if the position is still pristine
+            const double f15 = est * sqrt_inrange(est);
+            int stop_at = -1;
+            while (dms) {
+                const int jj = __builtin_ctz(dms);
+                dms &= dms - 1u;
+                if (nbl[ai + jj] == 0) {
+                    const uint32_t e = draw_slot(As, jj);
+                    if (lane == 0) { nbl[ai + jj] = (uint16_t)(e | 0x8000u); gnb[ai + jj] = (uint16_t)(e | 0x8000u); }
+                    change_count++;
+                    const int len_j = (int)((e >> 12) & 7u);
+                    errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
+                    if (++cc25 == 25) { cc25 = 0; stop_at = jj; break; }                  // ALIGNMENT_INTERVAL
+                }
+            }
+            wave_sync();
+            if (stop_at >= 0) {
+                st = NEED_ALN;
+                if (stop_at + 1 < k) { resume_j = stop_at + 1; est_keep = est; n += (uint32_t)src; }   // the rest of this draw follows the alignment
+                else { resume_j = 0; n += (uint32_t)src + 1u; }
+                break;
+            }
+            resume_j = 0;
+            // the rules at the top of the next iteration
+            est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
+            if ((double)change_count > 0.9 * frag_len || est_cur <= target) { st = DONE; st_draws = (int)n + src + 1; break; }
+        }
+        if (st != RUN) break;
+        resume_j = 0;
+        if (dead) { st = DONE; st_draws = (int)loop_limit; break; }
+        n += 64u;
+    }
+    // ---- as at the end of k_loop: a read at a re-estimation point gets an alignment job, one whose loop has ended waits (stage 3)
+    if (lane == 0) {
+        int st_aligns = S.st_aligns;
+        uint32_t job = 0;
+        if (st == NEED_ALN) {
+            job = FB.base_cur[rc] + atomicAdd(&FB.job_cnt[rc * 32u], 1u);
+            st_aligns++;
+            uint32_t p0 = 0, nrows = (uint32_t)L;
+            if (L > 1000) {
+                p0 = __umulhi(philox(P.seed, g, ST_ALNPOS, aln_no).x, (uint32_t)(L - 1000 + 1));
+                nrows = 1000u;
+            }
+            *reinterpret_cast<uint4*>(FB.job_meta + 4ull * job) = make_uint4(r, p0, nrows, 0u);
+        }
+        sp->errors = errors; sp->est = est_keep; sp->change_count = change_count; sp->n_base = n; sp->aln_no = aln_no;
+        sp->resume_src = -1; sp->resume_j = (int16_t)resume_j; sp->st_draws = st_draws; sp->st_aligns = st_aligns;
+        sp->pending = st == NEED_ALN ? 1 : 0;
+        sp->job = job;
+        sp->stage = st == NEED_ALN ? 0 : 3;
+        if (st == DONE) {
+            atomicAdd(&FB.defer_cnt[rc * 32u], 1u);
+            FB.defer_list[atomicAdd(&FB.counters[1], 1u)] = make_uint2(r, rc);
+        }
+    }
+}
+
 // ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (job staging / alignment ops).
 // STATE_IN_HBM (long reads): the fragment and its slot codes stay in HBM and are edited in place -- a round touches ~130
 // candidate positions and a 1000-slot window, so staging the whole fragment costs more than it saves, and its LDS
@@ -2671,6 +2859,12 @@ hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuf
     if (!count) return hipSuccess;
     const int Wl = std::min(loop_lds_words(lcap), fb.fw2);
     hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
+    return hipGetLastError();
+}
+hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
+                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_loopw, dim3(count), dim3(64), (size_t)lcap * 2 + 16, s, em, p, fb, order, begin, count, from_jobs, c0, c1);
     return hipGetLastError();
 }
 hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s) {
