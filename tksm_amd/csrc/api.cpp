@@ -917,7 +917,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             kinds.push_back(-1);
             HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 3, 0, 4, s));   // rows of the full-width pool
             HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 10, 0, 8, s));  // jobs handed to the second and third alignment pass
-            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= ctx->small_aln, qround ? 1 : 0, s));
+            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= std::min(ctx->small_aln, FB.full_rows), qround ? 1 : 0, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
             // next round: its jobs are packed by this round's counts (a read has at most one job per round)
