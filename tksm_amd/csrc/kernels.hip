@@ -1100,100 +1100,20 @@ DEV int joined_len(const uint16_t* nb, int p0, int n, int lane) {
     return m;
 }
 
-// Walks the slots of window [p0, p0+n) once, slot per lane, and
-//  build != 0: packs the joined sequence straight into the alignment job's block records (base code + 5-bit window
-//              shift per column) through one staging byte per column in LDS -- the owner array is never materialised;
-//  out_seq   : writes the joined bases [lo, hi) to out_seq (final stage).
-// Returns the job id (bit 31: the job cannot be represented: a shift > 31 rows).
-DEV uint32_t join_job(const FastBuffers& FB, int build, uint64_t r, uint32_t pos, int mode, const uint8_t* frag, const uint16_t* nb,
-                      int p0, int n, int& m, int ncap_l, uint8_t* stage, uint8_t* out_seq, int lo, int hi, int lane) {
-    // staging: one byte per column of the joined sequence, {bits 0-1 base code, bits 2-6 window shift (first symbol of a
-    // slot only)}; every column is written exactly once, by plain byte stores (bit planes filled by LDS atomics had 32
-    // lanes serialising on one word)
-    uint8_t* colb = stage;
-    uint32_t idx = 0;
-    const uint32_t rc = pos / FB.rs;                       // the read's range of the sorted order
-    if (build) {
-        ncap_l = min(ncap_l, (int)FB.geo_cur[rc].ncap);    // rows of the range's jobs are this long
-        if (lane == 0) idx = FB.base_cur[rc] + atomicAdd(&FB.job_cnt[rc * 32u], 1u);
-        idx = __shfl(idx, 0, 64);
-    }
-    bool fail = false;
-    int base = 0, last_nonempty = -1;
+// Walks the slots [0, n) once, slot per lane, and writes the joined bases [lo, hi) to out_seq (the last visit).
+DEV void join_out(const uint8_t* frag, const uint16_t* nb, int n, uint8_t* out_seq, int lo, int hi, int lane) {
+    int base = 0;
     for (int q = 0; q < n; q += 64) {
         const int p = q + lane;
         uint32_t code = 0; int len = 0; uint8_t orig = 0;
-        if (p < n) { code = nb[p0 + p]; len = slot_len(code); orig = frag[p0 + p]; }
+        if (p < n) { code = nb[p]; len = slot_len(code); orig = frag[p]; }
         int total;
         const int off = base + prefix_small(len, total);
-        const unsigned long long ne = __ballot(len > 0);
-        if (build && len > 0 && off + len <= ncap_l) {
-            const unsigned long long below = ne & ((1ull << lane) - 1ull);
-            const int prevp = below ? q + 63 - __builtin_clzll(below) : last_nonempty;
-            const int sh = max(1, p + 1 - 31) - max(1, prevp + 1 - 31);
-            if (sh > 31) fail = true;
-            // the slot's symbols, 2 bits each: the original base of a pristine slot, else the stored codes (the fast
-            // pipeline stores every symbol explicitly: its fragments are plain ACGT, no original-base markers)
-            const uint32_t syms = code ? code & 0x3ffu : planar1((uint32_t)orig);
-            colb[off] = (uint8_t)((syms & 1u) | (((syms >> 5) & 1u) << 1) | ((uint32_t)(sh & 31) << 2));
-            for (int x2 = 1; x2 < len; x2++) colb[off + x2] = (uint8_t)(((syms >> x2) & 1u) | (((syms >> (5 + x2)) & 1u) << 1));
-        }
-        if (out_seq) {
-            const uint32_t syms = code ? code & 0x3ffu : planar1((uint32_t)orig);
-            for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = base_char((int)(((syms >> x2) & 1u) | (((syms >> (5 + x2)) & 1u) << 1))); }
-        }
-        if (ne) last_nonempty = q + 63 - __builtin_clzll(ne);
+        // the slot's symbols, 2 bits each, planar: the original base of a pristine slot, else the stored codes
+        const uint32_t syms = code ? code & 0x3ffu : planar1((uint32_t)orig);
+        for (int x2 = 0; x2 < len; x2++) { const int c = off + x2; if (c >= lo && c < hi) out_seq[c - lo] = base_char((int)(((syms >> x2) & 1u) | (((syms >> (5 + x2)) & 1u) << 1))); }
         base += total;
     }
-    if (build) {
-        // the joined length is known now; a window that outgrew the staging area leaves an empty job behind (the caller
-        // reports the overflow)
-        m = base;
-        if (lane == 0) {
-            uint32_t* meta = FB.job_meta + 4ull * idx;
-            meta[0] = (uint32_t)r; meta[1] = (uint32_t)p0; meta[2] = (uint32_t)n | ((uint32_t)mode << 31);
-            meta[3] = (uint32_t)(m > ncap_l ? 0 : m);
-        }
-        if (m > ncap_l) return idx;
-        if (lane < 32) colb[m + lane] = 0;                        // the columns past the end that the last records cover
-        wave_sync();
-        // one record per 8 columns: {shifts, code bits, entering fragment rows}; one zero record after the end
-        const RangeGeo G = FB.geo_cur[rc];
-        uint4* jc = FB.job_cols + G.jc_off + (size_t)(idx - FB.base_cur[rc]) * G.cw;
-        const unsigned long long* fp = FB.st_fplanes + r * 2ull * FB.fw;
-        const int nrec = m / 8 + 2;
-        int tcar = 1;                                             // window top at the start of the chunk's first block
-        for (int q = 0; q < nrec; q += 64) {
-            const int t = q + lane;
-            // the block's 8 column bytes -> shift nibbles, code bits and shift bit 4 of the 8 columns, sum of the shifts
-            const unsigned long long v = t < nrec ? *reinterpret_cast<const unsigned long long*>(colb + 8 * t) : 0ull;
-            auto bit_of_bytes = [](unsigned long long x) { return (uint32_t)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); };
-            unsigned long long nb4 = (v >> 2) & 0x0f0f0f0f0f0f0f0full;
-            nb4 = (nb4 | (nb4 >> 4)) & 0x00ff00ff00ff00ffull; nb4 = (nb4 | (nb4 >> 8)) & 0x0000ffff0000ffffull; nb4 = nb4 | (nb4 >> 16);
-            const uint32_t shw = (uint32_t)nb4, shx = bit_of_bytes(v >> 6);
-            const uint32_t clo = bit_of_bytes(v), chi = bit_of_bytes(v >> 1);
-            const int adv = (int)((((v >> 2) & 0x1f1f1f1f1f1f1f1full) * 0x0101010101010101ull) >> 56);
-            const int incl = scan_add_incl(adv, lane);
-            const int tk = tcar + incl - adv;                     // window top at the start of block t
-            tcar += __shfl(incl, 63, 64);
-            if (t < nrec) {
-                // fragment rows p0 + tk - 1 + 64 .. + 95 (zero past the padded fragment)
-                const int o = p0 + tk - 1 + 64, w = o >> 6, s2 = o & 63;
-                const uint32_t elo = lo32(funnel128(fp[2 * w], fp[2 * w + 2], s2)), ehi = lo32(funnel128(fp[2 * w + 1], fp[2 * w + 3], s2));
-                uint4 rec;
-                // bit 24: the window moves by more rows in this block than the record carries (a homopolymer that lost most of
-                // its bases): k_aln then takes the window from the read's fragment planes, column by column
-                rec.x = shw; rec.y = clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u); rec.z = elo; rec.w = ehi;
-                jc[t] = rec;
-            }
-        }
-        if (lane == 0) {
-            const int w = p0 >> 6, s2 = p0 & 63;
-            FB.job_win[2ull * idx] = funnel128(fp[2 * w], fp[2 * w + 2], s2);
-            FB.job_win[2ull * idx + 1] = funnel128(fp[2 * w + 1], fp[2 * w + 3], s2);
-        }
-    }
-    return idx | (__ballot(fail) ? 0x80000000u : 0u);
 }
 
 // ---- k_loop: the error loop (py/tksm_badread.py:351-403), one LANE per read.
@@ -1810,8 +1730,7 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
     } else {
         identity = 1.0 - errors / frag_len;
     }
-    int m2 = m;
-    (void)join_job(FB, 0, r, 0, 0, frag, nb, 0, L, m2, lds_ncap, aux, out_seq, lo, hi, lane);
+    join_out(frag, nb, L, out_seq, lo, hi, lane);
     if (P.quirk_perfect) identity = 1.0;
     finish_read(B, P, O, r, P.quirk_perfect ? out_len : raw_len, out_len, identity, status, st_draws, change_count, st_aligns, L, m,
                 start_trim, end_trim, errors, target, lane);
