@@ -933,6 +933,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         if (getenv("TKSMSEQ_VERBOSE")) {
             uint32_t cc[16];
             HIPCHK(ctx, hipMemcpy(cc, ctx->f_counters.p, 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[tksmseq] this thread so far: %u device allocations, %.3f s in hipMalloc\n", alloc_calls(), alloc_seconds());
             fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
                     (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);
         }

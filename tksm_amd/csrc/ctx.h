@@ -2,6 +2,7 @@
 // mdf_ops.cpp).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <string>
@@ -23,6 +24,10 @@ using namespace tkh;
         }                                                                                         \
     } while (0)
 
+// (diagnostics, TKSMSEQ_VERBOSE: time this thread has spent in hipMalloc)
+inline double& alloc_seconds() { static thread_local double v = 0.0; return v; }
+inline unsigned& alloc_calls() { static thread_local unsigned v = 0; return v; }
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -37,7 +42,10 @@ struct DevBuf {
         size_t ncap = std::max(bytes > (64u << 20) ? bytes + bytes / 8 : bytes, owned ? cap + cap / 2 : cap);
         ncap = (ncap + 255) & ~(size_t)255;
         void* np = nullptr;
+        const auto t_alloc = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&np, ncap);
+        alloc_seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
+        alloc_calls()++;
         if (e != hipSuccess) return e;
         if (keep && p && cap) {
             e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);

@@ -15,11 +15,15 @@
 // usage errors (missing -i, neither -o nor --perfect) -- what the embedded interpreter returns.
 #include "sequencer_module.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -75,26 +79,42 @@ bool gzip_member(const uint8_t* d, size_t n, std::vector<uint8_t>& out) {
 }
 
 struct Writer {
-    FILE* f = nullptr; bool gz = false, fastq = false, wrote = false;
+    int fd = -1; bool gz = false, fastq = false, wrote = false;
+    bool positional = false;                             // a regular file: the workers write their batches at their offsets (pwrite)
     bool open(const std::string& path) {                 // get_output_file, py/sequence.py:291-300
         std::string p = path;
         if (p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0) { gz = true; p.resize(p.size() - 3); }
-        f = fopen(path.c_str(), "wb");
-        if (!f) return false;
+        fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) return false;
+        struct stat st;
+        positional = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
         auto ends = [&](const char* s) { size_t n = strlen(s); return p.size() >= n && p.compare(p.size() - n, n, s) == 0; };
         fastq = ends(".fastq") || ends(".fq");
         return true;
     }
-    bool write(const uint8_t* d, size_t n) {             // for .gz outputs the bytes are finished gzip members
+    bool write(const uint8_t* d, size_t n) {             // appends; for .gz outputs the bytes are finished gzip members
         wrote = wrote || n;
-        return fwrite(d, 1, n, f) == n;
+        while (n) {
+            const ssize_t w = ::write(fd, d, std::min<size_t>(n, (size_t)1 << 30));
+            if (w < 0) { if (errno == EINTR) continue; return false; }
+            d += w; n -= (size_t)w;
+        }
+        return true;
     }
-    bool close() {                                       // false: the last buffered bytes could not be written
-        if (!f) return true;
+    bool write_at(const uint8_t* d, size_t n, uint64_t off) const {
+        while (n) {
+            const ssize_t w = ::pwrite(fd, d, std::min<size_t>(n, (size_t)1 << 30), (off_t)off);
+            if (w < 0) { if (errno == EINTR) continue; return false; }
+            d += w; n -= (size_t)w; off += (uint64_t)w;
+        }
+        return true;
+    }
+    bool close() {                                       // false: the last bytes could not be written
+        if (fd < 0) return true;
         bool ok = true;
-        if (gz && !wrote) { std::vector<uint8_t> e; if (gzip_member(nullptr, 0, e)) ok = fwrite(e.data(), 1, e.size(), f) == e.size(); }   // a valid empty .gz
-        ok = fclose(f) == 0 && ok;
-        f = nullptr;
+        if (gz && !wrote) { std::vector<uint8_t> e; if (gzip_member(nullptr, 0, e)) ok = write(e.data(), e.size()); }   // a valid empty .gz
+        ok = ::close(fd) == 0 && ok;
+        fd = -1;
         return ok;
     }
 };
@@ -366,6 +386,9 @@ public:
             for (auto& W : workers) { std::lock_guard<std::mutex> wl(W->m); W->cv.notify_all(); }
         };
         uint64_t n_batches = 0; bool reader_done = false;                                          // guarded by done_m
+        // every open output is a regular file: positional writes from the workers, no writer thread
+        const bool positional = (a.badread.empty() || wb.positional) && (a.perfect.empty() || wp.positional);
+        uint64_t next_place = 0, place[2] = {0, 0};                                                // guarded by done_m
         // stage clocks (TKSMSEQ_VERBOSE): seconds spent parsing, running, copying, writing, reading
         const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr || log.level <= Logger::DEBUG;
         std::mutex clk_m; double clk[6] = {0, 0, 0, 0, 0, 0};
@@ -374,6 +397,7 @@ public:
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> l(clk_m); clk[k] += dt;
         };
+        const bool verbose2 = getenv("TKSMSEQ_VERBOSE") && atoi(getenv("TKSMSEQ_VERBOSE")) >= 2;
         const auto t_start = now();
         if (verbose) fprintf(stderr, "[sequence] device, reference and models ready after %.2f s\n", std::chrono::duration<double>(t_start - t_begin).count());
         uint64_t total_reads = 0;
@@ -401,6 +425,8 @@ public:
                     const auto t_run = now();
                     if (tksmseq_run(W.ctx, b, &p, &r)) { set_error(tksmseq_last_error(W.ctx)); return false; }
                     add_clk(1, t_run);
+                    if (verbose2) fprintf(stderr, "[sequence] batch %llu worker %d: run %.3f s (%llu reads) at %.3f s\n", (unsigned long long)c.seq, wi,
+                                          std::chrono::duration<double>(now() - t_run).count(), (unsigned long long)n, std::chrono::duration<double>(now() - t_start).count());
                     const auto t_wait = now();
                     if (!waited) {                                  // the previous batch of this worker has been written
                         std::unique_lock<std::mutex> l(W.m);
@@ -411,8 +437,11 @@ public:
                     if (failed) return false;
                     const auto t_copy = now();
                     if (!W.reserve(k, r.records_bytes)) { set_error("out of page-locked host memory"); return false; }
+                    const auto t_copy2 = now();
                     if (tksmseq_result_download(W.ctx, W.host[k], nullptr)) { set_error(tksmseq_last_error(W.ctx)); return false; }
                     add_clk(2, t_copy);
+                    if (verbose2) fprintf(stderr, "[sequence] batch %llu worker %d: host buffer %.3f s, copy %.3f s\n", (unsigned long long)c.seq, wi,
+                                          std::chrono::duration<double>(t_copy2 - t_copy).count(), std::chrono::duration<double>(now() - t_copy2).count());
                     fin.bytes[k] = r.records_bytes;
                     if ((k == 0 ? wb : wp).gz) {
                         // 16 MB pieces, compressed side by side (level 1), concatenated in order
@@ -439,6 +468,28 @@ public:
                 }
                 tksmseq_batch_free(W.ctx, b);
                 if (!ok) continue;
+                if (positional) {
+                    // regular files: the batch's place in each output is known as soon as every earlier batch has announced its
+                    // size; the worker writes its own buffers there (the page cache takes ~4 GB/s from one thread)
+                    uint64_t off[2];
+                    {
+                        std::unique_lock<std::mutex> l(done_m);
+                        done_cv.wait(l, [&] { return next_place == c.seq || failed.load(); });
+                        if (failed) continue;
+                        off[0] = place[0]; off[1] = place[1];
+                        place[0] += fin.bytes[0]; place[1] += fin.bytes[1];
+                        next_place++;
+                        total_reads += fin.n_reads;
+                    }
+                    done_cv.notify_all();
+                    const auto t_write = now();
+                    bool wok = true;
+                    if (fin.bytes[0]) { wok = wb.write_at(wb.gz ? W.packed[0].data() : W.host[0], fin.bytes[0], off[0]); }
+                    if (wok && fin.bytes[1]) { wok = wp.write_at(wp.gz ? W.packed[1].data() : W.host[1], fin.bytes[1], off[1]); }
+                    add_clk(3, t_write);
+                    if (!wok) set_error("write failed");
+                    continue;
+                }
                 { std::lock_guard<std::mutex> l(W.m); W.host_busy = true; }
                 { std::lock_guard<std::mutex> l(done_m); done[c.seq] = fin; }
                 done_cv.notify_all();
@@ -469,7 +520,8 @@ public:
         };
         std::vector<std::thread> threads;
         for (int w = 0; w < n_workers; w++) threads.emplace_back(work, w);
-        std::thread writer(write_all);
+        std::thread writer;
+        if (!positional) writer = std::thread(write_all);
 
         // reader: batches of whole molecules, numbered; the first read index of a batch is known before it is parsed
         std::vector<char> buf;
@@ -506,7 +558,8 @@ public:
         done_cv.notify_all();
         for (auto& t : threads) t.join();
         done_cv.notify_all();
-        writer.join();
+        if (writer.joinable()) writer.join();
+        if (positional && !failed) { wb.wrote = place[0] != 0; wp.wrote = place[1] != 0; }
         int status = failed ? 1 : 0;
         if (status) fprintf(stderr, "Error: %s\n", first_error.c_str());
         if (verbose)

@@ -16,7 +16,7 @@ with open(f"{d}/ref.fa", "w") as f:
 m = synthetic.make_molecules(rs, lens, n, 1000, 200)
 t = time.time(); text = synthetic.mdf_text(m, [f"chr{c+1}" for c in range(4)]); open(f"{d}/mols.mdf", "w").write(text)
 print(f"MDF text {len(text)/1e6:.0f} MB for {n} molecules (generated in {time.time()-t:.0f} s)", flush=True)
-env = dict(os.environ, TKSMSEQ_VERBOSE="1", TKSM_MODELS=os.path.join(os.getcwd(), "tksm_amd", "models"))
+env = dict(os.environ, TKSMSEQ_VERBOSE=os.environ.get("E2E_VERBOSE", "1"), TKSM_MODELS=os.path.join(os.getcwd(), "tksm_amd", "models"))
 ext = ".fastq.gz" if os.environ.get("E2E_GZ") else ".fastq"
 for args, name in ((["--perfect", f"{d}/p{ext}"], "perfect"), (["-o", f"{d}/b{ext}"], "badread+qual")):
     t = time.time()
