@@ -132,13 +132,15 @@ def _make_molecules(rs, ref, n, mean_len, literal=True):
 @pytest.mark.parametrize("mean_len,n,compute_q", [(300, 96, True), (1000, 64, True), (1000, 32, False), (2600, 24, True), (9000, 6, True)])
 def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n, compute_q, path):
     """whole records of the stochastic path, GPU vs oracle, same (seed, read index).  mean_len 2600 exercises
-    the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = k_err per length bucket +
-    k_aln with 8-byte predecessor columns and full-width redo (what large batches run; reads touching N / IUPAC bytes
-    still take the wave-wide kernel), "fast-hbm" = the same with k_err's long-read variant for every length, "fast-small" = the latency-bound variant small rounds switch to (one k_err launch,
-    full-width k_aln), "slow" = wave-wide kernel for all."""
+    the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = what the large rounds of large batches
+    run: k_loop (one lane per read) in every round, k_aln with 16 stored rows and its 32- / 64-row follow-up passes, k_err per length
+    bucket (reads touching N / IUPAC bytes still take the wave-wide kernel); "fast-hbm" = the same with k_err's long-read variant for
+    every length; "fast-small" = the latency-bound variants small rounds switch to (k_loopw: one wave per read; every alignment with
+    all 64 rows stored; one k_err launch); "slow" = wave-wide kernel for all."""
     monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
     if path in ("fast", "fast-hbm"):
         monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_TAIL_CUT", "0")
+        monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0")
     if path == "fast-hbm":          # the long-read variant of k_err (fragment state edited in HBM) for every length
         monkeypatch.setenv("TKSMSEQ_HBM_STATE_LEN", "0")
     s, ref, rs = _random_genome_seqr()
@@ -244,10 +246,12 @@ def test_full_size_properties_and_shard_invariance():
     rec1, off1 = s.run(b, seed=5).download()
     rec2, _ = s.run(b, seed=5).download()
     assert rec1 == rec2                                                   # deterministic
-    # the same batch with every alignment at full width and no tail cut: the 8-byte predecessor columns + redo,
-    # the launch grouping and the tail hand-over to the wave-wide kernel do not change a byte
+    # the same batch with every alignment at full width, the error loop one lane per read in every round and no tail cut: the
+    # 16-row predecessor codes + follow-up passes, k_loopw in the late rounds, the launch grouping and the tail hand-over to the
+    # wave-wide kernel do not change a byte
     with pytest.MonkeyPatch.context() as mp:
         mp.setenv("TKSMSEQ_SMALL_ALN", str(1 << 30)); mp.setenv("TKSMSEQ_SMALL_ROUND", str(1 << 30)); mp.setenv("TKSMSEQ_TAIL_CUT", "0")
+        mp.setenv("TKSMSEQ_WAVE_LOOP", "0")
         s3 = Sequencer(0)
     setup(s3)
     b3 = s3.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
@@ -499,7 +503,7 @@ def test_tail_noise_bit_exact_vs_oracle(oracle_models, po, monkeypatch, path):
     same batch rebuilds the batch's lengths and order; symbols outside ACGT in `bases` take the wave-wide kernel."""
     monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
     if path == "fast":
-        monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0")
+        monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0")
     import json
     s, ref, rs = _random_genome_seqr()
     s.set_identity(84.0, 99.0, 5.5)
@@ -615,10 +619,13 @@ def test_cli_devices_list_threads_and_error_path(tmp_path, po, oracle_models):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n", [("pcr", 2500), ("scrna", 3000)])
-def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_models, kind, n):
+def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_models, monkeypatch, kind, n):
     """The bench generator's other workloads through the HIP path against the oracle, record for record (Badread with q-scores
     and --perfect): `pcr` = substitution-heavy molecules as 20 PCR cycles leave them (BASELINE config 5: ~5 substitutions per kb,
-    both strands, interval ends), `scrna` = barcode + UMI + polyA literal segments (config 3)."""
+    both strands, interval ends), `scrna` = barcode + UMI + polyA literal segments (config 3).  Run as the large rounds of a large
+    batch are (k_loop in every round; 16 stored rows per alignment: 5 % of the polyA-tailed jobs go on to the 32-row pass, some of
+    those to the 64-row one)."""
+    monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0")
     from tksm_amd import synthetic
     rs = np.random.RandomState(17)
     lens = [200_000, 150_000]
