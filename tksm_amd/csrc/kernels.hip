@@ -1201,7 +1201,14 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     int cc25 = change_count % 25;
     enum { RUN = 0, NEED_ALN = 1, DONE = 2, IDLE = 3 };
     int st = act ? RUN : IDLE;
+#ifdef TKSM_ABLATE
+    if (P.ablate == 33) st = IDLE;                              // timing experiment: prologue only
+    int nbatch = 0;
+#endif
     while (__ballot(st == RUN) != 0ull) {
+#ifdef TKSM_ABLATE
+        if (P.ablate >= 34 && P.ablate <= 36 && ++nbatch > (P.ablate == 34 ? 10 : P.ablate == 35 ? 20 : 40)) break;   // ... a fixed number of batches
+#endif
         if (st != RUN) continue;
         // ---- four draws: positions and k-mers (first base in the high bits of the table index)
         int di[LOOP_B], kidx[LOOP_B];
@@ -1214,6 +1221,13 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
 #pragma unroll
         for (int b = 0; b < LOOP_B; b++) {
             const int w = di[b] >> 4, o = di[b] & 15;
+#ifdef TKSM_ABLATE
+            if (P.ablate == 31 || P.ablate == 32) {             // timing experiment: every k-mer from the words in LDS (wrong results)
+                const int w2 = min(w, Wl - 2);
+                kidx[b] = (int)((uint32_t)(mk64(lf[w2 * 64 + lane], lf[(w2 + 1) * 64 + lane]) >> (64 - 2 * o - 2 * k)) & kmask);
+                continue;
+            }
+#endif
             const uint32_t hi = w < Wl ? lf[w * 64 + lane] : f2[w], lo = w + 1 < Wl ? lf[(w + 1) * 64 + lane] : f2[w + 1];
             kidx[b] = (int)((uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask);
         }
@@ -1226,6 +1240,12 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
         int nab[LOOP_B];
 #pragma unroll
         for (int b = 0; b < LOOP_B; b++) { seg[b] = EM.pseg[kidx[b]]; nab[b] = EM.max_alts; }
+#ifdef TKSM_ABLATE
+        if (P.ablate == 30 || P.ablate == 32) {                 // timing experiment: no first-level gather (wrong results)
+#pragma unroll
+            for (int b = 0; b < LOOP_B; b++) seg[b] = make_uint4(3478923509u + (uint32_t)(kidx[b] & 1023), 3800000000u, 4000000000u, 4200000000u);
+        }
+#endif
         if (!EM.uniform_nalts) {
 #pragma unroll
             for (int b = 0; b < LOOP_B; b++) nab[b] = (int)EM.nalts[kidx[b]];
