@@ -7,16 +7,16 @@ synthetic molecules with inputs resident in HBM.  Steps are issued the way a str
 consecutive batches fill each other's gaps (the instruction-bound error loop next to the memory-bound alignment, the
 latency-bound last rounds of one batch underneath the bulk of the next).  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
 Badread error+qual model" -- synthetic 24 x 128 Mb genome (GRCh38 is not available offline), nanopore2020 error +
-q-score models, identity 84,99,5.5, FASTQ with computed qualities; processed as 9 steps of --batch = 1,310,720 molecules
-(11.8 M molecules, the default run; sized so that rank 0 of an 8-GPU run also holds the gathered record streams:
-3 x 59 GB of contexts + 53 GB of gather and interleave buffers).
+q-score models, identity 84,99,5.5, FASTQ with computed qualities; processed as 9 steps of --batch = 1,703,936 molecules
+(15.3 M molecules, the default run; 156 GiB of HBM in use; sized so that rank 0 of an 8-GPU run also holds the gathered record
+streams: 3 x 50 GB of contexts + 14 GB of second output buffers + 74 GB of gather and interleave buffers).
 
 N>1 (torchrun, one rank per GPU): molecules are sharded round-robin (global read g -> rank g mod P, counter-based
 RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RCCL gather of the per-rank record
 streams to rank 0 and the device-side interleave into global read order (the FASTQ-order exchange step).
 
 Prints ONE JSON line on rank 0 (contract in the round instructions), including
-  `roofline`      dominant kernel = the largest of k_loop (error loop, one lane per read), k_job (alignment windows packed, one lane
+  `roofline`      dominant kernel = the largest of k_loop (error loop, one lane per read; with k_loopw, its wave-per-read form for the late rounds), k_job (alignment windows packed, one lane
                   per job) and k_aln (bit-parallel alignments, one lane per alignment) by EXCLUSIVE time: after the timed steps one
                   more step runs on one context alone (nothing else on the GPU) with HIP events around every launch on its stream;
                   achieved = algorithmic bytes of a step / that kernel's summed launch durations in that step.  The overlapped

@@ -1,3 +1,4 @@
+"""diagnostic: hipMalloc / hipHostMalloc latency on an idle device"""
 import torch, time, ctypes
 torch.cuda.init()
 hip = ctypes.CDLL("libamdhip64.so")
