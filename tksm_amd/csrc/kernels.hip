@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
 // candidate positions and a 1000-slot window, so staging the whole fragment costs more than it saves, and its LDS
 // footprint would leave a handful of waves per CU; only the aux area is in LDS.
 template <bool STATE_IN_HBM>
-__global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
+__global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
                                               FastBuffers FB, const uint32_t* __restrict__ order, uint32_t begin, uint32_t count,
                                               int lds_lcap, int lds_ncap, int from_jobs, uint32_t c0, uint32_t c1) {
     // one launch per length bucket: reads order[begin .. begin+count) share the LDS geometry (lds_lcap, lds_ncap),
@@ -1675,6 +1675,9 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
         const int margins = (QM.kmer_size - 1) / 2;
         const uint32_t hmask = (uint32_t)QM.n_slots - 1u;
         for (int i2 = lo + lane; i2 < hi; i2 += 64) {
+#ifdef TKSM_ABLATE
+            if (P.ablate == 40) { out_qual[i2 - lo] = 40; continue; }      // timing experiment: no lookups at all
+#endif
             const int d = max(0, max(margins - i2, i2 + margins - (m - 1)));     // window shrunk symmetrically at the ends
             int row = -1; uint32_t roff = 0, rcnt = 0;
             auto probe = [&](uint64_t key) {
@@ -1716,6 +1719,10 @@ __global__ __launch_bounds__(256, 6) void k_err(BatchView B, ErrModelView EM, Qs
                     const bool tryit = pend && h <= hmax;
                     if (__ballot(tryit) == 0ull) continue;
                     if (tryit && ln[h] <= 29) { probe(K[h] | ((uint64_t)ln[h] << 58)); pend = row < 0; }
+#ifdef TKSM_ABLATE
+                    if (P.ablate == 44) { if (row < 0) row = (int)(K[h] & 1023u); pend = false; }     // timing experiment: one level only
+                    if (P.ablate == 45 && h == 3) { if (row < 0) row = (int)(K[h] & 1023u); pend = false; }   // ... two levels
+#endif
                 }
             } else {
                 int s0 = i2 - margins + d, e0 = i2 + margins - d;

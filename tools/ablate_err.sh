@@ -1,0 +1,15 @@
+#!/bin/bash
+# k_err (last visit) launch durations with parts of its q-score loop switched off (diagnostic build: make ablate)
+set -e
+R=$PWD
+export TKSMSEQ_LIB=$R/tksm_amd/libtksmseq_prof.so
+cd /tmp && export TMPDIR=/tmp
+for a in "$@"; do
+  export TKSMSEQ_ABLATE=$a
+  timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ab$a -- python $R/tools/quick_stage_times.py 1310720 > $R/gpurun_out/ab$a.log 2>&1 || true
+  python -c "
+import csv,glob
+for r in csv.DictReader(open(glob.glob('$R/gpurun_out/ab$a/*/*kernel_stats.csv')[0])):
+    if 'k_err' in r['Name']: print('ablate $a: k_err', r['Calls'], 'launches', round(int(r['TotalDurationNs'])/3e6, 2), 'ms per step')"
+  rm -rf $R/gpurun_out/ab$a
+done
