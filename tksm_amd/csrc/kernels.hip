@@ -1682,6 +1682,9 @@ __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, Qs
             int row = -1; uint32_t roff = 0, rcnt = 0;
             auto probe = [&](uint64_t key) {
                 uint32_t sl = (uint32_t)qs_hash(key) & hmask;
+#ifdef TKSM_ABLATE
+                if (P.ablate == 41) { row = (int)(sl & 1023u); roff = 0u; rcnt = 1u; return; }    // timing experiment: no table probe
+#endif
                 for (;;) {
                     const uint4 e = QM.ent[sl];                   // {key lo, key hi, row offset, row count}
                     const uint64_t kk = ((uint64_t)e.y << 32) | e.x;
@@ -1743,6 +1746,14 @@ __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, Qs
                 }
             }
             uint8_t q = 0;
+#ifdef TKSM_ABLATE
+            if (P.ablate == 42) { out_qual[i2 - lo] = (uint8_t)(33 + (row & 31)); continue; }   // timing experiment: no draw, no row lookup
+            if (P.ablate == 43 && row >= 0) {                                                     // ... a row lookup without the generator
+                const uint32_t w = (uint32_t)i2 * 2654435761u;
+                const uint32_t a2 = QM.guide[(size_t)row * 64 + (w >> 26)];
+                out_qual[i2 - lo] = (uint8_t)(33 + QM.pairs[roff + a2].y); continue;
+            }
+#endif
             if (row >= 0) {
                 const uint32_t w = philox(P.seed, g, ST_QUAL, (uint32_t)i2).x;
                 // first a with w < cdf[a], else the last entry; the per-row guide table gives the first candidate
