@@ -133,7 +133,7 @@ def _make_molecules(rs, ref, n, mean_len, literal=True):
 def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n, compute_q, path):
     """whole records of the stochastic path, GPU vs oracle, same (seed, read index).  mean_len 2600 exercises
     the random 1000-base window re-estimation (py/tksm_badread.py:417-432).  path: "fast" = what the large rounds of large batches
-    run: k_loop (one lane per read) in every round, k_aln with 16 stored rows and its 32- / 64-row follow-up passes, k_err per length
+    run: k_loop (one lane per read) in every round, k_aln with 16 stored rows and its 64-row follow-up pass, k_err per length
     bucket (reads touching N / IUPAC bytes still take the wave-wide kernel); "fast-hbm" = the same with k_err's long-read variant for
     every length; "fast-small" = the latency-bound variants small rounds switch to (k_loopw: one wave per read; every alignment with
     all 64 rows stored; one k_err launch); "slow" = wave-wide kernel for all."""
@@ -623,8 +623,7 @@ def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_mode
     """The bench generator's other workloads through the HIP path against the oracle, record for record (Badread with q-scores
     and --perfect): `pcr` = substitution-heavy molecules as 20 PCR cycles leave them (BASELINE config 5: ~5 substitutions per kb,
     both strands, interval ends), `scrna` = barcode + UMI + polyA literal segments (config 3).  Run as the large rounds of a large
-    batch are (k_loop in every round; 16 stored rows per alignment: 5 % of the polyA-tailed jobs go on to the 32-row pass, some of
-    those to the 64-row one)."""
+    batch are (k_loop in every round; 16 stored rows per alignment: 5 % of the polyA-tailed jobs go on to the 64-row pass)."""
     monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0")
     from tksm_amd import synthetic
     rs = np.random.RandomState(17)

@@ -694,12 +694,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         }
         HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
         HIPCHK(ctx, ctx->f_geo.ensure((size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo) + 64));
-        // predecessor codes: pass 1's lines, then the pool of pass 2 (32 stored rows: 8 columns per line) for an eighth of the job
-        // slots at most (its waves loop over their list), 2 GB at most
-        FB.pool_tg = (((uint32_t)ncap + 31) & ~31u) / 8 + 1;
-        FB.pool_jobs = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(jcap / 8, (2ull << 30) / ((uint64_t)FB.pool_tg * 64)) & ~63ull);
-        HIPCHK(ctx, ctx->f_trace.ensure((tot_trace + (uint64_t)FB.pool_jobs * FB.pool_tg) * 64 + 64));
-        HIPCHK(ctx, ctx->f_redo.ensure(jcap * 8 + 64));
+        HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 64 + 64));                     // predecessor codes of the first alignment pass
+        HIPCHK(ctx, ctx->f_redo.ensure(jcap * 4 + 64));
         // pool of full-width rows: as many as a round can ask for, at most 4 GB (homopolymer-rich batches need many)
         FB.full_tg = (((uint32_t)ncap + 31) & ~31u) / 4 + 1;
         FB.full_rows = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(jcap, (4ull << 30) / ((uint64_t)FB.full_tg * 64)) & ~63ull);
@@ -708,8 +704,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.st_frag2 = ctx->f_frag2.as<uint32_t>();
-        FB.trace = ctx->f_trace.p; FB.trace_pool = ctx->f_trace.as<uint8_t>() + tot_trace * 64;
-        FB.redo_list = ctx->f_redo.as<uint32_t>(); FB.redo_list2 = FB.redo_list + jcap;
+        FB.trace = ctx->f_trace.p;
+        FB.redo_list = ctx->f_redo.as<uint32_t>();
         FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         HIPCHK(ctx, ctx->f_defer.ensure(n * 8 + 64));
@@ -916,7 +912,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
             HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 3, 0, 4, s));   // rows of the full-width pool
-            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 10, 0, 8, s));  // jobs handed to the second and third alignment pass
+            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 10, 0, 4, s));  // jobs handed to the second alignment pass
             HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= std::min(ctx->small_aln, FB.full_rows), qround ? 1 : 0, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);

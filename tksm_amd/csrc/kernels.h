@@ -157,13 +157,10 @@ struct FastBuffers {
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
     void* trace;                      // predecessor codes of the first alignment pass (16 band rows, 4 bytes per column): 64-byte lines of 16
                                       // columns, per range [wave][line][lane] (RangeGeo::trace_off / tstride)
-    uint8_t* trace_pool;              // ... of the second pass (32 rows, 8 columns per line): [wave of the launch][pool_tg lines][lane]
-    uint32_t pool_jobs, pool_tg;      // jobs the pool holds (multiple of 64), lines per job
-    uint32_t* redo_list;              // jobs whose path left the stored rows of pass 1 (counters[10] of them) ...
-    uint32_t* redo_list2;             // ... and of pass 2 (counters[11]): full-width pass
+    uint32_t* redo_list;              // jobs whose path left the stored rows of pass 1 (counters[10] of them): 64-row pass
     void* trace_full;                 // pool of the passes that store all 64 rows (16 bytes per column, 4 columns per line): [wave][full_tg lines][lane]; counters[3] allocates
     uint32_t full_rows, full_tg;      // jobs the full-width pool holds (multiple of 64), lines per job (4 columns each)
-    uint32_t* counters;               // [2] reads on the slow list, [3] rows taken from the full-width pool, [4..9] diagnostics, [10] / [11] jobs on redo_list / redo_list2
+    uint32_t* counters;               // [2] reads on the slow list, [3] rows taken from the full-width pool, [4..9] diagnostics, [10] jobs on redo_list
     uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
     uint32_t rs, n_ranges;
     // previous round's job set (double buffered): its jobs are the list of reads that are still running

@@ -1808,7 +1808,7 @@ struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
 
 // ---- the common case: the predecessor codes of a few band rows around the generative row per column -- the path practically
 // never leaves them: 16 rows (4 bytes per column: pass 1; 1 % of bulk and 5 % of polyA-tailed jobs leave them and are redone
-// with 32 rows (8 bytes, pass 2, from a list; 0.02 % / 0.14 % leave those and go to the full-width pass).  The kernel is bound by
+// with all 64 rows stored, 16 bytes per column: pass 2, from a list; ROWS 64, the same code).  The kernel is bound by
 // HBM traffic first (records 2 B per column in, codes 4 B out and 4 + 2 B in again for the walk) and vector instructions second
 // (~72 per column forward, ~24 in the walk), so:
 //  * everything a lane moves is a whole 64-byte line of its own -- 4 block records (32 columns), 16 columns of codes -- and the lines
@@ -1827,8 +1827,9 @@ struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
 // rule); tg groups per job, the last one spare.
 template <int MODE, int ROWS>
 DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, int ablate) {
-    constexpr int NC = ROWS == 16 ? 16 : (ROWS == 32 ? 8 : 4);    // columns per line of codes
-    constexpr int ST = ROWS == 16 ? 23 : (ROWS == 32 ? 12 : 0);   // first stored band row once the window moves
+    static_assert(ROWS == 16 || ROWS == 64, "16 stored rows, or all of them");
+    constexpr int NC = ROWS == 16 ? 16 : 4;                       // columns per line of codes
+    constexpr int ST = ROWS == 16 ? 23 : 0;                       // first stored band row once the window moves
     constexpr int RAMP0 = 31 - ST;
     const bool act = J.act;
     const int n = J.n, m = act ? J.m : 0;
@@ -1840,7 +1841,7 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, 
     const uint4* rcl = J.jcl;
     const size_t spare = (size_t)(tg - 1) * ls;
     uint4 rn0 = rcl[0], rn1 = rcl[1], rn2 = rcl[2], rn3 = rcl[3];
-    uint32_t tw[16];                                              // codes on their way out (16 rows: half a line, else a line)
+    uint32_t tw[16];                                              // codes on their way out (16 rows: half a line; all rows: a line)
     auto put_line = [&](int q, int half) {                        // half: -1 whole line, 0 / 1 its first / second 32 bytes
 #ifdef TKSM_ABLATE
         if (ablate == 12 || ablate == 14) { if (tw[0] == 0x1234567u) trl[spare] = make_uint4(tw[1], tw[2], tw[3], tw[4]); return; }
@@ -1909,12 +1910,10 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, 
             } else {
                 const uint32_t st = (uint32_t)(min(max(cb + x, RAMP0), 31) - RAMP0);
                 const uint32_t s0 = alignbit(hi32(w0), lo32(w0), st), s1 = alignbit(hi32(w1), lo32(w1), st);
-                if constexpr (ROWS == 16) tw[x] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);      // w1 rows in the high half
-                else { tw[2 * x] = s0; tw[2 * x + 1] = s1; }
+                tw[x] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);                                // w1 rows in the high half
             }
         }
         if constexpr (ROWS == 16) put_line(cb >> 4, bq & 1);
-        if constexpr (ROWS == 32) put_line(cb >> 3, -1);
     };
     for (int c0 = 0; c0 < mmax; c0 += 32) {
         // every record is requested again as soon as its block is done: 24 columns ahead of its use (a row has 8 spare records)
@@ -2011,7 +2010,6 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, 
 #pragma unroll
             for (int c = NC - 1; c >= 0; c--) {
                 if constexpr (ROWS == 16) walk_col(cq + c, ramp, w[c], w[c] >> 16, c >= 8 ? s1 : s0, c >= 8 ? pp1 : pp0, c >= 8 ? touched1 : touched0);
-                else if constexpr (ROWS == 32) walk_col(cq + c, ramp, w[2 * c], w[2 * c + 1], s0, pp0, touched0);
                 else walk_col(cq + c, ramp, mk64(w[4 * c + 1], w[4 * c]), mk64(w[4 * c + 3], w[4 * c + 2]), s0, ppk, tk);
             }
         };
@@ -2269,18 +2267,17 @@ DEV void list_append(uint32_t* list, uint32_t* counter, bool want, uint32_t job,
 }
 
 // Alignment passes of a round (launch_aln): pass 1 = every job with 16 stored rows; pass 2 = the jobs whose path left them
-// (counters[10] of them in redo_list), 32 stored rows, lines in a pool behind pass 1's; pass 3 = what is left (counters[11] in
-// redo_list2), all 64 rows, lines in the full-width pool.  Passes 2 and 3 loop over their list with a fixed grid, each wave on its
-// own pool lines.  Rounds with few jobs are bound by the latency of one lane's pass: all their jobs go straight to the 64-row
-// version (ROWS 64, LIST false; traffic is irrelevant; counters[3] allocates pool lines per wave).
+// (counters[10] of them in redo_list) with all 64 rows, lines in the full-width pool: a fixed grid whose waves loop over the list,
+// each on its own pool lines.  (A 32-row pass in between was measured: it takes 98 % of pass 1's misses, and costs a launch per
+// round that the direct way does not -- one context 3 % slower, three contexts no difference.)  Rounds with few jobs are bound by
+// the latency of one lane's pass: all their jobs go straight to the 64-row version (ROWS 64, LIST false; traffic is irrelevant;
+// counters[3] allocates pool lines per wave).
 #ifndef ALN_WAVES
 #define ALN_WAVES 4
 #endif
 template <int MODE, int ROWS, bool LIST>
 __global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
     const int lane = threadIdx.x;
-    uint32_t* next_list = ROWS == 16 ? FB.redo_list : FB.redo_list2;
-    uint32_t* next_cnt = FB.counters + (ROWS == 16 ? 10 : 11);
     if (!LIST) {
         const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
         // job ids of a range start at its wave-aligned base (this round's bases are the packed counts of the previous round)
@@ -2319,14 +2316,15 @@ __global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers 
 #endif
         AlnRes R = aln_fast<MODE, ROWS>(J, wave_max(act ? J.m : 0), trl, tg, ls, P.ablate);
         if (norow) { R.fail = true; R.needfull = false; }
-        if (ROWS != 64) list_append(next_list, next_cnt, act && R.needfull, job, lane);
+        if (ROWS != 64) list_append(FB.redo_list, FB.counters + 10, act && R.needfull, job, lane);
         if ((act || norow) && !R.needfull) store_result(FB, r, R);
     } else {
-        const uint32_t n_list = FB.counters[ROWS == 32 ? 10 : 11];
-        if (ROWS == 64 && lane == 0 && blockIdx.x == 0 && n_list) { atomicAdd(&FB.counters[8], n_list); atomicAdd(&FB.counters[9], (n_list + 63u) / 64u); }   // diagnostics
-        const uint32_t* list = ROWS == 32 ? FB.redo_list : FB.redo_list2;
-        const int tg = (int)(ROWS == 32 ? FB.pool_tg : FB.full_tg);
-        uint4* trl = reinterpret_cast<uint4*>(ROWS == 32 ? FB.trace_pool : reinterpret_cast<uint8_t*>(FB.trace_full)) + ((size_t)blockIdx.x * tg * 64 + (uint32_t)lane) * 4;
+        static_assert(!LIST || ROWS == 64, "the list holds the jobs of the 64-row pass");
+        const uint32_t n_list = FB.counters[10];
+        if (lane == 0 && blockIdx.x == 0 && n_list) { atomicAdd(&FB.counters[8], n_list); atomicAdd(&FB.counters[9], (n_list + 63u) / 64u); }   // diagnostics
+        const uint32_t* list = FB.redo_list;
+        const int tg = (int)FB.full_tg;
+        uint4* trl = reinterpret_cast<uint4*>(FB.trace_full) + ((size_t)blockIdx.x * tg * 64 + (uint32_t)lane) * 4;
         for (uint32_t base = blockIdx.x * 64u; base < n_list; base += gridDim.x * 64u) {     // wave-uniform: every wave ends
             const uint32_t idx = base + (uint32_t)lane;
             const bool act = idx < n_list;
@@ -2336,8 +2334,7 @@ __global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers 
             uint32_t r;
             load_job(FB, job, rng, act, J, r);
             const AlnRes R = aln_fast<MODE, ROWS>(J, wave_max(act ? J.m : 0), trl, tg, 256u, P.ablate);
-            if (ROWS != 64) list_append(next_list, next_cnt, act && R.needfull, job, lane);
-            if (act && !R.needfull) store_result(FB, r, R);
+            if (act) store_result(FB, r, R);
         }
     }
 }
@@ -2847,17 +2844,14 @@ hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs
         else hipLaunchKernelGGL((k_aln<0, 64, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
         return hipGetLastError();
     }
-    // pass 2 and 3 grids: an eighth / a sixty-fourth of the jobs per sweep (their waves loop over what the lists hold), within their pools
-    const uint32_t g2 = std::max<uint32_t>(1u, std::min<uint32_t>((waves + 7) / 8, fb.pool_jobs / 64));
-    const uint32_t g3 = std::max<uint32_t>(1u, std::min<uint32_t>((waves + 63) / 64, std::max<uint32_t>(1u, fb.full_rows / 64)));
+    // pass 2's grid: an eighth of the jobs per sweep (its waves loop over what the list holds), within the pool
+    const uint32_t g2 = std::max<uint32_t>(1u, std::min<uint32_t>((waves + 7) / 8, std::max<uint32_t>(1u, fb.full_rows / 64)));
     if (mode) {
         hipLaunchKernelGGL((k_aln<1, 16, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
-        hipLaunchKernelGGL((k_aln<1, 32, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
-        hipLaunchKernelGGL((k_aln<1, 64, true>), dim3(g3), dim3(64), 0, s, p, fb, n_jobs);
+        hipLaunchKernelGGL((k_aln<1, 64, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
     } else {
         hipLaunchKernelGGL((k_aln<0, 16, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
-        hipLaunchKernelGGL((k_aln<0, 32, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
-        hipLaunchKernelGGL((k_aln<0, 64, true>), dim3(g3), dim3(64), 0, s, p, fb, n_jobs);
+        hipLaunchKernelGGL((k_aln<0, 64, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
     }
     return hipGetLastError();
 }
