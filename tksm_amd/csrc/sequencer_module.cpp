@@ -176,6 +176,19 @@ struct ChunkQueue {                                       // bounded, closed by 
     void close() { std::lock_guard<std::mutex> l(m); closed = true; cv_get.notify_all(); cv_put.notify_all(); }
 };
 
+// a parsed batch on its way from a parser thread to a worker of the same device group
+struct Parsed { uint64_t seq = 0, first_read = 0, n_reads = 0; tksmseq_batch* b = nullptr; };
+struct ParsedQueue {
+    std::mutex m; std::condition_variable cv_put, cv_get; std::deque<Parsed> q; size_t cap = 2; bool closed = false;
+    // a group's parsers hand their batches over in the order in which they took the chunks (a worker that ran a later batch first
+    // would wait for the earlier one's place in the output while that one waits for a worker)
+    std::mutex take_m; uint64_t taken = 0;
+    std::mutex order_m; std::condition_variable order_cv; uint64_t handed = 0;
+    bool push(const Parsed& c) { std::unique_lock<std::mutex> l(m); cv_put.wait(l, [&] { return q.size() < cap || closed; }); if (closed) return false; q.push_back(c); cv_get.notify_one(); return true; }
+    bool pop(Parsed& c) { std::unique_lock<std::mutex> l(m); cv_get.wait(l, [&] { return !q.empty() || closed; }); if (q.empty()) return false; c = q.front(); q.pop_front(); cv_put.notify_one(); return true; }
+    void close() { std::lock_guard<std::mutex> l(m); closed = true; cv_get.notify_all(); cv_put.notify_all(); }       // (what is queued is still handed out)
+};
+
 struct Worker {                                           // one batch in flight: context + page-locked record buffers
     tksmseq_ctx* ctx = nullptr;
     uint8_t* host[2] = {nullptr, nullptr}; uint64_t host_cap[2] = {0, 0};
@@ -332,8 +345,10 @@ public:
         const int n_workers = n_groups * per_group;
         std::vector<std::unique_ptr<Worker>> workers;
         for (int w = 0; w < n_workers; w++) workers.emplace_back(new Worker());
+        std::vector<tksmseq_ctx*> pctx;                                     // the parser threads' contexts (clones)
         auto destroy_all = [&]() {
             // clones before the contexts they borrow from
+            for (auto& c : pctx) if (c) { tksmseq_destroy(c); c = nullptr; }
             for (int g = 0; g < n_groups; g++) for (int j = per_group - 1; j >= 0; j--) { tksmseq_ctx*& c = workers[(size_t)g * per_group + j]->ctx; if (c) { tksmseq_destroy(c); c = nullptr; } }
         };
         {
@@ -367,12 +382,28 @@ public:
             for (auto& t : gt) t.join();
             for (auto& e : gerr) if (!e.empty()) { destroy_all(); return die(e); }
         }
-        log.log(Logger::INFO, "%d device group(s) x %d contexts in flight, %d host thread(s) per batch for MDF parsing", n_groups, per_group, a.threads);
+        // MDF text is parsed (and its tables uploaded) ahead of the workers, by two parser threads per device group with contexts of
+        // their own, so that a worker's cycle is run + copy + write only
+        const int parsers_per_group = 2;
+        pctx.assign((size_t)n_groups * parsers_per_group, nullptr);
+        for (int g = 0; g < n_groups; g++)
+            for (int j = 0; j < parsers_per_group; j++) {
+                if (tksmseq_clone(workers[(size_t)g * per_group]->ctx, &pctx[(size_t)g * parsers_per_group + j])) {
+                    const std::string e = std::string("Error: parser context: ") + tksmseq_last_error(workers[(size_t)g * per_group]->ctx);
+                    destroy_all();
+                    return die(e);
+                }
+                tksmseq_set_host_threads(pctx[(size_t)g * parsers_per_group + j], a.threads);
+            }
+        log.log(Logger::INFO, "%d device group(s) x %d contexts in flight, %d parser(s) per group with %d host thread(s) each", n_groups, per_group,
+                parsers_per_group, a.threads);
 
         FILE* in = fopen(a.input.c_str(), "rb");
         if (!in) { destroy_all(); return die("Error: cannot open " + a.input); }
         ChunkQueue queue;
         queue.cap = (size_t)n_workers;
+        std::vector<std::unique_ptr<ParsedQueue>> pq;
+        for (int g = 0; g < n_groups; g++) { pq.emplace_back(new ParsedQueue()); pq.back()->cap = (size_t)per_group; }
         std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Finished> done;   // by batch number
         std::atomic<bool> failed{false};
         std::mutex err_m; std::string first_error;
@@ -380,6 +411,7 @@ public:
             std::lock_guard<std::mutex> l(err_m);
             if (!failed.exchange(true)) first_error = msg;
             queue.close();
+            for (auto& q2 : pq) q2->close();
             done_cv.notify_all();
             // a worker may be waiting for the writer to release its host buffers: nobody will (the writer stops at the
             // first error), so wake it -- its wait also checks `failed`
@@ -402,15 +434,34 @@ public:
         if (verbose) fprintf(stderr, "[sequence] device, reference and models ready after %.2f s\n", std::chrono::duration<double>(t_start - t_begin).count());
         uint64_t total_reads = 0;
 
+        auto parse_ahead = [&](int pi) {
+            tksmseq_ctx* pc = pctx[(size_t)pi];
+            ParsedQueue& out = *pq[(size_t)(pi / parsers_per_group)];
+            for (;;) {
+                Chunk c;
+                uint64_t ticket;
+                { std::lock_guard<std::mutex> l(out.take_m); if (!queue.pop(c)) break; ticket = out.taken++; }
+                Parsed pr; pr.seq = c.seq; pr.first_read = c.first_read; pr.n_reads = c.n_reads;
+                bool ok = !failed;
+                if (ok) {
+                    const auto t_parse = now();
+                    if (tksmseq_batch_from_mdf_text(pc, c.text.data(), c.text.size(), &pr.b)) { set_error(tksmseq_last_error(pc)); ok = false; }
+                    add_clk(0, t_parse);
+                }
+                std::unique_lock<std::mutex> l(out.order_m);
+                out.order_cv.wait(l, [&] { return out.handed == ticket; });
+                if (ok && !out.push(pr)) tksmseq_batch_free(pc, pr.b);     // (closed after an error)
+                out.handed++;
+                out.order_cv.notify_all();
+            }
+        };
         auto work = [&](int wi) {
             Worker& W = *workers[wi];
-            Chunk c;
-            while (queue.pop(c)) {
-                if (failed) continue;
-                tksmseq_batch* b = nullptr;
-                const auto t_parse = now();
-                if (tksmseq_batch_from_mdf_text(W.ctx, c.text.data(), c.text.size(), &b)) { set_error(tksmseq_last_error(W.ctx)); continue; }
-                add_clk(0, t_parse);
+            ParsedQueue& in_q = *pq[(size_t)(wi / per_group)];
+            Parsed c;
+            while (in_q.pop(c)) {
+                tksmseq_batch* b = c.b;
+                if (failed) { tksmseq_batch_free(W.ctx, b); continue; }
                 uint64_t n = 0;
                 tksmseq_batch_info(b, &n, nullptr, nullptr);
                 Finished fin; fin.worker = wi; fin.n_reads = n;
@@ -518,8 +569,9 @@ public:
                 next++;
             }
         };
-        std::vector<std::thread> threads;
+        std::vector<std::thread> threads, parsers;
         for (int w = 0; w < n_workers; w++) threads.emplace_back(work, w);
+        for (int pi = 0; pi < n_groups * parsers_per_group; pi++) parsers.emplace_back(parse_ahead, pi);
         std::thread writer;
         if (!positional) writer = std::thread(write_all);
 
@@ -556,6 +608,8 @@ public:
         { std::lock_guard<std::mutex> l(done_m); n_batches = seq; reader_done = true; }
         queue.close();
         done_cv.notify_all();
+        for (auto& t : parsers) t.join();
+        for (auto& q2 : pq) q2->close();                                                           // (the workers take what is still queued)
         for (auto& t : threads) t.join();
         done_cv.notify_all();
         if (writer.joinable()) writer.join();
