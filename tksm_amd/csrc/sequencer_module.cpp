@@ -7,10 +7,12 @@
 //   get_output_file                 py/sequence.py:291-300   (extension decides FASTQ/FASTA; .gz ok)
 //   utility flags                   src/module.h:75-104      (-s/--seed default 42, --verbosity, --log-file)
 //   worker pool                     py/sequence.py:354-366   (multiprocessing.Pool + imap_unordered over molecules)
-// Streaming: the reader cuts the MDF text into batches of whole molecules and numbers their reads; --in-flight worker
-// threads (one context each, sharing the packed reference and the model tables) parse, run and download a batch each,
-// so that parsing, the device work of consecutive batches and the copies overlap; one writer puts the record
-// streams back into MDF order.
+// Streaming: the reader cuts the MDF text into batches of whole molecules and numbers their reads; two parser threads per
+// device group (contexts of their own) turn the text into device batches ahead of time; --in-flight worker threads (one
+// context each, sharing the packed reference and the model tables) run and download a batch each, so that parsing, the
+// device work of consecutive batches, the copies and the writes overlap.  Regular output files are written by the workers
+// themselves at their final offsets (pwrite, MDF order); pipes and devices by one writer that puts the record streams back
+// into MDF order.
 // Exit codes: 0 ok; 1 for `sys.exit("msg")`-style validation and runtime errors; 2 for argparse
 // usage errors (missing -i, neither -o nor --perfect) -- what the embedded interpreter returns.
 #include "sequencer_module.h"
