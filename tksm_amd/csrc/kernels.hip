@@ -2539,7 +2539,7 @@ int perfect_lds_bytes(int img_bytes) { return WAVES_PER_WG * (img_bytes + 32 + P
 // complement, then four codes -> four ASCII bytes by byte-parallel arithmetic.  Literal segments and reference blocks that
 // hold other symbols than ACGT are copied bytewise; substitutions are written over the image afterwards, in order.
 #ifndef PERFECT_WAVES
-#define PERFECT_WAVES 6
+#define PERFECT_WAVES 5
 #endif
 __global__ __launch_bounds__(256, PERFECT_WAVES) void k_perfect(BatchView B, RefView R, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
                                                      uint8_t* __restrict__ records, int img_bytes, int skip_below, int last) {
