@@ -660,7 +660,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     } else {
         // ---- fast pipeline: k_init, then rounds of k_err (wave per read) + k_aln (lane per alignment)
         tk::FastBuffers FB{};
-        FB.fw = lcap / 64 + 8;
         // job-id ranges: ~256 ranges of rs (multiple of 64) consecutive reads of the sorted order
         FB.rs = (uint32_t)((((n + 255) / 256) + 63) & ~63ull);
         FB.n_ranges = (uint32_t)((n + FB.rs - 1) / FB.rs);
@@ -677,11 +676,18 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             tot_trace += (uint64_t)FB.rs * r_tg[c]; tot_jc += (uint64_t)FB.rs * r_cw[c]; tot_popd += (uint64_t)FB.rs * r_ncap[c];
         }
         HIPCHK(ctx, ctx->f_state.ensure(n * sizeof(tk::ReadState) + 64));
-        HIPCHK(ctx, ctx->f_frag.ensure(n * (size_t)lcap + 64));
-        HIPCHK(ctx, ctx->f_nb.ensure(n * (size_t)lcap * 2 + 64));
-        HIPCHK(ctx, ctx->f_fplanes.ensure(n * (size_t)FB.fw * 16 + 64));
-        FB.fw2 = ((lcap + 15) / 16 + 1 + 3) & ~3;
-        HIPCHK(ctx, ctx->f_frag2.ensure(n * (size_t)FB.fw2 * 4 + 64));
+        // ragged per-read state rows: whole 64-position blocks, the padded fragment + at least one spare block
+        ctx->h_row64.resize(n + 1);
+        uint64_t nblk = 0;
+        for (uint64_t r2 = 0; r2 < n; r2++) { ctx->h_row64[r2] = (uint32_t)nblk; nblk += ((uint64_t)b->raw_len[r2] + 2 * k + 63) / 64 + 1; }
+        ctx->h_row64[n] = (uint32_t)nblk;
+        if (nblk >= (1ull << 32)) { ctx->err = "batch too large (split it)"; return TKSMSEQ_ELIMIT; }
+        HIPCHK(ctx, ctx->f_row64.ensure((n + 1) * 4 + 64));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->f_row64.p, ctx->h_row64.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, ctx->f_frag.ensure(nblk * 64 + 256));
+        HIPCHK(ctx, ctx->f_nb.ensure(nblk * 128 + 256));
+        HIPCHK(ctx, ctx->f_fplanes.ensure((nblk + 8 * n) * 16 + 256));
+        HIPCHK(ctx, ctx->f_frag2.ensure((4 * nblk + 4 * n) * 4 + 1024));
         for (int z = 0; z < 2; z++) {
             HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
             if (z == 0) {
@@ -703,7 +709,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_counters.ensure(1024));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
-        FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.st_frag2 = ctx->f_frag2.as<uint32_t>();
+        FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.st_frag2 = ctx->f_frag2.as<uint32_t>(); FB.row64 = ctx->f_row64.as<uint32_t>();
         FB.trace = ctx->f_trace.p;
         FB.redo_list = ctx->f_redo.as<uint32_t>();
         FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
@@ -775,7 +781,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             return hipEventRecord(ctx->evpool[evi++], s) == hipSuccess ? 0 : 1;
         };
         std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other (k_init, k_err, wave-wide kernel), 1 k_loop, 2 k_aln, 3 k_job, -1 host gap
-        HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, n * (size_t)lcap * 2, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, nblk * 128, s));
         HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 1024, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, lcap * tk::WAVES_PER_WG <= 150 * 1024 ? tk::WAVES_PER_WG : (lcap * 2 <= 150 * 1024 ? 2 : 1), s));

@@ -142,12 +142,12 @@ struct RangeGeo {
 
 struct FastBuffers {
     ReadState* state;                 // [n_reads]
-    uint8_t* st_frag;                 // [n_reads][lcap]
-    uint16_t* st_nb;                  // [n_reads][lcap]
-    unsigned long long* st_fplanes;   // [n_reads][fw][2] 2-bit planes of the padded fragment, {lo, hi} word pairs
-    uint32_t* st_frag2;               // [n_reads][fw2] the padded fragment, 16 bases per word, first base in the top bits: what the
+    const uint32_t* row64;            // [n_reads + 1] first 64-position block of every read's state rows (ragged; kernels.hip frag_row ...)
+    uint8_t* st_frag;                 // [blocks][64] 2-bit codes of the padded fragments, one per byte
+    uint16_t* st_nb;                  // [blocks][64] slot codes
+    unsigned long long* st_fplanes;   // [blocks + 8 n_reads][2] 2-bit planes of the padded fragments, {lo, hi} word pairs
+    uint32_t* st_frag2;               // [4 blocks + 4 n_reads] the padded fragments, 16 bases per word, first base in the top bits: what the
                                       // error loop (k_loop, one LANE per read) keeps in LDS and cuts its k-mers from
-    int fw2;
     uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, m}
     // [n_reads][cw] one 16-byte record per 8 columns of the joined window: {bits 0-3 of the columns' window shifts,
     // low | high << 8 bits of the columns' 2-bit base codes | bit 4 of the shifts << 16, low / high code bit of the 32 fragment rows that follow
@@ -176,7 +176,6 @@ struct FastBuffers {
     uint2* defer_list;                // [n_reads] {read, range}; counters[1] counts
     uint32_t* defer_cnt;              // [n_ranges] per range, one counter per 128 B
     int defer_len;
-    int fw;
 };
 
 hipError_t launch_pack(const uint8_t* ascii, uint64_t n, uint64_t gstart, uint32_t* packed, uint32_t* blockflag,

@@ -913,6 +913,16 @@ DEV void go_slow(const FastBuffers& FB, uint64_t r, int lane, int cause) {
     }
 }
 
+// Per-read state rows are ragged: read r owns the 64-position blocks row64[r] .. row64[r + 1] - 1 of st_frag / st_nb (its padded
+// fragment and at least one spare block), as many pairs of plane words + 8, and four packed words per block + 4 -- one 100 kb molecule
+// among a million short ones costs its own row, not a million rows of its length.
+DEV uint8_t* frag_row(const FastBuffers& FB, uint64_t r) { return FB.st_frag + (size_t)FB.row64[r] * 64; }
+DEV uint16_t* nb_row(const FastBuffers& FB, uint64_t r) { return FB.st_nb + (size_t)FB.row64[r] * 64; }
+DEV unsigned long long* planes_row(const FastBuffers& FB, uint64_t r) { return FB.st_fplanes + 2 * ((size_t)FB.row64[r] + 8 * r); }
+DEV int planes_words(const FastBuffers& FB, uint64_t r) { return (int)(FB.row64[r + 1] - FB.row64[r]) + 8; }      // pairs {lo, hi}
+DEV uint32_t* frag2_row(const FastBuffers& FB, uint64_t r) { return FB.st_frag2 + 4 * ((size_t)FB.row64[r] + r); }
+DEV int frag2_words(const FastBuffers& FB, uint64_t r) { return 4 * (int)(FB.row64[r + 1] - FB.row64[r]) + 4; }
+
 // ---- k_init: splice (S1), flanks, target identity, 2-bit planes of the fragment, classification
 __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
                                                SimBuffers O, FastBuffers FB) {
@@ -960,8 +970,9 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
         target = IM.value * (qa + (qb - qa) * fr);
     }
     wave_sync();
-    uint8_t* gfrag = FB.st_frag + r * (size_t)P.lcap;
-    unsigned long long* fpl = FB.st_fplanes + r * 2ull * FB.fw;
+    uint8_t* gfrag = frag_row(FB, r);
+    unsigned long long* fpl = planes_row(FB, r);
+    const int fw_r = planes_words(FB, r), fw2_r = frag2_words(FB, r);
     // the fragment goes to HBM as one 2-bit code per byte ("ACGT" -> 0..3: bits 1 and 2 of the letter, xor-ed), in 8-byte
     // pieces (the slot is a multiple of 8 long; bytes past L are never used).  Reads with other letters never use it:
     // they take the wave-wide kernel, which splices its own fragment.
@@ -973,8 +984,8 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
     // ... and once more packed, 16 bases per word with the first base in the top bits, for the error loop (k_loop cuts a
     // k-mer's table index out of two consecutive words); bases past L are zero
     {
-        uint32_t* f2 = FB.st_frag2 + r * (size_t)FB.fw2;
-        for (int w = lane; w < FB.fw2; w += 64) {
+        uint32_t* f2 = frag2_row(FB, r);
+        for (int w = lane; w < fw2_r; w += 64) {
             uint32_t word = 0u;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -991,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
     // the words past the fragment are zero (the alignment's window runs into them)
     bool dirty = false;
     const int nw = (L + 63) >> 6;
-    for (int q0 = 0; q0 < FB.fw; q0 += 64) {
+    for (int q0 = 0; q0 < fw_r; q0 += 64) {
         unsigned long long mylo = 0ull, myhi = 0ull;
         for (int q = q0; q < min(q0 + 64, nw); q++) {
             const int p = q * 64 + lane;
@@ -1002,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
             const unsigned long long lo = __ballot(valid && (code & 1)), hi = __ballot(valid && (code & 2));
             if (lane == q - q0) { mylo = lo; myhi = hi; }
         }
-        if (q0 + lane < FB.fw) { ulonglong2 v; v.x = mylo; v.y = myhi; *reinterpret_cast<ulonglong2*>(fpl + 2 * (q0 + lane)) = v; }
+        if (q0 + lane < fw_r) { ulonglong2 v; v.x = mylo; v.y = myhi; *reinterpret_cast<ulonglong2*>(fpl + 2 * (q0 + lane)) = v; }
     }
     const bool slow = __ballot(dirty) != 0ull;
     if (lane == 0) {
@@ -1154,7 +1165,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     act = act && S.stage == 0 && !S.slow;
     const int k = EM.k;
     const int L = S.raw_len + 2 * k;
-    const uint32_t* f2 = FB.st_frag2 + (size_t)r * FB.fw2;
+    const uint32_t* f2 = frag2_row(FB, r);
     // rows are zero beyond the fragment; Wl is a multiple of 4 <= fw2; unconditional loads, four in flight (idle lanes read
     // read 0's row)
     for (int w = 0; w < Wl; w += 16) {
@@ -1167,7 +1178,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
             lf[(ww + 0) * 64 + lane] = v[q].x; lf[(ww + 1) * 64 + lane] = v[q].y; lf[(ww + 2) * 64 + lane] = v[q].z; lf[(ww + 3) * 64 + lane] = v[q].w;
         }
     }
-    uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
+    uint16_t* gnb = nb_row(FB, r);
     const uint64_t g = P.first_read + (uint64_t)r * P.stride;
     const double frag_len = (double)L, target = S.target;
     const double rcp_len = rcp_refined(act ? frag_len : 1.0);
@@ -1422,8 +1433,8 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     if (S.stage != 0 || S.slow) return;
     const int k = EM.k;
     const int L = S.raw_len + 2 * k;
-    const uint32_t* f2 = FB.st_frag2 + (size_t)r * FB.fw2;
-    uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
+    const uint32_t* f2 = frag2_row(FB, r);
+    uint16_t* gnb = nb_row(FB, r);
     for (int t = 2 * lane; t < L; t += 128) *reinterpret_cast<uint32_t*>(nbl + t) = *reinterpret_cast<const uint32_t*>(gnb + t);   // (rows are padded to 8 slots)
     wave_sync();
     const uint64_t g = P.first_read + (uint64_t)r * P.stride;
@@ -1617,10 +1628,10 @@ __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, Qs
     ReadState S = FB.state[r];
     if (S.stage == 2 || S.slow) return;
     if (S.stage == 0) return;                                  // still in its error loop (k_loop's business)
-    uint16_t* gnb = FB.st_nb + r * (size_t)P.lcap;
+    uint16_t* gnb = nb_row(FB, r);
     const int per_wave = STATE_IN_HBM ? lds_ncap + 128 : lds_lcap * 3 + lds_ncap + 128;
     uint8_t* lds_wave = lds_raw + (size_t)wave * per_wave;
-    uint8_t* frag = STATE_IN_HBM ? FB.st_frag + r * (size_t)P.lcap : lds_wave;
+    uint8_t* frag = STATE_IN_HBM ? frag_row(FB, r) : lds_wave;
     uint16_t* nb = STATE_IN_HBM ? gnb : reinterpret_cast<uint16_t*>(lds_wave + lds_lcap);
     uint8_t* aux = STATE_IN_HBM ? lds_wave : lds_wave + 3 * (size_t)lds_lcap;
     const int k = EM.k;
@@ -1632,7 +1643,7 @@ __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, Qs
     uint8_t* out_seq = O.scratch + slot;
     uint8_t* out_qual = out_seq + cap;
     if (!STATE_IN_HBM) {
-        const uint8_t* gfrag0 = FB.st_frag + r * (size_t)P.lcap;
+        const uint8_t* gfrag0 = frag_row(FB, r);
         for (int t = lane * 4; t < L; t += 256) *reinterpret_cast<uint32_t*>(frag + t) = *reinterpret_cast<const uint32_t*>(gfrag0 + t);
         for (int t = lane * 2; t < L; t += 128) *reinterpret_cast<uint32_t*>(nb + t) = *reinterpret_cast<const uint32_t*>(gnb + t);
     }
@@ -2114,8 +2125,8 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
     // (and this kernel's lanes write) neighbouring lines: 4 KB per wave and group of 32 columns
     uint4* jc = FB.job_cols + G.jc_off + (size_t)(job0 - rbase) * G.cw + (size_t)lane * 4;
     const int ncap_l = (int)G.ncap;
-    const uint16_t* gnb = FB.st_nb + (size_t)r * P.lcap;
-    const ulonglong2* fp = reinterpret_cast<const ulonglong2*>(FB.st_fplanes + (size_t)r * 2 * FB.fw);   // {lo, hi} per 64 positions
+    const uint16_t* gnb = nb_row(FB, r);
+    const ulonglong2* fp = reinterpret_cast<const ulonglong2*>(planes_row(FB, r));   // {lo, hi} per 64 positions
     const int base = p0 & ~1;                                         // slot codes are fetched from an even position
     const int skip = p0 - base;
     int nmax = act ? n + skip : 0;
@@ -2125,7 +2136,7 @@ __global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuff
     // its own stream.  LDS keeps the words j - 1 .. j + 2 around the current slot's word j (a block is packed up to ~60 slots
     // after it began, and its entering rows lie 33 .. 95 positions ahead of where it began); the next raw word is in flight.
     const int wbase = base >> 6, bsh = base & 63;
-    const int wlast = FB.fw - 1;
+    const int wlast = planes_words(FB, r) - 1;
     auto fpw = [&](int w) { return fp[min(max(w, 0), wlast)]; };
     auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 v; v.x = funnel128(a.x, b.x, bsh); v.y = funnel128(a.y, b.y, bsh); return v; };
     auto put_word = [&](int j, const ulonglong2& v) { pl[((j & 3) * 2 + 0) * 64 + lane] = v.x; pl[((j & 3) * 2 + 1) * 64 + lane] = v.y; };
@@ -2240,7 +2251,7 @@ DEV void load_job(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act, A
     }
     const RangeGeo G = FB.geo_cur[rng];
     const uint32_t rel = job - FB.base_cur[rng];                      // (range bases are multiples of 64: rel & 63 = the job's lane in k_job)
-    J.fp = FB.st_fplanes + (size_t)r * 2 * FB.fw;
+    J.fp = planes_row(FB, r);
     J.jcl = FB.job_cols + G.jc_off + (size_t)(rel & ~63u) * G.cw + (size_t)(rel & 63u) * 4;
     J.win.x = 0ull; J.win.y = 0ull;
     if (act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
@@ -2811,7 +2822,7 @@ int loop_lds_words(int lcap) { return std::min(LOOP_WL_MAX, (((lcap + 15) / 16 +
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
-    const int Wl = std::min(loop_lds_words(lcap), fb.fw2);
+    const int Wl = loop_lds_words(lcap);
     hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
     return hipGetLastError();
 }
