@@ -8,8 +8,8 @@ consecutive batches fill each other's gaps (the instruction-bound error loop nex
 latency-bound last rounds of one batch underneath the bulk of the next).  Workload at N=1: BASELINE.json configs[1], "Bulk 10M molecules,
 Badread error+qual model" -- synthetic 24 x 128 Mb genome (GRCh38 is not available offline), nanopore2020 error +
 q-score models, identity 84,99,5.5, FASTQ with computed qualities; processed as 9 steps of --batch = 1,703,936 molecules
-(15.3 M molecules, the default run; 156 GiB of HBM in use; sized so that rank 0 of an 8-GPU run also holds the gathered record
-streams: 3 x 50 GB of contexts + 14 GB of second output buffers + 74 GB of gather and interleave buffers).
+(15.3 M molecules, the default run; 133 GiB of HBM in use; sized so that rank 0 of an 8-GPU run also holds the gathered record
+streams: 3 x 44 GB of contexts + 14 GB of second output buffers + 74 GB of gather and interleave buffers).
 
 N>1 (torchrun, one rank per GPU): molecules are sharded round-robin (global read g -> rank g mod P, counter-based
 RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RCCL gather of the per-rank record
