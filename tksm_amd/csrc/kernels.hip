@@ -1,8 +1,9 @@
 // kernels.hip -- hand-written gfx950 kernels of the TKSM Seq hot path.
 //
 // Two implementations of the Badread path share the stage code below:
-//   * the fast pipeline: k_init, then rounds of k_err (one wavefront per read: error loop up to the next identity
-//     re-estimation, alignment job packed from LDS) and k_aln (one LANE per alignment, bit-parallel) -- ACGT reads;
+//   * the fast pipeline: k_init, then rounds of k_loop (one LANE per read: error loop up to the next identity re-estimation;
+//     k_loopw, one wave per read, when few reads are left), k_job (one lane per alignment job: window packed into block
+//     records) and k_aln (one lane per alignment, bit-parallel), then the last visit k_err (one wave per read) -- ACGT reads;
 //   * k_simulate: one wavefront owns one read from splice to finished sequence/qualities, alignment done across the
 //     wave -- byte-exact for any alphabet; the exact fallback and the --perfect path.
 // Reference behaviour restated per stage (file:line into vpc-ccg/tksm):
@@ -869,8 +870,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
 }
 
 // ================================================================================================
-// Fast Badread pipeline: k_init -> rounds of { k_err (one wave per read, error loop up to the next
-// identity re-estimation) -> k_aln (bit-parallel banded alignment, one LANE per alignment) }.
+// Fast Badread pipeline: k_init -> rounds of { k_loop / k_loopw (error loop up to the next identity
+// re-estimation) -> k_job (windows packed) -> k_aln (bit-parallel banded alignment, one LANE per
+// alignment) } -> k_qjobs + k_job + k_aln (q-score alignments) -> k_err (q-scores, trims, output).
 // Reads whose fragment holds a non-ACGT byte (or whose alignment leaves the band representation)
 // are routed to the byte-exact wave-wide path (k_simulate over slow_list).  Same specification,
 // same results, bit for bit.
@@ -1139,8 +1141,8 @@ DEV void join_out(const uint8_t* frag, const uint16_t* nb, int n, uint8_t* out_s
 // follows a stop (re-estimation point, end of the loop) is dropped and drawn again on the next visit.
 // Per lane in LDS: the first Wl words of the padded fragment at 2 bits per base (longer fragments read the rest from HBM); the
 // slot codes stay in HBM (read and written only by the draws that change something).
-// A read that stops at a re-estimation point asks k_err for an alignment job (pending = 2); one whose loop has ended goes on
-// to its trims / q-score job / output there (stage 4).  k_err walks the same list of reads right after this kernel.
+// A read that stops at a re-estimation point gets an alignment job here (id, meta record: k_job packs its window, k_aln aligns
+// it; pending = 1); one whose loop has ended waits in stage 3 for its q-score job and its last visit (k_qjobs, k_err).
 constexpr int LOOP_B = 4;
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
                                               uint32_t begin, uint32_t count, int Wl, int from_jobs, uint32_t c0, uint32_t c1) {
@@ -1594,10 +1596,10 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     }
 }
 
-// ---- k_err: one wave per read.  LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (job staging / alignment ops).
-// STATE_IN_HBM (long reads): the fragment and its slot codes stay in HBM and are edited in place -- a round touches ~130
-// candidate positions and a 1000-slot window, so staging the whole fragment costs more than it saves, and its LDS
-// footprint would leave a handful of waves per CU; only the aux area is in LDS.
+// ---- k_err: the last visit of a read, one wave per read: trims, q-score lookups from the ops of its q-score alignment (S5),
+// output sequence, record sizes.  LDS per wave: frag[lcap] | nb[lcap] u16 | aux[ncap + 128] (the alignment's op bytes).
+// STATE_IN_HBM (long reads): the fragment and its slot codes are read where they are in HBM -- their LDS footprint would leave
+// a handful of waves per CU; only the aux area is in LDS.
 template <bool STATE_IN_HBM>
 __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, QsModelView QM, SimParams P, SimBuffers O,
                                               FastBuffers FB, const uint32_t* __restrict__ order, uint32_t begin, uint32_t count,
