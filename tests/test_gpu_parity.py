@@ -610,6 +610,17 @@ def test_cli_devices_list_threads_and_error_path(tmp_path, po, oracle_models):
         r = subprocess.run(base + ["-o", str(o2), "--badread-error-model", model, "--badread-qscore-model", model], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr
         assert o2.read_bytes().count(b"\n@") > 100 and o2.read_bytes() != one.read_bytes()
+    # a pipe (not seekable): the ordered writer thread instead of the workers' positional writes -- same bytes
+    import threading
+    fifo = tmp_path / "pipe.fastq"                     # (the extension decides the format)
+    os.mkfifo(fifo)
+    got = []
+    rd = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()), daemon=True)
+    rd.start()
+    r = subprocess.run(base + ["-o", str(fifo), "--devices", "0", "--in-flight", "3"], capture_output=True, text=True, env=env, timeout=300)
+    rd.join(timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert got and got[0] == one.read_bytes()
     # error path: /dev/full fails on write; several small batches, three in flight
     r = subprocess.run(base + ["-o", "/dev/full", "--skip-qual-compute", "--in-flight", "3", "--batch-bytes", "2048"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 1 and "write failed" in r.stderr
