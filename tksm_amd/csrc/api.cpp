@@ -425,9 +425,7 @@ static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmse
         b->total_raw += t;
         if ((uint64_t)d->ids[2 * r] + d->ids[2 * r + 1] > d->id_bytes) { ctx->err = "molecule id outside the id pool"; return TKSMSEQ_EINVAL; }
     }
-    b->order.resize(d->n_reads);
-    for (uint64_t r = 0; r < d->n_reads; r++) b->order[r] = (uint32_t)r;
-    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) { return b->raw_len[x] < b->raw_len[y]; });
+    order_by_length(b->raw_len, b->order);
     auto up = [&](DevBuf& buf, const void* src, size_t bytes) -> int {
         HIPCHK(ctx, buf.ensure(bytes + 64));
         if (bytes) HIPCHK(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -542,8 +540,7 @@ static int apply_tail(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_para
     } else b->raw_len = b->splice_len;
     b->max_raw = 0;
     for (uint32_t v : b->raw_len) b->max_raw = std::max(b->max_raw, v);
-    for (uint64_t r = 0; r < n; r++) b->order[r] = (uint32_t)r;
-    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) { return b->raw_len[x] < b->raw_len[y]; });
+    order_by_length(b->raw_len, b->order);
     HIPCHK(ctx, hipMemcpyAsync(b->d_order.p, b->order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     b->cache_k = -1;                      // the cached scratch size was for the old lengths

@@ -122,7 +122,7 @@ int finalize_device_batch(tksmseq_ctx* ctx, tksmseq_batch* b) {
     HIPCHK(ctx, hipMemcpyAsync(b->raw_len.data(), ctx->w_rawlen.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (uint64_t r = 0; r < n; r++) { b->max_raw = std::max(b->max_raw, b->raw_len[r]); b->total_raw += b->raw_len[r]; b->order[r] = (uint32_t)r; }
-    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) { return b->raw_len[x] < b->raw_len[y]; });
+    order_by_length(b->raw_len, b->order);
     HIPCHK(ctx, hipMemcpyAsync(b->d_order.p, b->order.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TKSMSEQ_OK;
