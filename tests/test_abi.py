@@ -98,3 +98,34 @@ def test_default_model_rule_follows_the_reference(tmp_path):
     assert lib.tksmseq_model_available(b"no_such_model", b"error") == 0
 
 
+
+
+def test_read_order_is_a_stable_sort_by_length(tmp_path):
+    """Every batch's read order (bucketed launches, per-range buffer sizing) is `order_by_length` of csrc/host.h, a counting sort over
+    16-bit digits: the same permutation as a stable comparison sort, for empty / single / short / > 65 535-base length sets."""
+    src = tmp_path / "order_check.cpp"
+    src.write_text(r'''
+#include "host.h"
+#include <cstdio>
+#include <random>
+int main() {
+    std::mt19937 g(5);
+    const size_t ns[] = {0, 1, 2, 1000, 300000};
+    const uint32_t mxs[] = {1, 7, 3000, 65536, 70000, 3000000};
+    for (size_t n : ns) for (uint32_t mx : mxs) {
+        std::vector<uint32_t> len(n), got, want(n);
+        for (auto& v : len) v = g() % mx;
+        if (n > 2) { len[0] = mx - 1; len[n - 1] = 0; }
+        tkh::order_by_length(len, got);
+        for (size_t i = 0; i < n; i++) want[i] = (uint32_t)i;
+        std::stable_sort(want.begin(), want.end(), [&](uint32_t x, uint32_t y) { return len[x] < len[y]; });
+        if (got != want) { std::printf("differs: n=%zu mx=%u\n", n, mx); return 1; }
+    }
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "order_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tksm_amd", "csrc"), "-o", str(exe), str(src)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

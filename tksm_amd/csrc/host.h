@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -27,6 +28,26 @@ struct IdentityHost {
     double mean = 0, stdev = 0, max_identity = 0, value = 0, beta_a = 0, beta_b = 0;
     std::vector<double> qtab;
 };
+
+// reads sorted by length, ties in read order (what a stable comparison sort gives): two counting passes over 16-bit digits -- a
+// million reads in a few milliseconds instead of a tenth of a second
+inline void order_by_length(const std::vector<uint32_t>& len, std::vector<uint32_t>& order) {
+    const size_t n = len.size();
+    order.resize(n);
+    std::vector<uint32_t> tmp(n);
+    std::vector<uint32_t> cnt(65537);
+    auto pass = [&](int shift, const uint32_t* src, uint32_t* dst, bool first) {
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        for (size_t i = 0; i < n; i++) cnt[((len[first ? i : src[i]] >> shift) & 0xffffu) + 1]++;
+        for (size_t d = 0; d < 65536; d++) cnt[d + 1] += cnt[d];
+        for (size_t i = 0; i < n; i++) { const uint32_t r = first ? (uint32_t)i : src[i]; dst[cnt[(len[r] >> shift) & 0xffffu]++] = r; }
+    };
+    uint32_t mx = 0;
+    for (uint32_t v : len) mx = std::max(mx, v);
+    if (mx < 65536u) { pass(0, nullptr, order.data(), true); return; }
+    pass(0, nullptr, tmp.data(), true);
+    pass(16, tmp.data(), order.data(), false);
+}
 
 // host image of a molecule batch in the binary layout of include/tksmseq.h
 struct BatchHost {
