@@ -5,7 +5,11 @@ sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tksm_amd import synthetic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
-extra = sys.argv[2:]                                   # e.g. --in-flight 1 --batch-bytes 16777216
+extras = [[]]                                          # e.g. --in-flight 1 --batch-bytes 16777216 [:: another set of flags ...]
+for a in sys.argv[2:]:
+    if a == "::": extras.append([])
+    else: extras[-1].append(a)
+modes = os.environ.get("E2E_MODES", "perfect,badread").split(",")
 d = "/tmp/e2e"; os.makedirs(d, exist_ok=True)
 rs = np.random.RandomState(1)
 lens = [8_000_000] * 4
@@ -18,7 +22,8 @@ t = time.time(); text = synthetic.mdf_text(m, [f"chr{c+1}" for c in range(4)]); 
 print(f"MDF text {len(text)/1e6:.0f} MB for {n} molecules (generated in {time.time()-t:.0f} s)", flush=True)
 env = dict(os.environ, TKSMSEQ_VERBOSE=os.environ.get("E2E_VERBOSE", "1"), TKSM_MODELS=os.path.join(os.getcwd(), "tksm_amd", "models"))
 ext = ".fastq.gz" if os.environ.get("E2E_GZ") else ".fastq"
-for args, name in ((["--perfect", f"{d}/p{ext}"], "perfect"), (["-o", f"{d}/b{ext}"], "badread+qual")):
+for extra, args, name in [(e, a, nm) for e in extras for a, nm in ((["--perfect", f"{d}/p{ext}"], "perfect"), (["-o", f"{d}/b{ext}"], "badread+qual")) if nm.split("+")[0] in modes]:
+    if os.path.exists(args[-1]): os.remove(args[-1])   # (overwriting a 16 GB file costs 1 - 3 s more: truncation, and ext4 flushes a file replaced via truncate when it is closed)
     t = time.time()
     r = subprocess.run([os.environ.get("E2E_EXE", os.path.join("tksm_amd", "tksm")), "sequence", "-i", f"{d}/mols.mdf", "-r", f"{d}/ref.fa"] + args + extra, capture_output=True, text=True, env=env)
     dt = time.time() - t
