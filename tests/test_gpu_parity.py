@@ -660,3 +660,39 @@ def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_mode
         assert per[i] == po.perfect_record(True, 6, i, raw, mid), (kind, i)
         assert bad[i] == po.badread_record(True, 6, i, raw, ident, oracle_models["em"], oracle_models["qm"], True, mid)[0], (kind, i)
     b.free(); s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,sigma", [("bulk", 1_703_936, None), ("scrna", 1_703_936, None), ("bulk", 1_048_576, 0.6)])
+def test_bench_size_batch_sampled_reads_equal_the_oracle(po, oracle_models, kind, n, sigma):
+    """BASELINE's full sizes: one batch of 1 703 936 molecules (bench.py's default: every launch shape, buffer size and 32-bit
+    offset of the bench; bulk = config 2, scRNA-like with barcode / UMI / polyA literals = config 3) and one of 1 048 576
+    molecules with lognormal lengths (median 1 kb, clipped at 16 kb: ragged state rows, the long-read buckets), default settings.
+    Results depend on (seed, global read index) only, so every 499th read (first and last included) is compared with the
+    oracle's record for that index, byte for byte, and the whole stream is checked for its record structure."""
+    from tksm_amd import synthetic
+    from tksm_amd.sequence import Sequencer
+    rs = np.random.RandomState(23)
+    lens = [8_000_000] * 4
+    names = [f"chr{c + 1}" for c in range(4)]
+    ref = {nm: rs.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes().decode() for nm, L in zip(names, lens)}
+    s = Sequencer(0)
+    for k, v in ref.items():
+        s.add_contig(k, v)
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    m = synthetic.make_molecules(rs, lens, n, 1000, 200, kind=kind, lognormal_sigma=sigma)
+    b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+    rec, off = s.run(b, target="badread", fastq=True, compute_qual=True, seed=9).download()
+    assert len(off) == n + 1 and int(off[-1]) == len(rec) and rec.count(b"\n") == 4 * n
+    sel = np.unique(np.concatenate([np.arange(0, n, 499), [n - 1]]))
+    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    text = synthetic.mdf_text({**m, "reads": m["reads"][sel], "ids": m["ids"][sel]}, names)
+    mols = list(po.mdf_generator(text.splitlines(keepends=True)))
+    assert len(mols) == len(sel)
+    for g, (mid, ivs) in zip(sel, mols):
+        raw = po.splice(ref, ivs)
+        want = po.badread_record(True, 9, int(g), raw, ident, oracle_models["em"], oracle_models["qm"], True, mid)[0]
+        assert rec[int(off[g]):int(off[g + 1])] == want, int(g)
+    b.free(); s.close()
