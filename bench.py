@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--mean-len", type=int, default=1000)
     ap.add_argument("--genome-contigs", type=int, default=24)
     ap.add_argument("--contig-mb", type=int, default=128)
-    ap.add_argument("--kind", default="bulk", choices=["bulk", "scrna"])
+    ap.add_argument("--kind", default="bulk", choices=["bulk", "scrna", "pcr"], help="bulk (config 2), scRNA-like literals (config 3), substitution-heavy molecules as PCR leaves them (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU sample (0 = sized for ~20 s)")
     ap.add_argument("--skip-qual", action="store_true")
@@ -391,13 +391,14 @@ def main():
                 traffic_source = f"profiles/{tj.get('profile', 'traffic_latest.json')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
         except Exception:
             traffic = None
+    kind_name = {"bulk": "Bulk", "scrna": "scRNA-like (barcode, UMI, polyA literals)", "pcr": "PCR-amplified (substitution-heavy)"}[args.kind]
     out = {
         "metric": "sequenced reads/s", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"Bulk molecules, Badread error+qual model (nanopore2020, identity 84,99,5.5), "
+        "config": {"workload": f"{kind_name} molecules, Badread error+qual model (nanopore2020, identity 84,99,5.5), "
                                f"{args.genome_contigs} x {args.contig_mb} Mb random genome, FASTQ"
-                               if not args.perfect else "Bulk molecules, --perfect splice path, FASTQ",
+                               if not args.perfect else f"{kind_name} molecules, --perfect splice path, FASTQ",
                    "kind": args.kind, "molecules_per_gpu_per_step": args.batch, "mean_len": args.mean_len,
                    "length_distribution": f"lognormal(median {args.mean_len}, sigma {args.lognormal_sigma})" if args.lognormal_sigma else f"normal({args.mean_len}, {args.mean_len * 0.2:.0f})",
                    "compute_qual": bool(compute_q and not args.perfect), "sharding": f"round-robin x{world}",
