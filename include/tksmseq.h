@@ -189,6 +189,10 @@ int tksmseq_model_available(const char* name, const char* kind);
 int tksmseq_set_timing(tksmseq_ctx* ctx, int enable);   /* hipEvent per stage, read via result.kernel_ms */
 /* Copies the last result to host memory (records: records_bytes, offsets: n_reads + 1). */
 int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets);
+/* A slice [offset, offset + bytes) of the last result's record stream to host memory -- for callers that stream a large result
+ * through a small page-locked buffer (tksmseq_host_alloc) instead of holding it whole.  async != 0: returns once the copy is
+ * queued on the context's stream (tksmseq_synchronize before the bytes are read). */
+int tksmseq_result_download_range(tksmseq_ctx* ctx, uint8_t* dst, uint64_t offset, uint64_t bytes, int async);
 /* Device-to-device copies of the last result into caller buffers (either may be NULL): records_bytes bytes and
  * n_reads + 1 u64 offsets.  Asynchronous on the context's stream. */
 int tksmseq_result_copy_device(tksmseq_ctx* ctx, void* records_dst, void* offsets_dst);

@@ -244,8 +244,14 @@ def test_full_size_properties_and_shard_invariance():
     m = synthetic.make_molecules(rs, lens, n, 1000, 200)
     b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
     rec1, off1 = s.run(b, seed=5).download()
-    rec2, _ = s.run(b, seed=5).download()
+    res2 = s.run(b, seed=5)
+    rec2, _ = res2.download()
     assert rec1 == rec2                                                   # deterministic
+    # slices of the record stream (tksmseq_result_download_range: what the CLI streams through its page-locked pieces)
+    for lo, nb in ((0, 1), (12345, 70001), (len(rec1) - 5, 5), (len(rec1), 0)):
+        assert res2.download_range(lo, nb) == rec1[lo:lo + nb]
+    with pytest.raises(Exception):
+        res2.download_range(len(rec1) - 3, 4)
     # the same batch with every alignment at full width, the error loop one lane per read in every round and no tail cut: the
     # 16-row predecessor codes + follow-up passes, k_loopw in the late rounds, the launch grouping and the tail hand-over to the
     # wave-wide kernel do not change a byte

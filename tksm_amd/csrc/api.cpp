@@ -376,6 +376,7 @@ int tksmseq_get_identity(const tksmseq_ctx* ctx, int32_t* constant, double* valu
 }
 
 // ------------------------------------------------------------------------------------------- batches
+static int verbose_level() { const char* v = getenv("TKSMSEQ_VERBOSE"); return v ? std::max(1, atoi(v)) : 0; }
 static int batch_from_host(tksmseq_ctx* ctx, const tksmseq_batch_desc* d, tksmseq_batch** out, bool check_mods = true) {
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -464,7 +465,10 @@ int tksmseq_molecules_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t
 static int batch_from_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out, bool check_mods) {
     if (!ctx || (!text && len) || !out) return TKSMSEQ_EINVAL;
     BatchHost h;
+    const auto t_text = std::chrono::steady_clock::now();
     if (!parse_mdf_mt(text, len, *ctx, h, ctx->err, ctx->host_threads)) return TKSMSEQ_EINVAL;
+    const double s_text = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_text).count();
+    const double a0 = alloc_seconds();
     tksmseq_batch_desc d{};
     d.n_reads = h.reads.size() / 2; d.n_intervals = h.intervals.size() / 4; d.n_mods = h.mods.size() / 2;
     d.n_literals = h.literals.size() / 2; d.literal_bytes = h.literal_pool.size(); d.id_bytes = h.id_pool.size();
@@ -472,6 +476,9 @@ static int batch_from_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tks
     d.literal_pool = h.literal_pool.data(); d.ids = h.ids.data(); d.id_pool = h.id_pool.data();
     const int rc = batch_from_host(ctx, &d, out, check_mods);
     if (rc != TKSMSEQ_OK) return rc;
+    if (verbose_level() >= 2)
+        fprintf(stderr, "[tksmseq] batch from %.0f MB of MDF text: parse %.3f s, tables + upload %.3f s (of which device allocation %.3f s)\n", len / 1e6, s_text,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_text).count() - s_text, alloc_seconds() - a0);
     // kept for PCR / truncation / the MDF writer: which reads are copies of a depth > 1 molecule, and the header comments
     tksmseq_batch* b = *out;
     bool any_dup = false;
@@ -496,7 +503,9 @@ int tksmseq_batch_info(const tksmseq_batch* b, uint64_t* n_reads, uint64_t* n_in
 
 void tksmseq_batch_free(tksmseq_ctx* ctx, tksmseq_batch* b) {
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    const auto t_free = std::chrono::steady_clock::now();
     delete b;
+    if (b && verbose_level() >= 2) fprintf(stderr, "[tksmseq] batch freed in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_free).count());
 }
 
 // ------------------------------------------------------------------------------------------- run
@@ -1064,6 +1073,15 @@ int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offset
     if (records && ctx->last.records_bytes) HIPCHK(ctx, hipMemcpyAsync(records, ctx->last.records, ctx->last.records_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (offsets) HIPCHK(ctx, hipMemcpyAsync(offsets, ctx->last.record_offsets, (ctx->last.n_reads + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_result_download_range(tksmseq_ctx* ctx, uint8_t* dst, uint64_t offset, uint64_t bytes, int async) {
+    if (!ctx || !ctx->have_last || (!dst && bytes)) return TKSMSEQ_ESTATE;
+    if (offset > ctx->last.records_bytes || bytes > ctx->last.records_bytes - offset) { ctx->err = "record range outside the last result"; return TKSMSEQ_EINVAL; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, (const uint8_t*)ctx->last.records + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (!async) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TKSMSEQ_OK;
 }
 

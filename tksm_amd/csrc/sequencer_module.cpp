@@ -196,6 +196,14 @@ struct Worker {                                           // one batch in flight
     uint8_t* host[2] = {nullptr, nullptr}; uint64_t host_cap[2] = {0, 0};
     std::vector<uint8_t> packed[2];                     // .gz outputs: the batch as gzip members
     std::mutex m; std::condition_variable cv; bool host_busy = false;     // the writer still reads the buffers
+    // regular uncompressed files: the records pass through two page-locked pieces (one being written while the next arrives)
+    static constexpr uint64_t PIECE = 64ull << 20;
+    uint8_t* ring[2] = {nullptr, nullptr};
+    bool ring_ready() {
+        for (int q = 0; q < 2; q++)
+            if (!ring[q]) { void* p = nullptr; if (tksmseq_host_alloc(PIECE, &p)) return false; ring[q] = (uint8_t*)p; }
+        return true;
+    }
     bool reserve(int k, uint64_t bytes) {
         if (bytes <= host_cap[k]) return true;
         tksmseq_host_free(host[k]); host[k] = nullptr; host_cap[k] = 0;
@@ -422,7 +430,7 @@ public:
         uint64_t n_batches = 0; bool reader_done = false;                                          // guarded by done_m
         // every open output is a regular file: positional writes from the workers, no writer thread
         const bool positional = (a.badread.empty() || wb.positional) && (a.perfect.empty() || wp.positional);
-        uint64_t next_place = 0, place[2] = {0, 0};                                                // guarded by done_m
+        uint64_t next_place[2] = {0, 0}, place[2] = {0, 0};                                        // per output; guarded by done_m
         // stage clocks (TKSMSEQ_VERBOSE): seconds spent parsing, running, copying, writing, reading
         const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr || log.level <= Logger::DEBUG;
         std::mutex clk_m; double clk[6] = {0, 0, 0, 0, 0, 0};
@@ -457,6 +465,19 @@ public:
                 out.order_cv.notify_all();
             }
         };
+        // regular files: batch `seq` takes its place in output k once every earlier batch has (sizes are announced in batch order)
+        const int first_out = a.badread.empty() ? 1 : 0;
+        auto take_place = [&](int k, uint64_t seq_no, uint64_t bytes, uint64_t n_reads_of_batch, uint64_t& off) -> bool {
+            {
+                std::unique_lock<std::mutex> l(done_m);
+                done_cv.wait(l, [&] { return next_place[k] == seq_no || failed.load(); });
+                if (failed) return false;
+                off = place[k]; place[k] += bytes; next_place[k]++;
+                if (k == first_out) total_reads += n_reads_of_batch;
+            }
+            done_cv.notify_all();
+            return true;
+        };
         auto work = [&](int wi) {
             Worker& W = *workers[wi];
             ParsedQueue& in_q = *pq[(size_t)(wi / per_group)];
@@ -480,6 +501,30 @@ public:
                     add_clk(1, t_run);
                     if (verbose2) fprintf(stderr, "[sequence] batch %llu worker %d: run %.3f s (%llu reads) at %.3f s\n", (unsigned long long)c.seq, wi,
                                           std::chrono::duration<double>(now() - t_run).count(), (unsigned long long)n, std::chrono::duration<double>(now() - t_start).count());
+                    Writer& wr = k == 0 ? wb : wp;
+                    if (positional && !wr.gz) {
+                        // a regular uncompressed file: the batch's place in it is known as soon as every earlier batch has announced
+                        // its size; the records go there in pieces, straight from the device (pwrite into the page cache takes
+                        // ~4 GB/s per thread; the copy of the next piece runs meanwhile)
+                        uint64_t off = 0;
+                        if (!take_place(k, c.seq, r.records_bytes, n, off)) return false;
+                        if (!W.ring_ready()) { set_error("out of page-locked host memory"); return false; }
+                        const uint64_t np = (r.records_bytes + Worker::PIECE - 1) / Worker::PIECE;
+                        auto piece_bytes = [&](uint64_t q) { return std::min<uint64_t>(Worker::PIECE, r.records_bytes - q * Worker::PIECE); };
+                        if (np && tksmseq_result_download_range(W.ctx, W.ring[0], 0, piece_bytes(0), 1)) { set_error(tksmseq_last_error(W.ctx)); return false; }
+                        for (uint64_t q = 0; q < np; q++) {
+                            const auto t_copy = now();
+                            if (tksmseq_synchronize(W.ctx)) { set_error(tksmseq_last_error(W.ctx)); return false; }
+                            if (q + 1 < np && tksmseq_result_download_range(W.ctx, W.ring[(q + 1) & 1], (q + 1) * Worker::PIECE, piece_bytes(q + 1), 1)) { set_error(tksmseq_last_error(W.ctx)); return false; }
+                            add_clk(2, t_copy);
+                            const auto t_write = now();
+                            const bool wok = wr.write_at(W.ring[q & 1], piece_bytes(q), off + q * Worker::PIECE);
+                            add_clk(3, t_write);
+                            if (!wok) { (void)tksmseq_synchronize(W.ctx); set_error("write failed"); return false; }
+                        }
+                        fin.bytes[k] = r.records_bytes;
+                        return true;
+                    }
                     const auto t_wait = now();
                     if (!waited) {                                  // the previous batch of this worker has been written
                         std::unique_lock<std::mutex> l(W.m);
@@ -512,37 +557,27 @@ public:
                         size_t at = 0;
                         for (size_t q = 0; q < np; q++) { memcpy(W.packed[k].data() + at, parts[q].data(), parts[q].size()); at += parts[q].size(); }
                         fin.bytes[k] = total;
+                        if (positional) {                           // a regular .gz file: the worker writes its members at their place
+                            uint64_t off = 0;
+                            if (!take_place(k, c.seq, total, n, off)) return false;
+                            const auto t_write = now();
+                            const bool wok = wr.write_at(W.packed[k].data(), total, off);
+                            add_clk(3, t_write);
+                            if (!wok) { set_error("write failed"); return false; }
+                        }
                     }
                     return true;
                 };
                 if (ok && n) {
                     if (!a.badread.empty()) ok = emit(0, wb.fastq, TKSMSEQ_MODE_BADREAD, 0);
                     if (ok && !a.perfect.empty()) ok = a.badread.empty() ? emit(1, wp.fastq, TKSMSEQ_MODE_PERFECT, 0) : emit(1, wp.fastq, TKSMSEQ_MODE_BADREAD, 1);
+                } else if (ok && positional) {                      // an empty batch still takes its (empty) place
+                    uint64_t off = 0;
+                    if (!a.badread.empty()) ok = take_place(0, c.seq, 0, 0, off);
+                    if (ok && !a.perfect.empty()) ok = take_place(1, c.seq, 0, 0, off);
                 }
                 tksmseq_batch_free(W.ctx, b);
-                if (!ok) continue;
-                if (positional) {
-                    // regular files: the batch's place in each output is known as soon as every earlier batch has announced its
-                    // size; the worker writes its own buffers there (the page cache takes ~4 GB/s from one thread)
-                    uint64_t off[2];
-                    {
-                        std::unique_lock<std::mutex> l(done_m);
-                        done_cv.wait(l, [&] { return next_place == c.seq || failed.load(); });
-                        if (failed) continue;
-                        off[0] = place[0]; off[1] = place[1];
-                        place[0] += fin.bytes[0]; place[1] += fin.bytes[1];
-                        next_place++;
-                        total_reads += fin.n_reads;
-                    }
-                    done_cv.notify_all();
-                    const auto t_write = now();
-                    bool wok = true;
-                    if (fin.bytes[0]) { wok = wb.write_at(wb.gz ? W.packed[0].data() : W.host[0], fin.bytes[0], off[0]); }
-                    if (wok && fin.bytes[1]) { wok = wp.write_at(wp.gz ? W.packed[1].data() : W.host[1], fin.bytes[1], off[1]); }
-                    add_clk(3, t_write);
-                    if (!wok) set_error("write failed");
-                    continue;
-                }
+                if (!ok || positional) continue;                    // (regular files: written inside emit)
                 { std::lock_guard<std::mutex> l(W.m); W.host_busy = true; }
                 { std::lock_guard<std::mutex> l(done_m); done[c.seq] = fin; }
                 done_cv.notify_all();
@@ -622,7 +657,7 @@ public:
             fprintf(stderr, "[sequence] %d batches, %d in flight, %.2f s streaming: parse %.2f, run %.2f, copy %.2f, wait for writer %.2f "
                             "(summed over workers); write %.2f; read + count %.2f\n", (int)seq, n_workers,
                     std::chrono::duration<double>(now() - t_start).count(), clk[0], clk[1], clk[2], clk[4], clk[3], clk[5]);
-        for (auto& W : workers) { tksmseq_host_free(W->host[0]); tksmseq_host_free(W->host[1]); }
+        for (auto& W : workers) { tksmseq_host_free(W->host[0]); tksmseq_host_free(W->host[1]); tksmseq_host_free(W->ring[0]); tksmseq_host_free(W->ring[1]); }
         const auto t_close = now();
         fclose(in);
         if ((!wb.close() || !wp.close()) && !status) { status = 1; fprintf(stderr, "Error: write failed\n"); }

@@ -59,6 +59,12 @@ class RunResult:
         self._seq._chk(self._seq._lib.tksmseq_result_download(self._seq._ctx, rec.ctypes.data, off.ctypes.data))
         return rec.tobytes(), off
 
+    def download_range(self, offset, nbytes):
+        """bytes [offset, offset + nbytes) of the record stream (tksmseq_result_download_range)"""
+        rec = np.empty(nbytes, np.uint8)
+        self._seq._chk(self._seq._lib.tksmseq_result_download_range(self._seq._ctx, rec.ctypes.data, offset, nbytes, 0))
+        return rec.tobytes()
+
     def copy_to_device(self, records_ptr=None, offsets_ptr=None):
         self._seq._chk(self._seq._lib.tksmseq_result_copy_device(
             self._seq._ctx, C.c_void_p(records_ptr) if records_ptr else None, C.c_void_p(offsets_ptr) if offsets_ptr else None))

@@ -31,4 +31,4 @@ for extra, args, name in [(e, a, nm) for e in extras for a, nm in ((["--perfect"
     print(f"{name} {' '.join(extra)}: rc={r.returncode} {dt:.2f} s wall -> {n/dt:.0f} reads/s end to end, output {os.path.getsize(out)/1e6:.0f} MB", flush=True)
     if r.returncode: print(r.stderr[-500:])
     for line in r.stderr.splitlines():
-        if line.startswith("[sequence]"): print(line)
+        if line.startswith("["): print(line)
