@@ -186,6 +186,12 @@ int tksmseq_set_host_threads(tksmseq_ctx* ctx, int n);
  * (set_tksm_models_dicts, py/sequence.py:17-31): the CLI's default-model rule "nanopore2020 if discoverable else random"
  * (py/sequence.py:86-107). */
 int tksmseq_model_available(const char* name, const char* kind);
+/* Host only, no context, callable from any thread: parses a model file ("error" / "qscore") or computes the identity quantile
+ * table now and keeps the result for the process, so that a later tksmseq_load_*_model / tksmseq_set_identity with the same
+ * file / parameters copies it instead of parsing again.  The CLI calls these on threads of their own while the device is set up
+ * and the reference packed (the reference's Python loads its models serially at import, py/sequence.py:323-345). */
+int tksmseq_prefetch_model(const char* name_or_path, const char* kind);
+int tksmseq_prefetch_identity(double mean, double max, double stdev);
 int tksmseq_set_timing(tksmseq_ctx* ctx, int enable);   /* hipEvent per stage, read via result.kernel_ms */
 /* Copies the last result to host memory (records: records_bytes, offsets: n_reads + 1). */
 int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets);

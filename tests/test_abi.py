@@ -129,3 +129,18 @@ int main() {
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tksm_amd", "csrc"), "-o", str(exe), str(src)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_prefetch_entry_points_are_host_only():
+    """tksmseq_prefetch_model / tksmseq_prefetch_identity parse into the process-wide store without a context or a device"""
+    from tksm_amd import _lib
+    lib = _lib.load()
+    models = os.path.join(ROOT, "tksm_amd", "models", "badread")
+    assert lib.tksmseq_prefetch_model(os.path.join(models, "nanopore2020.error.gz").encode(), b"error") == 0
+    assert lib.tksmseq_prefetch_model(os.path.join(models, "nanopore2020.error.gz").encode(), b"error") == 0     # (from the store)
+    assert lib.tksmseq_prefetch_model(os.path.join(models, "nanopore2020.qscore.gz").encode(), b"qscore") == 0
+    assert lib.tksmseq_prefetch_model(b"random", b"error") == 0 and lib.tksmseq_prefetch_model(b"ideal", b"qscore") == 0
+    assert lib.tksmseq_prefetch_model(b"/nonexistent/model.gz", b"error") != 0
+    assert lib.tksmseq_prefetch_model(b"random", b"tail") != 0
+    assert lib.tksmseq_prefetch_identity(84.0, 99.0, 5.5) == 0
+    assert lib.tksmseq_prefetch_identity(50.0, 60.0, 40.0) != 0          # invalid beta parameters

@@ -58,7 +58,7 @@ SYMBOLS = [
     "tksmseq_load_qscore_model", "tksmseq_set_identity", "tksmseq_get_error_model", "tksmseq_get_qscore_model",
     "tksmseq_get_identity", "tksmseq_batch_create", "tksmseq_batch_from_mdf_text", "tksmseq_batch_info",
     "tksmseq_batch_free", "tksmseq_run", "tksmseq_set_output_buffer", "tksmseq_set_timing",
-    "tksmseq_result_download", "tksmseq_result_download_range", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
+    "tksmseq_prefetch_model", "tksmseq_prefetch_identity", "tksmseq_result_download", "tksmseq_result_download_range", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
     "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
     "tksmseq_set_host_threads", "tksmseq_model_available",
     "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
@@ -117,6 +117,8 @@ def load():
         "tksmseq_set_output_buffer": (C.c_int, [vp, vp, u64]),
         "tksmseq_set_timing": (C.c_int, [vp, C.c_int]),
         "tksmseq_result_download": (C.c_int, [vp, vp, vp]),
+        "tksmseq_prefetch_model": (C.c_int, [C.c_char_p, C.c_char_p]),
+        "tksmseq_prefetch_identity": (C.c_int, [C.c_double, C.c_double, C.c_double]),
         "tksmseq_result_download_range": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_int]),
         "tksmseq_result_copy_device": (C.c_int, [vp, vp, vp]),
         "tksmseq_stats_download": (C.c_int, [vp, vp, vp]),

@@ -340,6 +340,19 @@ int tksmseq_set_identity(tksmseq_ctx* ctx, double mean, double max, double stdev
     return TKSMSEQ_OK;
 }
 
+int tksmseq_prefetch_model(const char* name_or_path, const char* kind) {
+    if (!name_or_path || !kind) return TKSMSEQ_EINVAL;
+    std::string err;
+    if (!strcmp(kind, "error")) { ErrorModelHost m; return load_error_model(name_or_path, m, err) ? TKSMSEQ_OK : TKSMSEQ_EIO; }
+    if (!strcmp(kind, "qscore")) { QScoreModelHost m; return load_qscore_model(name_or_path, m, err) ? TKSMSEQ_OK : TKSMSEQ_EIO; }
+    return TKSMSEQ_EINVAL;
+}
+
+int tksmseq_prefetch_identity(double mean, double max, double stdev) {
+    IdentityHost id; std::string err;
+    return make_identity(mean, max, stdev, id, err) ? TKSMSEQ_OK : TKSMSEQ_EINVAL;
+}
+
 int tksmseq_get_error_model(const tksmseq_ctx* ctx, int32_t* type, int32_t* k, int32_t* max_alts, uint32_t* cdf, uint64_t* alts, uint8_t* nalts) {
     if (!ctx || ctx->em.type < 0) return TKSMSEQ_ESTATE;
     if (type) *type = ctx->em.type;

@@ -19,6 +19,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <mutex>
 
 namespace tkh {
 
@@ -148,7 +152,7 @@ static std::string strip(const std::string& s) {
     return s.substr(a, b - a);
 }
 
-bool load_error_model(const std::string& name_or_path, ErrorModelHost& m, std::string& err) {
+static bool parse_error_model(const std::string& name_or_path, ErrorModelHost& m, std::string& err) {
     m = ErrorModelHost();
     if (name_or_path == "random") {        // py/tksm_badread.py:80-83
         m.type = 0; m.k = 1; m.max_alts = 1;
@@ -234,7 +238,7 @@ static bool encode_key(const std::string& cigar, uint64_t& key) {
     return true;
 }
 
-bool load_qscore_model(const std::string& name_or_path, QScoreModelHost& m, std::string& err) {
+static bool parse_qscore_model(const std::string& name_or_path, QScoreModelHost& m, std::string& err) {
     m = QScoreModelHost();
     struct Row { std::string cigar; std::vector<int> scores; std::vector<double> probs; };
     std::vector<Row> rows;
@@ -546,7 +550,7 @@ static double beta_pdf(double a, double b, double x) {
     return exp(lgamma(a + b) - lgamma(a) - lgamma(b) + (a - 1.0) * log(x) + (b - 1.0) * log1p(-x));
 }
 
-bool make_identity(double mean, double max, double stdev, IdentityHost& id, std::string& err) {
+static bool compute_identity(double mean, double max, double stdev, IdentityHost& id, std::string& err) {
     id = IdentityHost();
     id.mean = mean / 100.0; id.stdev = stdev / 100.0; id.max_identity = max / 100.0;
     if (id.mean == id.max_identity) { id.constant = true; id.value = id.mean; return true; }
@@ -580,6 +584,59 @@ bool make_identity(double mean, double max, double stdev, IdentityHost& id, std:
         }
         id.qtab[i] = x;
     }
+    return true;
+}
+
+
+// ---- parsed models are kept for the life of the process, keyed by file (path, size, modification time) or parameters: a model
+// parsed once -- e.g. ahead of its use, on a thread of its own while the device is being set up and the reference packed
+// (sequencer_module.cpp) -- is copied, not parsed again (0.1 - 0.2 s each for the shipped models and the identity table).
+namespace {
+template <class T> struct Memo {
+    std::mutex m;
+    std::map<std::string, std::shared_ptr<const T>> map;
+    bool get(const std::string& key, T& out) {
+        std::lock_guard<std::mutex> l(m);
+        auto it = map.find(key);
+        if (it == map.end()) return false;
+        out = *it->second;
+        return true;
+    }
+    void put(const std::string& key, const T& v) { std::lock_guard<std::mutex> l(m); map[key] = std::make_shared<const T>(v); }
+};
+std::string file_key(const std::string& name_or_path, const char* kind) {
+    const std::string path = resolve_model(name_or_path, kind);
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return std::string();
+    return path + '|' + std::to_string((long long)st.st_size) + '|' + std::to_string((long long)st.st_mtim.tv_sec) + '.' + std::to_string((long long)st.st_mtim.tv_nsec);
+}
+Memo<ErrorModelHost> error_models;
+Memo<QScoreModelHost> qscore_models;
+Memo<IdentityHost> identities;
+}  // namespace
+
+bool load_error_model(const std::string& name_or_path, ErrorModelHost& m, std::string& err) {
+    const std::string key = name_or_path == "random" ? std::string() : file_key(name_or_path, "error");
+    if (!key.empty() && error_models.get(key, m)) return true;
+    if (!parse_error_model(name_or_path, m, err)) return false;
+    if (!key.empty()) error_models.put(key, m);
+    return true;
+}
+
+bool load_qscore_model(const std::string& name_or_path, QScoreModelHost& m, std::string& err) {
+    const std::string key = (name_or_path == "random" || name_or_path == "ideal") ? std::string() : file_key(name_or_path, "qscore");
+    if (!key.empty() && qscore_models.get(key, m)) return true;
+    if (!parse_qscore_model(name_or_path, m, err)) return false;
+    if (!key.empty()) qscore_models.put(key, m);
+    return true;
+}
+
+bool make_identity(double mean, double max, double stdev, IdentityHost& id, std::string& err) {
+    char key[96];
+    snprintf(key, sizeof key, "%a|%a|%a", mean, max, stdev);
+    if (identities.get(key, id)) return true;
+    if (!compute_identity(mean, max, stdev, id, err)) return false;
+    identities.put(key, id);
     return true;
 }
 

@@ -361,6 +361,16 @@ public:
             for (auto& c : pctx) if (c) { tksmseq_destroy(c); c = nullptr; }
             for (int g = 0; g < n_groups; g++) for (int j = per_group - 1; j >= 0; j--) { tksmseq_ctx*& c = workers[(size_t)g * per_group + j]->ctx; if (c) { tksmseq_destroy(c); c = nullptr; } }
         };
+        // the models are parsed (and the identity quantile table computed) on threads of their own while the devices are set up and
+        // the reference is read and packed: the loaders below find them parsed (models.cpp keeps parsed models)
+        std::vector<std::thread> prefetch;
+        if (!a.badread.empty()) {
+            prefetch.emplace_back([&]() { (void)tksmseq_prefetch_identity(mean, maxi, sd); });
+            prefetch.emplace_back([&]() { (void)tksmseq_prefetch_model(a.error_model.c_str(), "error"); });
+            if (compute_q) prefetch.emplace_back([&]() { (void)tksmseq_prefetch_model(a.qscore_model.c_str(), "qscore"); });
+        }
+        std::once_flag prefetch_joined;
+        auto join_prefetch = [&]() { std::call_once(prefetch_joined, [&]() { for (auto& t : prefetch) t.join(); }); };
         {
             std::vector<std::string> gerr((size_t)n_groups);
             std::vector<std::thread> gt;
@@ -377,6 +387,7 @@ public:
                         if (tksmseq_reference_add_fasta(ctx, r.c_str())) return fail("loading reference");
                     }
                     if (!a.badread.empty()) {
+                        join_prefetch();
                         if (tksmseq_set_identity(ctx, mean, maxi, sd)) return fail("identity distribution");
                         if (g == 0) fprintf(stderr, "\nLoading error model from %s\n", a.error_model.c_str());
                         if (tksmseq_load_error_model(ctx, a.error_model.c_str())) return fail("error model");
@@ -390,6 +401,7 @@ public:
                         if (tksmseq_clone(ctx, &workers[(size_t)g * per_group + j]->ctx)) return fail("second context");
                 });
             for (auto& t : gt) t.join();
+            join_prefetch();
             for (auto& e : gerr) if (!e.empty()) { destroy_all(); return die(e); }
         }
         // MDF text is parsed (and its tables uploaded) ahead of the workers, by two parser threads per device group with contexts of
