@@ -10,7 +10,7 @@ for a in sys.argv[2:]:
     if a == "::": extras.append([])
     else: extras[-1].append(a)
 modes = os.environ.get("E2E_MODES", "perfect,badread").split(",")
-d = "/tmp/e2e"; os.makedirs(d, exist_ok=True)
+d = os.environ.get("E2E_DIR", "/tmp/e2e"); os.makedirs(d, exist_ok=True)
 rs = np.random.RandomState(1)
 lens = [8_000_000] * 4
 with open(f"{d}/ref.fa", "w") as f:
