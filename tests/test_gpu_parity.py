@@ -616,6 +616,20 @@ def test_cli_devices_list_threads_and_error_path(tmp_path, po, oracle_models):
         r = subprocess.run(base + ["-o", str(o2), "--badread-error-model", model, "--badread-qscore-model", model], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr
         assert o2.read_bytes().count(b"\n@") > 100 and o2.read_bytes() != one.read_bytes()
+    # regular files take a batch's records in page-locked pieces (64 MB; here 4 KB, so every batch is many pieces): same bytes,
+    # also with a gzip output next to a plain one (gzip members are written whole, the plain file in pieces)
+    small = dict(env, TKSMSEQ_PIECE_BYTES="4096")
+    pieces = tmp_path / "pieces.fastq"
+    r = subprocess.run(base[:-2] + ["--batch-bytes", "65536", "-o", str(pieces), "--in-flight", "3"], capture_output=True, text=True, env=small, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert pieces.read_bytes() == one.read_bytes()
+    import gzip
+    gz_b, plain_p = tmp_path / "both.fastq.gz", tmp_path / "both_perfect.fasta"
+    r = subprocess.run(base + ["-o", str(gz_b), "--perfect", str(plain_p), "--in-flight", "3"], capture_output=True, text=True, env=small, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert gzip.decompress(gz_b.read_bytes()) == one.read_bytes()
+    seqs = one.read_bytes().split(b"\n")[1::4]
+    assert plain_p.read_bytes().split(b"\n")[1::2] == seqs          # the -o + --perfect quirk: the badread sequence (py/sequence.py:317-319)
     # a pipe (not seekable): the ordered writer thread instead of the workers' positional writes -- same bytes
     import threading
     fifo = tmp_path / "pipe.fastq"                     # (the extension decides the format)

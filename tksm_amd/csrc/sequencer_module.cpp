@@ -197,11 +197,11 @@ struct Worker {                                           // one batch in flight
     std::vector<uint8_t> packed[2];                     // .gz outputs: the batch as gzip members
     std::mutex m; std::condition_variable cv; bool host_busy = false;     // the writer still reads the buffers
     // regular uncompressed files: the records pass through two page-locked pieces (one being written while the next arrives)
-    static constexpr uint64_t PIECE = 64ull << 20;
+    uint64_t piece = 64ull << 20;                       // (TKSMSEQ_PIECE_BYTES: small pieces for the tests)
     uint8_t* ring[2] = {nullptr, nullptr};
     bool ring_ready() {
         for (int q = 0; q < 2; q++)
-            if (!ring[q]) { void* p = nullptr; if (tksmseq_host_alloc(PIECE, &p)) return false; ring[q] = (uint8_t*)p; }
+            if (!ring[q]) { void* p = nullptr; if (tksmseq_host_alloc(piece, &p)) return false; ring[q] = (uint8_t*)p; }
         return true;
     }
     bool reserve(int k, uint64_t bytes) {
@@ -355,6 +355,7 @@ public:
         const int n_workers = n_groups * per_group;
         std::vector<std::unique_ptr<Worker>> workers;
         for (int w = 0; w < n_workers; w++) workers.emplace_back(new Worker());
+        if (const char* pb = getenv("TKSMSEQ_PIECE_BYTES")) for (auto& W : workers) W->piece = std::max<uint64_t>(4096, strtoull(pb, nullptr, 10));
         std::vector<tksmseq_ctx*> pctx;                                     // the parser threads' contexts (clones)
         auto destroy_all = [&]() {
             // clones before the contexts they borrow from
@@ -521,16 +522,16 @@ public:
                         uint64_t off = 0;
                         if (!take_place(k, c.seq, r.records_bytes, n, off)) return false;
                         if (!W.ring_ready()) { set_error("out of page-locked host memory"); return false; }
-                        const uint64_t np = (r.records_bytes + Worker::PIECE - 1) / Worker::PIECE;
-                        auto piece_bytes = [&](uint64_t q) { return std::min<uint64_t>(Worker::PIECE, r.records_bytes - q * Worker::PIECE); };
+                        const uint64_t np = (r.records_bytes + W.piece - 1) / W.piece;
+                        auto piece_bytes = [&](uint64_t q) { return std::min<uint64_t>(W.piece, r.records_bytes - q * W.piece); };
                         if (np && tksmseq_result_download_range(W.ctx, W.ring[0], 0, piece_bytes(0), 1)) { set_error(tksmseq_last_error(W.ctx)); return false; }
                         for (uint64_t q = 0; q < np; q++) {
                             const auto t_copy = now();
                             if (tksmseq_synchronize(W.ctx)) { set_error(tksmseq_last_error(W.ctx)); return false; }
-                            if (q + 1 < np && tksmseq_result_download_range(W.ctx, W.ring[(q + 1) & 1], (q + 1) * Worker::PIECE, piece_bytes(q + 1), 1)) { set_error(tksmseq_last_error(W.ctx)); return false; }
+                            if (q + 1 < np && tksmseq_result_download_range(W.ctx, W.ring[(q + 1) & 1], (q + 1) * W.piece, piece_bytes(q + 1), 1)) { set_error(tksmseq_last_error(W.ctx)); return false; }
                             add_clk(2, t_copy);
                             const auto t_write = now();
-                            const bool wok = wr.write_at(W.ring[q & 1], piece_bytes(q), off + q * Worker::PIECE);
+                            const bool wok = wr.write_at(W.ring[q & 1], piece_bytes(q), off + q * W.piece);
                             add_clk(3, t_write);
                             if (!wok) { (void)tksmseq_synchronize(W.ctx); set_error("write failed"); return false; }
                         }
