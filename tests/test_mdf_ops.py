@@ -231,6 +231,27 @@ def test_config5_pipeline_pcr_truncation_seq_on_device(gseq, mo, po, oracle_mode
 
 
 @pytest.mark.gpu
+def test_mdf_parser_and_writer_do_not_depend_on_the_host_threads(gseq, mo):
+    """20 000 molecules (1.4 MB of MDF text, a third of them with substitutions, depth 1 - 3): parsed and written back with 1 and
+    with 7 host threads -- the same text, equal to the oracle's reader / writer pair; PCR of it as well."""
+    s, _ = gseq
+    text = _mdf(np.random.RandomState(31), 20000)
+    assert len(text) > (1 << 20)
+    want = mo.write_mdf(mo.stream_mdf(text, unroll=True))
+    got = {}
+    for nt in (1, 7):
+        s.set_host_threads(nt)
+        b = s.batch_from_mdf(text)
+        got[nt] = s.to_mdf_text(b)
+        out = s.pcr(b, 4, 30000, error_rate=1e-3, efficiency=0.8, seed=3)
+        got[nt, "pcr"] = s.to_mdf_text(out)
+        out.free(); b.free()
+    s.set_host_threads(1)
+    assert got[1] == want and got[7] == want
+    assert got[7, "pcr"] == got[1, "pcr"] and got[1, "pcr"].count("\n+") > 20000
+
+
+@pytest.mark.gpu
 def test_device_batch_writer_reproduces_the_cpp_writer_known_answers(gseq):
     """tksmseq_batch_to_mdf_text on a parsed batch == the hand-derived output of the C++ reader / writer pair (cases that the
     Seq grammar, exactly 5 fields per segment line, accepts)"""

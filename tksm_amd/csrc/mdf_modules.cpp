@@ -7,10 +7,13 @@
 //                                                    "exactly one of kde-model, normal or lognormal"
 //   utility flags           src/module.h:75-104      -s/--seed (default 42), --verbosity, --log-file, -h
 // Exit codes as the reference's run(): 0 ok (also for --help), 1 for missing / inconsistent arguments and runtime errors.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/tksmseq.h"
@@ -45,25 +48,41 @@ int common_flag(int argc, char** argv, int& i, Common& c) {
 }
 
 int run_transform(const Common& c, const char* what, int (*apply)(tksmseq_ctx*, const tksmseq_batch*, void*, tksmseq_batch**), void* arg) {
+    const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* name) {
+        const auto t = std::chrono::steady_clock::now();
+        if (verbose) fprintf(stderr, "[%s] %s %.3f s\n", what, name, std::chrono::duration<double>(t - t_last).count());
+        t_last = t;
+    };
     std::string text;
     if (!read_file(c.input, text)) { fprintf(stderr, "Could not open file %s\n", c.input.c_str()); return 1; }
+    lap("input read");
     tksmseq_ctx* ctx = nullptr;
     if (tksmseq_create(c.device, &ctx)) { fprintf(stderr, "Error: %s\n", tksmseq_last_error(nullptr)); return 1; }
+    lap("device ready");
+    // host threads for the MDF parser and writer (the reference's modules are single-threaded; results do not depend on it)
+    tksmseq_set_host_threads(ctx, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
     tksmseq_batch *in = nullptr, *out = nullptr;
     char* otext = nullptr; uint64_t olen = 0;
     int rc = tksmseq_molecules_from_mdf_text(ctx, text.data(), text.size(), &in);
+    lap("molecules parsed and uploaded");
     if (!rc) rc = apply(ctx, in, arg, &out);
+    lap("device pass");
     if (!rc) rc = tksmseq_batch_to_mdf_text(ctx, out, &otext, &olen);
+    lap("MDF text written");
     int status = 0;
     if (rc) { fprintf(stderr, "Error: %s: %s\n", what, tksmseq_last_error(ctx)); status = 1; }
     else {
         FILE* f = fopen(c.output.c_str(), "wb");
         if (!f || fwrite(otext, 1, olen, f) != olen || fclose(f)) { fprintf(stderr, "Error: cannot write %s\n", c.output.c_str()); status = 1; }
     }
+    lap("output file written");
     tksmseq_text_free(otext);
     if (out) tksmseq_batch_free(ctx, out);
     if (in) tksmseq_batch_free(ctx, in);
     tksmseq_destroy(ctx);
+    lap("released");
     return status;
 }
 

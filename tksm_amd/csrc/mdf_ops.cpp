@@ -11,6 +11,7 @@
 #include <memory>
 
 #include "ctx.h"
+#include <thread>
 #include "mdf_kernels.h"
 
 namespace {
@@ -380,34 +381,59 @@ int tksmseq_batch_to_mdf_text(tksmseq_ctx* ctx, const tksmseq_batch* b, char** t
     if (!lpool.empty()) HIPCHK(ctx, hipMemcpyAsync(lpool.data(), b->litpool.p, lpool.size(), hipMemcpyDeviceToHost, s));
     if (!idpool.empty()) HIPCHK(ctx, hipMemcpyAsync(idpool.data(), b->idpool.p, idpool.size(), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
-    std::string out;
-    out.reserve(n * 96);
     // One molecule per read, depth 1: what every C++ module of the reference writes after reading with unroll = true
     // (copies of a depth > 1 molecule are named id_0, id_1, ...: src/mdf.h:97-105).  print_tsv: "+id<TAB>depth<TAB>comment".
-    for (uint64_t r = 0; r < n; r++) {
-        out += '+';
-        out.append(idpool.data() + ids[2 * r], ids[2 * r + 1]);
-        if (!b->h_dup.empty() && (b->h_dup[r] >> 31)) { out += '_'; out += std::to_string(b->h_dup[r] & 0x7fffffffu); }
-        out += "\t1\t";
-        if (!b->h_comments.empty()) out += normalize_comment(b->h_comment_pool.data() + b->h_comments[2 * r], b->h_comments[2 * r + 1], {});
-        out += '\n';
-        const uint32_t ib = reads[2 * r], ic = reads[2 * r + 1];
-        for (uint32_t i = 0; i < ic; i++) {
-            const uint32_t* iv = ivs.data() + 4 * (size_t)(ib + i);
-            if (iv[0] >> 31) { const uint32_t li = iv[0] & 0x7fffffffu; out.append(lpool.data() + lits[2 * (size_t)li], (size_t)lits[2 * (size_t)li + 1]); }
-            else out += ctx->contig_names[iv[0]];
-            out += '\t'; out += std::to_string(iv[1]); out += '\t'; out += std::to_string(iv[2]); out += '\t';
-            out += (iv[3] >> 31) ? '-' : '+';
-            out += '\t';
-            const uint32_t mb = iv[3] & 0x7fffffffu, me = iv[7] & 0x7fffffffu;
-            for (uint32_t q = mb; q < me; q++) { if (q > mb) out += ','; out += std::to_string(mods[2 * (size_t)q]); out += (char)mods[2 * (size_t)q + 1]; }
+    // The reads are formatted in contiguous shares, one per host thread (tksmseq_set_host_threads), and the shares copied into
+    // the result side by side.
+    auto put_u32 = [](std::string& o, uint32_t v) {
+        char tmp[10]; int k = 10;
+        do { tmp[--k] = (char)('0' + v % 10u); v /= 10u; } while (v);
+        o.append(tmp + k, (size_t)(10 - k));
+    };
+    auto format = [&](uint64_t r0, uint64_t r1, std::string& out) {
+        out.reserve((r1 - r0) * 112);
+        for (uint64_t r = r0; r < r1; r++) {
+            out += '+';
+            out.append(idpool.data() + ids[2 * r], ids[2 * r + 1]);
+            if (!b->h_dup.empty() && (b->h_dup[r] >> 31)) { out += '_'; put_u32(out, b->h_dup[r] & 0x7fffffffu); }
+            out += "\t1\t";
+            if (!b->h_comments.empty()) out += normalize_comment(b->h_comment_pool.data() + b->h_comments[2 * r], b->h_comments[2 * r + 1], {});
             out += '\n';
+            const uint32_t ib = reads[2 * r], ic = reads[2 * r + 1];
+            for (uint32_t i = 0; i < ic; i++) {
+                const uint32_t* iv = ivs.data() + 4 * (size_t)(ib + i);
+                if (iv[0] >> 31) { const uint32_t li = iv[0] & 0x7fffffffu; out.append(lpool.data() + lits[2 * (size_t)li], (size_t)lits[2 * (size_t)li + 1]); }
+                else out += ctx->contig_names[iv[0]];
+                out += '\t'; put_u32(out, iv[1]); out += '\t'; put_u32(out, iv[2]); out += '\t';
+                out += (iv[3] >> 31) ? '-' : '+';
+                out += '\t';
+                const uint32_t mb = iv[3] & 0x7fffffffu, me = iv[7] & 0x7fffffffu;
+                for (uint32_t q = mb; q < me; q++) { if (q > mb) out += ','; put_u32(out, mods[2 * (size_t)q]); out += (char)mods[2 * (size_t)q + 1]; }
+                out += '\n';
+            }
         }
+    };
+    const uint64_t nt = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, ctx->host_threads), n / 1024 + 1));
+    std::vector<std::string> parts(nt);
+    {
+        std::vector<std::thread> th;
+        for (uint64_t t = 1; t < nt; t++) th.emplace_back([&, t]() { format(n * t / nt, n * (t + 1) / nt, parts[t]); });
+        format(0, n / nt, parts[0]);
+        for (auto& x : th) x.join();
     }
-    char* buf = (char*)malloc(out.size() + 1);
+    uint64_t total = 0;
+    std::vector<uint64_t> at(nt);
+    for (uint64_t t = 0; t < nt; t++) { at[t] = total; total += parts[t].size(); }
+    char* buf = (char*)malloc(total + 1);
     if (!buf) return TKSMSEQ_ENOMEM;
-    memcpy(buf, out.data(), out.size()); buf[out.size()] = 0;
-    *text = buf; *len = out.size();
+    {
+        std::vector<std::thread> th;
+        for (uint64_t t = 1; t < nt; t++) th.emplace_back([&, t]() { memcpy(buf + at[t], parts[t].data(), parts[t].size()); });
+        memcpy(buf, parts[0].data(), parts[0].size());
+        for (auto& x : th) x.join();
+    }
+    buf[total] = 0;
+    *text = buf; *len = total;
     return TKSMSEQ_OK;
 }
 

@@ -289,6 +289,10 @@ class Sequencer:
         finally:
             b.free()
 
+    def set_host_threads(self, n):
+        """host threads of the MDF parser and writer (tksmseq_set_host_threads; the CLI's -t)"""
+        self._chk(self._lib.tksmseq_set_host_threads(self._ctx, int(n)))
+
     def set_timing(self, on=True):
         self._chk(self._lib.tksmseq_set_timing(self._ctx, 1 if on else 0))
 
