@@ -94,6 +94,8 @@ void tksmseq_destroy(tksmseq_ctx* ctx) {
     for (auto& ev : ctx->side_done) if (ev) (void)hipEventDestroy(ev);
     if (ctx->side_start) (void)hipEventDestroy(ctx->side_start);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h_round) (void)hipHostFree(ctx->h_round);
+    if (ctx->h_geo) (void)hipHostFree(ctx->h_geo);
     delete ctx;
 }
 
@@ -715,47 +717,66 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 HIPCHK(ctx, ctx->f_jwin[z].ensure(jcap * 16 + 64));
                 HIPCHK(ctx, ctx->f_jpopd[z].ensure(tot_popd + 64));
             }
-            HIPCHK(ctx, ctx->f_jobcnt[z].ensure((size_t)FB.n_ranges * 128 + 64));
         }
-        HIPCHK(ctx, ctx->f_prefix.ensure((size_t)(FB.n_ranges + 1) * 12 + 64));
-        HIPCHK(ctx, ctx->f_geo.ensure((size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo) + 64));
+        // the round's exchange with the host, one copy each way (ctx.h): {job counts even | counters | job counts odd} down,
+        // {prefix, bases | range geometry} up, through page-locked host memory
+        const size_t nrb = (size_t)FB.n_ranges * 128;                               // bytes of one set of job counts
+        const size_t round_bytes = 2 * nrb + 1024;
+        const size_t geo_off = (((size_t)(FB.n_ranges + 1) * 12 + 63) & ~(size_t)63);   // range geometry behind {prefix, base_prev, base_cur}
+        const size_t geo_bytes = geo_off + (size_t)FB.n_ranges * 2 * sizeof(tk::RangeGeo);
+        HIPCHK(ctx, ctx->f_round.ensure(round_bytes + 64));
+        HIPCHK(ctx, ctx->f_geoall.ensure(geo_bytes + 64));
+        if (ctx->h_round_bytes < round_bytes) {
+            if (ctx->h_round) (void)hipHostFree(ctx->h_round);
+            ctx->h_round = nullptr; ctx->h_round_bytes = 0;
+            HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_round, round_bytes * 2, hipHostMallocDefault));
+            ctx->h_round_bytes = round_bytes * 2;
+        }
+        if (ctx->h_geo_bytes < geo_bytes) {
+            if (ctx->h_geo) (void)hipHostFree(ctx->h_geo);
+            ctx->h_geo = nullptr; ctx->h_geo_bytes = 0;
+            HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_geo, geo_bytes * 2, hipHostMallocDefault));
+            ctx->h_geo_bytes = geo_bytes * 2;
+        }
+        uint8_t* const d_round = ctx->f_round.as<uint8_t>();
         HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 64 + 64));                     // predecessor codes of the first alignment pass
         HIPCHK(ctx, ctx->f_redo.ensure(jcap * 4 + 64));
         // pool of full-width rows: as many as a round can ask for, at most 4 GB (homopolymer-rich batches need many)
         FB.full_tg = (((uint32_t)ncap + 31) & ~31u) / 4 + 1;
         FB.full_rows = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(jcap, (4ull << 30) / ((uint64_t)FB.full_tg * 64)) & ~63ull);
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * FB.full_tg * 64 + 64));
-        HIPCHK(ctx, ctx->f_counters.ensure(1024));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
         FB.state = ctx->f_state.as<tk::ReadState>(); FB.st_frag = ctx->f_frag.as<uint8_t>(); FB.st_nb = ctx->f_nb.as<uint16_t>();
         FB.st_fplanes = ctx->f_fplanes.as<unsigned long long>(); FB.st_frag2 = ctx->f_frag2.as<uint32_t>(); FB.row64 = ctx->f_row64.as<uint32_t>();
         FB.trace = ctx->f_trace.p;
         FB.redo_list = ctx->f_redo.as<uint32_t>();
-        FB.trace_full = ctx->f_tracefull.p; FB.counters = ctx->f_counters.as<uint32_t>();
+        FB.trace_full = ctx->f_tracefull.p; FB.counters = reinterpret_cast<uint32_t*>(d_round + nrb);
         FB.slow_list = ctx->f_slow.as<uint32_t>();
         HIPCHK(ctx, ctx->f_defer.ensure(n * 8 + 64));
         HIPCHK(ctx, ctx->f_defercnt.ensure((size_t)FB.n_ranges * 128 + 64));
         FB.defer_list = ctx->f_defer.as<uint2>(); FB.defer_cnt = ctx->f_defercnt.as<uint32_t>(); FB.defer_len = ctx->defer_len;
         HIPCHK(ctx, hipMemsetAsync(ctx->f_defercnt.p, 0, (size_t)FB.n_ranges * 128, s));
-        FB.prefix = ctx->f_prefix.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
-        FB.geo_cur = ctx->f_geo.as<tk::RangeGeo>(); FB.geo_prev = FB.geo_cur + FB.n_ranges;
+        FB.prefix = ctx->f_geoall.as<uint32_t>(); FB.base_prev = FB.prefix + (FB.n_ranges + 1); FB.base_cur = FB.prefix + 2 * (FB.n_ranges + 1);
+        FB.geo_cur = reinterpret_cast<tk::RangeGeo*>(ctx->f_geoall.as<uint8_t>() + geo_off); FB.geo_prev = FB.geo_cur + FB.n_ranges;
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
             FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[0].as<uint4>(); FB.job_win = ctx->f_jwin[0].as<unsigned long long>();
-            FB.job_popd = ctx->f_jpopd[0].as<uint8_t>(); FB.job_cnt = ctx->f_jobcnt[z].as<uint32_t>();
+            FB.job_popd = ctx->f_jpopd[0].as<uint8_t>(); FB.job_cnt = reinterpret_cast<uint32_t*>(d_round + (z ? nrb + 1024 : 0));
             FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[0].as<uint8_t>();
         };
         select_set(0);
         // host copy of {prefix, base_prev, base_cur}, uploaded before every round
         const size_t nr1 = FB.n_ranges + 1;
-        std::vector<uint32_t> hgeo(3 * nr1, 0);
-        uint32_t* hprefix = hgeo.data();
-        uint32_t* hbase_prev = hgeo.data() + nr1;
-        uint32_t* hbase_cur = hgeo.data() + 2 * nr1;
+        // (page-locked: the copy of a round has run by the time the host writes the next round's values -- after that round's
+        // synchronisation -- so one buffer is enough)
+        HIPCHK(ctx, hipStreamSynchronize(s));                                      // (an earlier run's last copy)
+        memset(ctx->h_geo, 0, geo_bytes);
+        uint32_t* hprefix = reinterpret_cast<uint32_t*>(ctx->h_geo);
+        uint32_t* hbase_prev = hprefix + nr1;
+        uint32_t* hbase_cur = hprefix + 2 * nr1;
         for (uint32_t c = 0; c <= FB.n_ranges; c++) hbase_cur[c] = hbase_prev[c] = c * FB.rs;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
         // where the rows of every range start in this round's (first half) and the previous round's (second half) job set
-        std::vector<tk::RangeGeo> hrg(2 * (size_t)FB.n_ranges);
+        tk::RangeGeo* hrg = reinterpret_cast<tk::RangeGeo*>(ctx->h_geo + geo_off);
         auto place_ranges = [&]() {
             uint64_t ot = 0, oj = 0, op = 0;
             for (uint32_t c = 0; c < FB.n_ranges; c++) {
@@ -767,10 +788,11 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 hrg[c] = g;
                 ot += slots * g.tstride; oj += slots * g.cw; op += slots * g.ncap;
             }
-            return hipMemcpyAsync(ctx->f_geo.p, hrg.data(), hrg.size() * sizeof(tk::RangeGeo), hipMemcpyHostToDevice, s);
+            return hipMemcpyAsync(ctx->f_geoall.p, ctx->h_geo, geo_bytes, hipMemcpyHostToDevice, s);      // {prefix, bases} go along
         };
         HIPCHK(ctx, place_ranges());
-        std::vector<uint32_t> hcnt((size_t)FB.n_ranges * 32);
+        uint32_t* const cnt = ctx->h_round + nrb / 4;                              // the counters' place in the host copy of f_round
+        const uint32_t* hcnt = ctx->h_round;                                       // this round's job counts (set below)
         // length buckets over the sorted read order: each bucket gets its own LDS geometry
         struct Bucket { uint32_t begin, count; int lcap, ncap, wpw; bool hbm; };
         std::vector<Bucket> buckets;
@@ -801,12 +823,12 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         };
         std::vector<int> kinds;   // kernel kind between event i and i+1: 0 other (k_init, k_err, wave-wide kernel), 1 k_loop, 2 k_aln, 3 k_job, -1 host gap
         HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, nblk * 128, s));
-        HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.p, 0, 1024, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->f_round.p, 0, round_bytes, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, lcap * tk::WAVES_PER_WG <= 150 * 1024 ? tk::WAVES_PER_WG : (lcap * 2 <= 150 * 1024 ? 2 : 1), s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         kinds.push_back(0);
-        uint32_t cnt[4] = {0, 0, 0, 0};
+        cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
         // reads with non-ACGT bytes are known after k_init: their wave-wide kernel (latency-bound, a few waves) starts
         // now on a second stream and runs underneath the rounds
         // ... and so does the kernel of every read that leaves the fast pipeline later (an alignment the band
@@ -836,14 +858,15 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             n_side = upto; side_launches++;
             return TKSMSEQ_OK;
         };
-        HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(cnt, FB.counters, 64, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
         { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
         uint32_t rounds = 0, n_deferred = 0;
         bool revive = false, revived = false;
         for (;; rounds++) {
             select_set(rounds);
-            HIPCHK(ctx, hipMemsetAsync((void*)FB.job_cnt, 0, (size_t)FB.n_ranges * 128, s));
+            hcnt = ctx->h_round + ((rounds & 1) ? (nrb + 1024) / 4 : 0);
+            HIPCHK(ctx, tk::launch_round_reset(FB, s));                  // this round's job counts, the alignment passes' counters
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
             bool regular = false;
@@ -892,8 +915,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(regular ? 3 : 0);
-            HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
-            HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), (const void*)FB.job_cnt, (size_t)FB.n_ranges * 128, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_round, ctx->f_round.p, round_bytes, hipMemcpyDeviceToHost, s));     // counters + job counts
             HIPCHK(ctx, hipStreamSynchronize(s));
             cnt[0] = 0;
             for (uint32_t c = 0; c < FB.n_ranges; c++) { hprefix[c] = cnt[0]; cnt[0] += hcnt[(size_t)c * 32]; }
@@ -918,7 +940,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 uint32_t acc = 0;
                 for (uint32_t c = 0; c < FB.n_ranges; c++) { hbase_prev[c] = hbase_cur[c]; hbase_cur[c] = acc; acc += (hd[(size_t)c * 32] + 63) & ~63u; hprefix[c] = 0; }
                 hbase_prev[FB.n_ranges] = hbase_cur[FB.n_ranges]; hbase_cur[FB.n_ranges] = acc; hprefix[FB.n_ranges] = 0;
-                HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
                 HIPCHK(ctx, place_ranges());
                 continue;
             }
@@ -929,15 +950,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 // tail: every further round costs a full alignment latency for a handful of reads; finish the
                 // stragglers in one launch of the wave-wide kernel instead (same results: it recomputes them)
                 HIPCHK(ctx, tk::launch_collect_unfinished(FB, n, s));
-                HIPCHK(ctx, hipMemcpyAsync(cnt, ctx->f_counters.p, 16, hipMemcpyDeviceToHost, s));
+                HIPCHK(ctx, hipMemcpyAsync(cnt, FB.counters, 64, hipMemcpyDeviceToHost, s));
                 HIPCHK(ctx, hipStreamSynchronize(s));
                 break;
             }
             if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 3, 0, 4, s));   // rows of the full-width pool
-            HIPCHK(ctx, hipMemsetAsync(ctx->f_counters.as<uint32_t>() + 10, 0, 4, s));  // jobs handed to the second alignment pass
             HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= std::min(ctx->small_aln, FB.full_rows), qround ? 1 : 0, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
@@ -946,14 +965,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 uint32_t acc = 0;
                 for (uint32_t c = 0; c < FB.n_ranges; c++) { hbase_prev[c] = hbase_cur[c]; hbase_cur[c] = acc; acc += (hcnt[(size_t)c * 32] + 63) & ~63u; }
                 hbase_prev[FB.n_ranges] = hbase_cur[FB.n_ranges]; hbase_cur[FB.n_ranges] = acc;
-                HIPCHK(ctx, hipMemcpyAsync(ctx->f_prefix.p, hgeo.data(), hgeo.size() * 4, hipMemcpyHostToDevice, s));
                 HIPCHK(ctx, place_ranges());
             }
         }
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
         if (getenv("TKSMSEQ_VERBOSE")) {
             uint32_t cc[16];
-            HIPCHK(ctx, hipMemcpy(cc, ctx->f_counters.p, 64, hipMemcpyDeviceToHost));
+            HIPCHK(ctx, hipMemcpy(cc, FB.counters, 64, hipMemcpyDeviceToHost));
             fprintf(stderr, "[tksmseq] this thread so far: %u device allocations, %.3f s in hipMalloc\n", alloc_calls(), alloc_seconds());
             fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
                     (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);

@@ -210,6 +210,7 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
 // q-score jobs for the first `count` reads of fb.defer_list (after the last regular round)
 hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s);
 hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s);
+hipError_t launch_round_reset(const FastBuffers& fb, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 // mode: 0 = the round's jobs are identity re-estimations, 1 = q-score alignments (all jobs of a round have one mode)
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, hipStream_t s);

@@ -2844,6 +2844,18 @@ hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffer
     hipLaunchKernelGGL(k_job, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, o, n_jobs);
     return hipGetLastError();
 }
+// start of a round: this round's per-range job counts and the alignment passes' two counters (rows of the full-width pool, jobs
+// handed to the second pass), in one launch
+__global__ void k_round_reset(uint32_t* __restrict__ job_cnt, uint32_t n_words, uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) job_cnt[i] = 0u;
+    if (i == 0) { counters[3] = 0u; counters[10] = 0u; }
+}
+hipError_t launch_round_reset(const FastBuffers& fb, hipStream_t s) {
+    const uint32_t n_words = fb.n_ranges * 32u;
+    hipLaunchKernelGGL(k_round_reset, dim3((n_words + 255) / 256), dim3(256), 0, s, fb.job_cnt, n_words, fb.counters);
+    return hipGetLastError();
+}
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s) {
     if (!n_reads) return hipSuccess;
     hipLaunchKernelGGL(k_collect_unfinished, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, fb, n_reads);
