@@ -575,6 +575,11 @@ static int apply_tail(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_para
 
 static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params* p, int cap_num, int cap_den, int cap_add,
                     tksmseq_result* res, bool* overflow) {
+    const int vlevel = verbose_level();
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (vlevel >= 2) fprintf(stderr, "[tksmseq] run: %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count());
+    };
     *overflow = false;
     const uint64_t n = b->n_reads;
     hipStream_t s = ctx->stream;
@@ -825,6 +830,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, hipMemsetAsync(ctx->f_nb.p, 0, nblk * 128, s));
         HIPCHK(ctx, hipMemsetAsync(ctx->f_round.p, 0, round_bytes, s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
+        mark("buffers ready");
         HIPCHK(ctx, tk::launch_init(B, R, EM, IM, P, O, FB, lcap * tk::WAVES_PER_WG <= 150 * 1024 ? tk::WAVES_PER_WG : (lcap * 2 <= 150 * 1024 ? 2 : 1), s));
         if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
         kinds.push_back(0);
@@ -860,6 +866,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         };
         HIPCHK(ctx, hipMemcpyAsync(cnt, FB.counters, 64, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
+        mark("fragments spliced (k_init)");
         { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
         uint32_t rounds = 0, n_deferred = 0;
         bool revive = false, revived = false;
@@ -969,6 +976,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             }
         }
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
+        mark("rounds done");
         if (getenv("TKSMSEQ_VERBOSE")) {
             uint32_t cc[16];
             HIPCHK(ctx, hipMemcpy(cc, FB.counters, 64, hipMemcpyDeviceToHost));
