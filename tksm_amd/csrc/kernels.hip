@@ -90,6 +90,14 @@ DEV uint32_t hi32(unsigned long long v) { return (uint32_t)(v >> 32); }
 DEV unsigned long long mk64(uint32_t hi, uint32_t lo) { return ((unsigned long long)hi << 32) | lo; }
 // ({hi, lo} >> s) & 0xffffffff for s in 0..31: one v_alignbit_b32
 DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+// Any boolean function of three words in one instruction (V_BITOP3_B32, new in gfx950): the truth table is the function applied
+// to the constants TA, TB, TC below, e.g. bool3<BOOL3(TA | ~(TB | TC))>(x, y, z) = x | ~(y | z).
+constexpr uint32_t TA = 0xF0u, TB = 0xCCu, TC = 0xAAu;
+#define BOOL3(expr) ((uint32_t)((expr) & 0xFFu))
+template <uint32_t TT> DEV uint32_t bool3(uint32_t x, uint32_t y, uint32_t z) { return __builtin_amdgcn_bitop3_b32(x, y, z, TT); }
+template <uint32_t TT> DEV unsigned long long bool3(unsigned long long x, unsigned long long y, unsigned long long z) {
+    return mk64(bool3<TT>(hi32(x), hi32(y), hi32(z)), bool3<TT>(lo32(x), lo32(y), lo32(z)));
+}
 // bits [s, s + 64) of the 128-bit value {x1, x0}, s in 0..63
 DEV unsigned long long funnel128(unsigned long long x0, unsigned long long x1, int s) {
     const bool a = (s & 32) != 0;
@@ -1846,7 +1854,6 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, 
     constexpr int RAMP0 = 31 - ST;
     const bool act = J.act;
     const int n = J.n, m = act ? J.m : 0;
-    constexpr unsigned long long M64 = MODE ? ~0ull : 0ull;
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1, t32 = 1;
     // the window rows' code planes are kept COMPLEMENTED: Eq = (~A ^ cl) & (~B ^ ch) saves the two inversions per column
@@ -1897,20 +1904,23 @@ DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, 
             const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
             const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
             // rows below the fragment (i > n) are not masked: they never feed a row above them
-            const unsigned long long Eq = (A ^ mk64(cl, cl)) & (B ^ mk64(ch, ch));
+            // (three-input boolean instructions throughout: 31 instead of 44 vector instructions for the logic of a column)
+            const unsigned long long clm = mk64(cl, cl), chm = mk64(ch, ch);
+            const unsigned long long Eq = bool3<BOOL3(TA & (TB ^ TC))>(A ^ clm, B, chm);
             const unsigned long long Xv = Eq | Mv;
-            const unsigned long long Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-            const unsigned long long Ph = Mv | ~(Xh | Pv);
+            const unsigned long long Xh = bool3<BOOL3((TA ^ TB) | TC)>((Eq & Pv) + Pv, Pv, Eq);
+            const unsigned long long Ph = bool3<BOOL3(TA | ~(TB | TC))>(Mv, Xh, Pv);
             const unsigned long long Mh = Pv & Xh;
             const unsigned long long D0 = Xh | Mv;
             const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
             const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
-            Pv = Mhs | ~(Xv | Phs);
+            Pv = bool3<BOOL3(TA | ~(TB | TC))>(Mhs, Xv, Phs);
             Mv = Phs & Xv;
             const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
-            // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal
-            const unsigned long long w1 = ~(upv | Ph);
-            const unsigned long long w0 = (Ph & (~upv | M64)) | (w1 & D0);
+            // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal.  w1 = neither up nor left; w0 = left, or a
+            // diagonal that is a match: (Ph & (~upv | M64)) | (w1 & D0), i.e. ~upv & (Ph | D0) in mode 0 and Ph | (~upv & D0) in mode 1
+            const unsigned long long w1 = bool3<BOOL3(~(TA | TB))>(upv, Ph, 0ull);
+            const unsigned long long w0 = MODE ? bool3<BOOL3(TB | (~TA & TC))>(upv, Ph, D0) : bool3<BOOL3(~TA & (TB | TC))>(upv, Ph, D0);
             // stored rows: ROWS around the generative row, which sits at bit 31 once the window moves (t > 1) and climbs from
             // bit 0 with the column index while the window is still clamped at row 1: band rows st .. st + ROWS - 1,
             // st = clamp(column - (31 - ST), 0, ST), a function of the column alone (scalar here, a constant in the walk).
