@@ -177,6 +177,9 @@ def main():
         n_cpu = args.cpu_sample or max(64, int(cores * 20.0 / 0.0023 * (1000.0 / args.mean_len)))
         cpu_base = cpu_baseline(n_cpu, args.mean_len)
 
+    # one hardware queue per stream in flight: the runtime's default of 4 makes the main streams of several contexts share a queue
+    # (their kernels then run one after the other); read when the runtime starts
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
     from tksm_amd import synthetic

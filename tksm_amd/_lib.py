@@ -76,6 +76,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C tksm_amd/csrc).  tksm_amd has no CPU fallback.")
+    # a hardware queue per stream in flight (the runtime's default of 4 serialises the kernels of contexts whose streams share
+    # one); read when the HIP runtime starts, so this only helps when nothing has touched the device yet
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     P = C.POINTER

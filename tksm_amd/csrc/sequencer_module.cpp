@@ -347,6 +347,10 @@ public:
             log.log(Logger::WARN, "with both -o and --perfect the reference writes the badread sequence (quals 'K') to the "
                                   "--perfect file (py/sequence.py:317-319); reproduced here");
 
+        // a hardware queue per stream in flight: with the runtime's default of 4 the main streams of several contexts share queues,
+        // and kernels of different batches that could run side by side run one after the other (tools/calib/hwq_check.hip).  Read
+        // when the runtime starts, i.e. at the first device call below; a value set by the user wins.
+        setenv("GPU_MAX_HW_QUEUES", "16", 0);
         // One group of --in-flight contexts per entry of --devices: the first context of a group loads the reference and the
         // models onto its device, the others share them (tksmseq_clone).  Reads are numbered by the reader, batches go to
         // whichever context is free, the writer restores MDF order: the output does not depend on the device list.
