@@ -44,6 +44,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_SMALL_ROUND")) c->small_round = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_WAVE_LOOP")) c->wave_loop = (uint32_t)atoi(tc);
+    if (const char* tc = getenv("TKSMSEQ_ALN_LDS_PAD")) c->aln_lds_pad = (unsigned)std::min(60000, std::max(0, atoi(tc)));
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
     if (const char* fp = getenv("TKSMSEQ_FULL_POOL_MB")) c->full_pool_bytes = (unsigned long long)atoll(fp) << 20;
@@ -964,7 +965,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= std::min(ctx->small_aln, FB.full_rows), qround ? 1 : 0, s));
+            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= std::min(ctx->small_aln, FB.full_rows), qround ? 1 : 0, ctx->aln_lds_pad, s));
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
             // next round: its jobs are packed by this round's counts (a read has at most one job per round)

@@ -213,7 +213,7 @@ hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffer
 hipError_t launch_round_reset(const FastBuffers& fb, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 // mode: 0 = the round's jobs are identity re-estimations, 1 = q-score alignments (all jobs of a round have one mode)
-hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, hipStream_t s);
+hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s);
 hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s);
 hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,
                           uint32_t max_raw, int n_cus, hipStream_t s);
