@@ -716,3 +716,36 @@ def test_bench_size_batch_sampled_reads_equal_the_oracle(po, oracle_models, kind
         want = po.badread_record(True, 9, int(g), raw, ident, oracle_models["em"], oracle_models["qm"], True, mid)[0]
         assert rec[int(off[g]):int(off[g + 1])] == want, int(g)
     b.free(); s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,ident", [("nanopore2018", (85.0, 95.0, 5.0)), ("pacbio2016", (85.0, 95.0, 5.0))])
+def test_other_shipped_models_bit_exact_vs_oracle(po, model, ident):
+    """The two other shipped model pairs (py/tksm_models/badread: nanopore2018, pacbio2016; their own k-mer tables, alternative
+    counts and q-score rows) through the same kernels, record for record vs the oracle loading the same files: bulk and scRNA-like
+    molecules, with q-scores and --perfect; the model tables as the device holds them equal the oracle's."""
+    from conftest import MODELS
+    from tksm_amd import synthetic
+    from tksm_amd.sequence import Sequencer
+    em_path, qs_path = os.path.join(MODELS, f"{model}.error.gz"), os.path.join(MODELS, f"{model}.qscore.gz")
+    em, qm = po.ErrorModel(em_path), po.QScoreModel(qs_path)
+    rs = np.random.RandomState(41)
+    lens = [300_000, 200_000]
+    ref = {f"g{i}": rs.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes().decode() for i, L in enumerate(lens)}
+    s = Sequencer(0)
+    for k, v in ref.items():
+        s.add_contig(k, v)
+    s.set_identity(*ident)                                 # (mean, max, stdev)
+    s.load_error_model(em_path)
+    s.load_qscore_model(qs_path)
+    idt = po.Identities(ident[0], ident[2], ident[1], qtab=s.identity_tables()["qtab"])
+    for kind, n in (("bulk", 1500), ("scrna", 700)):
+        m = synthetic.make_molecules(rs, lens, n, 900, 300, kind=kind)
+        b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+        bad = s.run(b, target="badread", fastq=True, compute_qual=True, seed=8).records()
+        text = synthetic.mdf_text(m, list(ref))
+        for i, (mid, ivs) in enumerate(po.mdf_generator(text.splitlines(keepends=True))):
+            raw = po.splice(ref, ivs)
+            assert bad[i] == po.badread_record(True, 8, i, raw, idt, em, qm, True, mid)[0], (model, kind, i)
+        b.free()
+    s.close()
