@@ -749,3 +749,31 @@ def test_other_shipped_models_bit_exact_vs_oracle(po, model, ident):
             assert bad[i] == po.badread_record(True, 8, i, raw, idt, em, qm, True, mid)[0], (model, kind, i)
         b.free()
     s.close()
+
+
+@pytest.mark.gpu
+def test_cli_gzipped_reference_and_two_reference_files(tmp_path):
+    """generate_fasta / get_reference_seqs (py/sequence.py:168-194): a .fa.gz reference, and the contigs split over two -r files,
+    give the bytes of the plain single file"""
+    import gzip
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    d = os.path.join(GOLDEN, "splice_corpus")
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    ref = open(os.path.join(d, "ref.fa"), "rb").read()
+    gz = tmp_path / "ref.fa.gz"
+    gz.write_bytes(gzip.compress(ref))
+    recs = ref.split(b">")[1:]
+    assert len(recs) >= 2
+    half = len(recs) // 2
+    a, b = tmp_path / "a.fa", tmp_path / "b.fasta"
+    a.write_bytes(b"".join(b">" + r for r in recs[:half])); b.write_bytes(b"".join(b">" + r for r in recs[half:]))
+    outs = {}
+    for name, refs in (("plain", [os.path.join(d, "ref.fa")]), ("gz", [str(gz)]), ("two", [str(a), str(b)])):
+        o = tmp_path / f"{name}.fastq"
+        r = subprocess.run([exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r"] + refs + ["--perfect", str(o), "-s", "3"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs[name] = o.read_bytes()
+    assert len(outs["plain"]) > 1000 and outs["gz"] == outs["plain"] and outs["two"] == outs["plain"]
