@@ -777,3 +777,33 @@ def test_cli_gzipped_reference_and_two_reference_files(tmp_path):
         assert r.returncode == 0, r.stderr
         outs[name] = o.read_bytes()
     assert len(outs["plain"]) > 1000 and outs["gz"] == outs["plain"] and outs["two"] == outs["plain"]
+
+
+@pytest.mark.gpu
+def test_cli_reads_mdf_from_a_pipe_and_chains_with_the_mdf_modules(tmp_path):
+    """MDF arriving on /dev/stdin (how a pipeline hands molecules from one module to the next) gives the bytes of the file input;
+    `tksm truncate` -> `tksm sequence` over a pipe equals the two steps over a file."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    d = os.path.join(GOLDEN, "splice_corpus")
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    mdf, ref = os.path.join(d, "mols.mdf"), os.path.join(d, "ref.fa")
+    f1, f2 = tmp_path / "file.fastq", tmp_path / "pipe.fastq"
+    r = subprocess.run([exe, "sequence", "-i", mdf, "-r", ref, "-o", str(f1), "-s", "4", "--batch-bytes", "4096"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with open(mdf, "rb") as fin:
+        r = subprocess.run([exe, "sequence", "-i", "/dev/stdin", "-r", ref, "-o", str(f2), "-s", "4", "--batch-bytes", "4096"], stdin=fin, capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f2.read_bytes() == f1.read_bytes() and len(f1.read_bytes()) > 10000
+    # truncate | sequence
+    t_file, o_file, o_pipe = tmp_path / "trc.mdf", tmp_path / "trc_file.fastq", tmp_path / "trc_pipe.fastq"
+    r = subprocess.run([exe, "truncate", "-i", mdf, "-o", str(t_file), "--normal", "300,50", "-s", "5"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "sequence", "-i", str(t_file), "-r", ref, "--perfect", str(o_file), "-s", "4"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    p1 = subprocess.Popen([exe, "truncate", "-i", mdf, "-o", "/dev/stdout", "--normal", "300,50", "-s", "5"], stdout=subprocess.PIPE, env=env)
+    p2 = subprocess.run([exe, "sequence", "-i", "/dev/stdin", "-r", ref, "--perfect", str(o_pipe), "-s", "4"], stdin=p1.stdout, capture_output=True, env=env, timeout=300)
+    p1.stdout.close()
+    assert p1.wait(timeout=120) == 0 and p2.returncode == 0, p2.stderr
+    assert o_pipe.read_bytes() == o_file.read_bytes() and len(o_file.read_bytes()) > 1000
