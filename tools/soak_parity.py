@@ -1,6 +1,7 @@
 """Soak parity: many synthetic reads through the HIP path and through the CPU oracle, records compared by digest.
 
-    python tools/soak_parity.py [n=200000] [kind=bulk|scrna] [mean=1000] [sigma=0 (lognormal)] [tail=0|1] [seed=42]
+    python tools/soak_parity.py [n=200000] [kind=bulk|scrna|pcr] [mean=1000] [sigma=0 (lognormal)] [tail=0|1] [seed=42]
+    (environment: SOAK_MODEL = nanopore2020 | nanopore2018 | pacbio2016, SOAK_IDENT = mean,max,stdev)
 
 The oracle runs first in forked workers (before this process touches the GPU), ~7 k reads/s on 16 cores.
 """
@@ -49,9 +50,11 @@ def main():
     text = synthetic.mdf_text(m, list(ref))
     mols = list(po.mdf_generator(text.splitlines(keepends=True)))
     models = os.path.join(ROOT, "tksm_amd", "models", "badread")
+    model = os.environ.get("SOAK_MODEL", "nanopore2020")                       # a shipped model pair by name
+    imean, imax, isd = (float(x) for x in os.environ.get("SOAK_IDENT", "84,99,5.5").split(","))   # identity mean,max,stdev
     tail_path = os.path.join(ROOT, "tests", "golden", "tail_model_synth.json")
-    _S.update(po=po, ref=ref, mols=mols, seed=seed, em=po.ErrorModel(os.path.join(models, "nanopore2020.error.gz")),
-              qm=po.QScoreModel(os.path.join(models, "nanopore2020.qscore.gz")), ident=po.Identities(84.0, 5.5, 99.0),
+    _S.update(po=po, ref=ref, mols=mols, seed=seed, em=po.ErrorModel(os.path.join(models, f"{model}.error.gz")),
+              qm=po.QScoreModel(os.path.join(models, f"{model}.qscore.gz")), ident=po.Identities(imean, isd, imax),
               tail=po.TailModel(tail_path) if tail else None)
     cores = min(16, len(os.sched_getaffinity(0)))
     step = 2000
@@ -71,9 +74,9 @@ def main():
     s = Sequencer(0)
     for name, seq in ref.items():
         s.add_contig(name, seq.encode())
-    s.set_identity(84.0, 99.0, 5.5)
-    s.load_error_model(os.path.join(models, "nanopore2020.error.gz"))
-    s.load_qscore_model(os.path.join(models, "nanopore2020.qscore.gz"))
+    s.set_identity(imean, imax, isd)
+    s.load_error_model(os.path.join(models, f"{model}.error.gz"))
+    s.load_qscore_model(os.path.join(models, f"{model}.qscore.gz"))
     if tail:
         s.load_tail_model(tail_path)
     b = s.batch_from_mdf(text)
@@ -81,7 +84,7 @@ def main():
     recs = s.run(b, target="badread", fastq=True, compute_qual=True, seed=seed).records()
     print(f"gpu: {len(recs)} records in {time.time() - t0:.2f} s (incl. download)", flush=True)
     bad = [i for i in range(n) if hashlib.md5(recs[i]).digest() != want[i]]
-    print(f"RESULT n={n} kind={kind} mean={mean} sigma={sigma} tail={tail} seed={seed}: mismatching records {len(bad)}"
+    print(f"RESULT n={n} kind={kind} mean={mean} sigma={sigma} tail={tail} seed={seed} model={model} identity={imean},{imax},{isd}: mismatching records {len(bad)}"
           + (f", first {bad[:5]}" if bad else ""), flush=True)
     s.close()
     sys.exit(1 if bad else 0)
