@@ -689,7 +689,8 @@ def test_bench_size_batch_sampled_reads_equal_the_oracle(po, oracle_models, kind
     offset of the bench; bulk = config 2, scRNA-like with barcode / UMI / polyA literals = config 3) and one of 1 048 576
     molecules with lognormal lengths (median 1 kb, clipped at 16 kb: ragged state rows, the long-read buckets), default settings.
     Results depend on (seed, global read index) only, so every 499th read (first and last included) is compared with the
-    oracle's record for that index, byte for byte, and the whole stream is checked for its record structure."""
+    oracle's record for that index, byte for byte, and the whole stream is checked for its record structure; then the same batch
+    and sample through the --perfect kernel."""
     from tksm_amd import synthetic
     from tksm_amd.sequence import Sequencer
     rs = np.random.RandomState(23)
@@ -711,10 +712,18 @@ def test_bench_size_batch_sampled_reads_equal_the_oracle(po, oracle_models, kind
     text = synthetic.mdf_text({**m, "reads": m["reads"][sel], "ids": m["ids"][sel]}, names)
     mols = list(po.mdf_generator(text.splitlines(keepends=True)))
     assert len(mols) == len(sel)
+    raws = []
     for g, (mid, ivs) in zip(sel, mols):
         raw = po.splice(ref, ivs)
+        raws.append(raw)
         want = po.badread_record(True, 9, int(g), raw, ident, oracle_models["em"], oracle_models["qm"], True, mid)[0]
         assert rec[int(off[g]):int(off[g + 1])] == want, int(g)
+    # the same batch through the direct --perfect kernel
+    del rec
+    prec, poff = s.run(b, target="perfect", fastq=True, seed=9).download()
+    assert len(poff) == n + 1 and int(poff[-1]) == len(prec)
+    for g, (mid, ivs), raw in zip(sel, mols, raws):
+        assert prec[int(poff[g]):int(poff[g + 1])] == po.perfect_record(True, 9, int(g), raw, mid), int(g)
     b.free(); s.close()
 
 
