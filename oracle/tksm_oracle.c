@@ -203,12 +203,24 @@ static inline int code_of(uint8_t c) {
  * j (1..m) at trace[j*64 + b] bit0 = up ok, bit1 = left ok and the window top in ttop[j]. */
 #define BW 32
 #define INF 0x3fffffff
+#ifdef BAND_STATS
+/* diagnostic build only (tools/band_rows.py): every cell also carries the range of row offsets from the generative row
+ * (i - g_j) along its preferred path; band_row_hist[lo + 64][hi + 64] counts the finished alignments of mode 0 */
+typedef struct { int32_t h, m, c; int16_t lo, hi; } cell;
+static int64_t band_row_hist[128][128];
+void oracle_band_row_hist(int64_t* out, int reset) { memcpy(out, band_row_hist, sizeof(band_row_hist)); if (reset) memset(band_row_hist, 0, sizeof(band_row_hist)); }
+#define BS_INIT(x) do { (x).lo = 0; (x).hi = 0; } while (0)
+#define BS_TAKE(dst, src, off) do { int o_ = (off); (dst).lo = (int16_t)((src).lo < o_ ? (src).lo : o_); (dst).hi = (int16_t)((src).hi > o_ ? (src).hi : o_); } while (0)
+#else
 typedef struct { int32_t h, m, c; } cell;
+#define BS_INIT(x) do { } while (0)
+#define BS_TAKE(dst, src, off) do { } while (0)
+#endif
 
 static inline cell col_cell(const cell* col, int t, int i, int jcol) {
     /* value of row i (1-based, i >= 1) in a finished column whose window starts at row t; jcol = column index */
     cell r;
-    if (i == 0) { if (t == 1) { r.h = jcol; r.m = 0; r.c = jcol; } else r.h = INF; return r; }
+    if (i == 0) { BS_INIT(r); if (t == 1) { r.h = jcol; r.m = 0; r.c = jcol; } else r.h = INF; return r; }
     int b = i - t;
     if (b < 0) { r.h = INF; return r; }
     if (b <= 63) return col[b];
@@ -221,7 +233,7 @@ static int band_align(const uint8_t* F, int n, const uint8_t* N, int m, const ui
                       int mode, int* out_match, int* out_cols, uint8_t* trace, int32_t* ttop) {
     cell prev[64], cur[64];
     int tp = 1;
-    for (int b = 0; b < 64; b++) { prev[b].h = 1 + b; prev[b].m = 0; prev[b].c = 1 + b; }
+    for (int b = 0; b < 64; b++) { prev[b].h = 1 + b; prev[b].m = 0; prev[b].c = 1 + b; BS_INIT(prev[b]); }
     for (int j = 1; j <= m; j++) {
         int g = (int)owner[j - 1] + 1;
         int t = g - (BW - 1) > 1 ? g - (BW - 1) : 1;
@@ -232,8 +244,8 @@ static int band_align(const uint8_t* F, int n, const uint8_t* N, int m, const ui
             if (i > n) { cur[b].h = INF; if (trace) trace[(size_t)j * 64 + b] = 0; continue; }
             cell up;
             if (b >= 1) up = cur[b - 1];
-            else if (t == 1) { up.h = j; up.m = 0; up.c = j; }
-            else up.h = INF;
+            else if (t == 1) { up.h = j; up.m = 0; up.c = j; BS_INIT(up); }
+            else { up.h = INF; BS_INIT(up); }
             cell dg = col_cell(prev, tp, i - 1, j - 1);
             cell lf = col_cell(prev, tp, i, j - 1);
             int match = F[i - 1] == nc;
@@ -247,15 +259,21 @@ static int band_align(const uint8_t* F, int n, const uint8_t* N, int m, const ui
             int upok = (vu == h), leftok = (vl == h);
             if (trace) trace[(size_t)j * 64 + b] = (uint8_t)(upok | (leftok << 1));
             int take = mode == 0 ? (upok ? 0 : (leftok ? 1 : 2)) : (leftok ? 1 : (upok ? 0 : 2));
-            if (take == 0) { cur[b].m = up.m; cur[b].c = up.c + 1; }
-            else if (take == 1) { cur[b].m = lf.m; cur[b].c = lf.c + 1; }
-            else { cur[b].m = dg.m + match; cur[b].c = dg.c + 1; }
+            if (take == 0) { cur[b].m = up.m; cur[b].c = up.c + 1; BS_TAKE(cur[b], up, i - g); }
+            else if (take == 1) { cur[b].m = lf.m; cur[b].c = lf.c + 1; BS_TAKE(cur[b], lf, i - g); }
+            else { cur[b].m = dg.m + match; cur[b].c = dg.c + 1; BS_TAKE(cur[b], dg, i - g); }
         }
         memcpy(prev, cur, sizeof(cur));
         tp = t;
     }
     cell f = col_cell(prev, tp, n, m);
     if (n - tp > 63 || f.h >= INF) return -1;
+#ifdef BAND_STATS
+    if (mode == 0) {
+        int lo = f.lo < -64 ? -64 : f.lo, hi = f.hi > 63 ? 63 : f.hi;
+        __atomic_fetch_add(&band_row_hist[lo + 64][hi + 64], 1, __ATOMIC_RELAXED);
+    }
+#endif
     *out_match = f.m; *out_cols = f.c;
     return f.h;
 }

@@ -154,8 +154,7 @@ def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n
                 collect_stats=True)
     recs = res.records()
     ist, dst = res.stats()
-    idt = s.identity_tables()
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=idt["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     em, qm = oracle_models["em"], oracle_models["qm"]
     for i, (mid, ivs) in enumerate(mols):
         raw = po.splice(ref, ivs)
@@ -164,7 +163,9 @@ def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n
         got_stats = (ist[i, 0], ist[i, 1], ist[i, 2], ist[i, 3], ist[i, 4], ist[i, 5], ist[i, 6])
         want_stats = (st.n_draws, st.change_count, st.n_aligns, st.frag_len, st.new_len, st.start_trim, st.end_trim)
         assert got_stats == want_stats, (i, got_stats, want_stats, dst[i], st.errors, st.target_identity)
-        assert dst[i, 1] == st.target_identity and dst[i, 0] == st.errors
+        # the oracle tabulates the Beta quantile function with scipy, the library with its own routine (1e-10 apart:
+        # test_identity_table_matches_scipy): the target agrees to that, everything downstream of it bit for bit
+        assert abs(dst[i, 1] - st.target_identity) <= 1e-9 and dst[i, 0] == st.errors
         assert recs[i] == want, (i, mid)
     s.close()
 
@@ -193,7 +194,7 @@ def test_cli_end_to_end_matches_goldens_and_oracle(tmp_path, po, oracle_models):
     from tksm_amd.sequence import Sequencer
     s = Sequencer(0)
     s.set_identity(84.0, 99.0, 5.5)
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     s.close()
     want = []
     with open(os.path.join(d, "mols.mdf")) as f:
@@ -309,7 +310,7 @@ def test_builtin_models_bit_exact_vs_oracle(po, oracle_models, err, qs):
     mols = _make_molecules(rs, ref, 40, 500)
     text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
     recs = s.run(s.batch_from_mdf(text), target="badread", fastq=True, compute_qual=True, seed=77).records()
-    ident = po.Identities(88.0, 4.0, 97.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(88.0, 4.0, 97.0)
     for i, (mid, ivs) in enumerate(mols):
         want, st = po.badread_record(True, 77, i, po.splice(ref, ivs), ident, em, qm, True, mid)
         assert recs[i] == want, (err, qs, i)
@@ -390,7 +391,7 @@ def test_output_slot_overflow_triggers_rerun(tmp_path, po):
     mols = [(f"m{i}", [("chr1", 100 * i, 100 * i + 300, "+", "")]) for i in range(12)]
     text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
     recs = s.run(s.batch_from_mdf(text), target="badread", fastq=True, compute_qual=True, seed=8).records()
-    ident = po.Identities(55.0, 1.0, 60.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(55.0, 1.0, 60.0)
     grew = 0
     for i, (mid, ivs) in enumerate(mols):
         want, st = po.badread_record(True, 8, i, po.splice(ref, ivs), ident, em, qm, True, mid)
@@ -485,7 +486,7 @@ def test_band_failure_falls_back_to_the_unbanded_alignment(oracle_models, po, mo
     s.set_identity(84.0, 99.0, 5.5)
     s.load_error_model(ERR_MODEL)
     s.load_qscore_model(QS_MODEL)
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     em, qm = oracle_models["em"], oracle_models["qm"]
     for x in json.load(open(os.path.join(GOLDEN, "unbanded_reads.json"))):
         seq = x["sequence"]
@@ -520,7 +521,7 @@ def test_tail_noise_bit_exact_vs_oracle(oracle_models, po, monkeypatch, path):
     mols = _make_molecules(rs, ref, 96, 700)
     text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
     batch = s.batch_from_mdf(text)
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     em, qm = oracle_models["em"], oracle_models["qm"]
 
     def check(seed, tail):
@@ -566,7 +567,7 @@ def test_cli_tail_model_flag(tmp_path, po, oracle_models):
     from tksm_amd.sequence import Sequencer
     s = Sequencer(0)
     s.set_identity(84.0, 99.0, 5.5)
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     s.close()
     tm = po.TailModel(TAIL_MODEL)
     want = []
@@ -673,7 +674,7 @@ def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_mode
     b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
     bad = s.run(b, target="badread", fastq=True, compute_qual=True, seed=6).records()
     per = s.run(b, target="perfect", fastq=True, seed=6).records()
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     text = synthetic.mdf_text(m, list(ref))
     for i, (mid, ivs) in enumerate(po.mdf_generator(text.splitlines(keepends=True))):
         raw = po.splice(ref, ivs)
@@ -708,7 +709,7 @@ def test_bench_size_batch_sampled_reads_equal_the_oracle(po, oracle_models, kind
     rec, off = s.run(b, target="badread", fastq=True, compute_qual=True, seed=9).download()
     assert len(off) == n + 1 and int(off[-1]) == len(rec) and rec.count(b"\n") == 4 * n
     sel = np.unique(np.concatenate([np.arange(0, n, 499), [n - 1]]))
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     text = synthetic.mdf_text({**m, "reads": m["reads"][sel], "ids": m["ids"][sel]}, names)
     mols = list(po.mdf_generator(text.splitlines(keepends=True)))
     assert len(mols) == len(sel)
@@ -747,7 +748,7 @@ def test_other_shipped_models_bit_exact_vs_oracle(po, model, ident):
     s.set_identity(*ident)                                 # (mean, max, stdev)
     s.load_error_model(em_path)
     s.load_qscore_model(qs_path)
-    idt = po.Identities(ident[0], ident[2], ident[1], qtab=s.identity_tables()["qtab"])
+    idt = po.Identities(ident[0], ident[2], ident[1])
     for kind, n in (("bulk", 1500), ("scrna", 700)):
         m = synthetic.make_molecules(rs, lens, n, 900, 300, kind=kind)
         b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])

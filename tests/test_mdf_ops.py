@@ -219,7 +219,7 @@ def test_config5_pipeline_pcr_truncation_seq_on_device(gseq, mo, po, oracle_mode
     s.load_qscore_model(QS_MODEL)
     perfect = s.run(b2, target="perfect", fastq=True, seed=5).records()
     bad = s.run(b2, target="badread", fastq=True, compute_qual=True, seed=5).records()
-    ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+    ident = po.Identities(84.0, 5.5, 99.0)
     gen = list(po.mdf_generator(mo.write_mdf(mols).splitlines(keepends=True)))
     assert len(gen) == len(perfect) == len(bad)
     for i, (mid, ivs) in enumerate(gen):

@@ -28,7 +28,7 @@ def init(model):
 def work(job):
     kind, lo, hi = job
     po = _W["po"]
-    rs = np.random.RandomState(1000003 * (hash(kind) % 1000) + lo)
+    rs = np.random.RandomState(1000003 * {"bulk": 1, "scrna": 2, "lognormal": 3}[kind] + lo)      # (a fixed number per workload: str hashes differ from process to process)
     out = dict(n=0, seq=0, ident=0, errors=0, qual=0, qual_pos=0, bases=0, band_fail=0, maxd=0.0)
     for r in range(lo, hi):
         if kind == "bulk":

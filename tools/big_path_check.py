@@ -16,7 +16,7 @@ t = time.time(); recs = s.run(s.batch_from_mdf(text), target="badread", fastq=Tr
 ist, dst = recs.stats()
 print("status words:", [int(x) for x in ist[:, 7]], flush=True)
 em = po.ErrorModel(os.path.join(md, "nanopore2020.error.gz")); qm = po.QScoreModel(os.path.join(md, "nanopore2020.qscore.gz"))
-ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+ident = po.Identities(84.0, 5.5, 99.0)
 for i, (mid, ivs) in enumerate(po.mdf_generator(text.splitlines(keepends=True))):
     want, st = po.badread_record(True, 11, i, po.splice({"big": big}, ivs), ident, em, qm, True, mid)
     a, b = out[i].split(b"\n"), want.split(b"\n")

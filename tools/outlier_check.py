@@ -27,7 +27,7 @@ for rep in range(2):
 recs = r.records()
 ref = {nm: c.decode() for nm, c in zip(names, contigs)}
 em = po.ErrorModel(os.path.join(md, "nanopore2020.error.gz")); qm = po.QScoreModel(os.path.join(md, "nanopore2020.qscore.gz"))
-ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+ident = po.Identities(84.0, 5.5, 99.0)
 mols = list(po.mdf_generator(text.splitlines(keepends=True)))
 bad = 0
 for i in list(range(0, n, max(1, n // 40))) + [n]:
