@@ -44,6 +44,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_SMALL_ROUND")) c->small_round = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_WAVE_LOOP")) c->wave_loop = (uint32_t)atoi(tc);
+    if (const char* tc = getenv("TKSMSEQ_FUSED")) c->fused = tc[0] != '0';
     if (const char* tc = getenv("TKSMSEQ_ALN_LDS_PAD")) c->aln_lds_pad = (unsigned)std::min(60000, std::max(0, atoi(tc)));
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
@@ -749,6 +750,11 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_redo.ensure(jcap * 4 + 64));
         // pool of full-width rows: as many as a round can ask for, at most 4 GB (homopolymer-rich batches need many)
         FB.full_tg = (((uint32_t)ncap + 31) & ~31u) / 4 + 1;
+        if (ctx->fused) {
+            // code lines (4 iterations each; whole passes of 16 iterations, some room for drain passes), one uint4 of shift bytes per pass, a spare line
+            FB.full_cl = ((((uint32_t)ncap + 31) & ~31u) / 4 + 16 + 3) & ~3u;
+            FB.full_tg = FB.full_cl + (FB.full_cl / 4 + 3) / 4 + 1;
+        }
         FB.full_rows = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(jcap, (4ull << 30) / ((uint64_t)FB.full_tg * 64)) & ~63ull);
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * FB.full_tg * 64 + 64));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
@@ -884,7 +890,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 // against the whole fragment (k_qjobs + k_job, then k_aln below); without: their output, in this one round
                 if (P.compute_q) {
                     HIPCHK(ctx, tk::launch_qjobs(FB, k, n_deferred, s));
-                    HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
+                    if (!ctx->fused) HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
                 } else {
                     const Bucket& bk = buckets.back();
                     HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, n_deferred, bk.lcap, bk.ncap, 2, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
@@ -918,7 +924,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 else HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
                 if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
                 kinds.push_back(1);
-                HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
+                if (!ctx->fused) HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
                 regular = true;
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
@@ -965,7 +971,12 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             if (rounds > 100000) { ctx->err = "internal: error loop did not terminate"; return TKSMSEQ_EDEVICE; }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(-1);
-            HIPCHK(ctx, tk::launch_aln(P, FB, hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u), cnt[0] <= std::min(ctx->small_aln, FB.full_rows), qround ? 1 : 0, ctx->aln_lds_pad, s));
+            {
+                const uint32_t n_jobs = hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u);
+                const bool full_only = cnt[0] <= std::min(ctx->small_aln, FB.full_rows);
+                if (ctx->fused) HIPCHK(ctx, tk::launch_alnf(P, FB, O, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, s));
+                else HIPCHK(ctx, tk::launch_aln(P, FB, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, s));
+            }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);
             // next round: its jobs are packed by this round's counts (a read has at most one job per round)
@@ -979,11 +990,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
         mark("rounds done");
         if (getenv("TKSMSEQ_VERBOSE")) {
-            uint32_t cc[16];
-            HIPCHK(ctx, hipMemcpy(cc, FB.counters, 64, hipMemcpyDeviceToHost));
+            uint32_t cc[32];
+            HIPCHK(ctx, hipMemcpy(cc, FB.counters, 128, hipMemcpyDeviceToHost));
             fprintf(stderr, "[tksmseq] this thread so far: %u device allocations, %.3f s in hipMalloc\n", alloc_calls(), alloc_seconds());
             fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
                     (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);
+            fprintf(stderr, "[tksmseq] fused alignment failures: %u, reasons or-ed 0x%x, last 0x%x (n %u, m %u)\n", cc[12], cc[13], cc[14], cc[15] & 0xffffu, cc[15] >> 16);
+            fprintf(stderr, "[tksmseq]   per reason: npend %u upos %u ev %u sh>31 %u sh>14 %u end cell %u walk %u | q-score jobs %u, list pass %u\n", cc[16], cc[17], cc[18], cc[19], cc[20], cc[21], cc[22], cc[24], cc[25]);
         }
         for (int k2 = 0; k2 < tksmseq_ctx::N_SIDE; k2++)
             if (ctx->side_used[k2]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_done[k2], 0));

@@ -124,6 +124,7 @@ struct tksmseq_ctx : ContigLookup {
     uint32_t* h_round = nullptr; size_t h_round_bytes = 0;
     uint8_t* h_geo = nullptr; size_t h_geo_bytes = 0;
     bool force_slow = false;
+    bool fused = true;          // windows decoded inside the alignment kernel (k_alnf); false: k_job + k_aln (round 2), for A/B runs
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t wave_loop = 16384;           // rounds with at most this many reads left run the error loop one wave per read (k_loopw)
     unsigned aln_lds_pad = 16384;         // LDS the first alignment pass asks for without using it: caps its waves per CU (kernels.hip launch_aln)

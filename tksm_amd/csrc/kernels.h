@@ -160,6 +160,7 @@ struct FastBuffers {
     uint32_t* redo_list;              // jobs whose path left the stored rows of pass 1 (counters[10] of them): 64-row pass
     void* trace_full;                 // pool of the passes that store all 64 rows (16 bytes per column, 4 columns per line): [wave][full_tg lines][lane]; counters[3] allocates
     uint32_t full_rows, full_tg;      // jobs the full-width pool holds (multiple of 64), lines per job (4 columns each)
+    uint32_t full_cl;                 // fused alignment (k_alnf): of a job's full_tg lines the first full_cl hold codes, the shift bytes follow, the last one is spare
     uint32_t* counters;               // [2] reads on the slow list, [3] rows taken from the full-width pool, [4..9] diagnostics, [10] jobs on redo_list
     uint32_t* job_cnt;                // [n_ranges] jobs of this round per range of rs reads, one counter per 128 B
     uint32_t rs, n_ranges;
@@ -214,6 +215,8 @@ hipError_t launch_round_reset(const FastBuffers& fb, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
 // mode: 0 = the round's jobs are identity re-estimations, 1 = q-score alignments (all jobs of a round have one mode)
 hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s);
+// the fused form (round 3): windows decoded from the slot codes inside the alignment kernel, no k_job
+hipError_t launch_alnf(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s);
 hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s);
 hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,
                           uint32_t max_raw, int n_cus, hipStream_t s);

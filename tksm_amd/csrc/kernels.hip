@@ -2298,6 +2298,9 @@ DEV void list_append(uint32_t* list, uint32_t* counter, bool want, uint32_t job,
 #ifndef ALN_WAVES
 #define ALN_WAVES 4
 #endif
+#ifndef ALNF_WAVES
+#define ALNF_WAVES 3
+#endif
 template <int MODE, int ROWS, bool LIST>
 __global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
     const int lane = threadIdx.x;
@@ -2358,6 +2361,415 @@ __global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers 
             load_job(FB, job, rng, act, J, r);
             const AlnRes R = aln_fast<MODE, ROWS>(J, wave_max(act ? J.m : 0), trl, tg, 256u, P.ablate);
             if (act) store_result(FB, r, R);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_alnf (round 3): window packing FUSED into the alignment -- no k_job, no block records, no job_win.
+// One lane per alignment job as in k_aln, but the lanes of a wave walk their windows SLOT BY SLOT in lockstep (as k_job did):
+// in iteration s every lane decodes slot s of its own window straight from the read's slot codes (32 codes = one 64-byte line
+// per 32 iterations, unconditional, prefetched one chunk ahead) and pushes the slot's 0 .. 5 columns into per-lane bit queues
+// (symbol low / high bit, and a unary slot stream: a 0 per slot boundary, a 1 per column); then it pops ONE column, if it has
+// one, and runs the bit-parallel column step on it.  The window shift of a column follows from the slot it belongs to
+// (top = max(1, slot + 1 - 31)), which the pop reads off the unary stream -- no shift queue.  Lanes whose windows hold more
+// columns than slots fall behind by their backlog (a few columns); a chunk of 32 pop-only iterations drains them when a
+// backlog passes BACKLOG_DRAIN columns and after the last slot.  The 32 .. 64 fragment rows below the window wait in a 64-bit
+// reservoir per plane, refilled by 32 rows at the end of every chunk (same position for all lanes: unconditional loads).
+// Predecessor codes are stored PER ITERATION (the iteration index is wave-uniform, the column index is not): one u32 per
+// iteration = 14 band rows x 2 bits + the column's window shift (4 bits; 15 + codes 0 = no column in this iteration, all ones
+// = a shift the field cannot hold: full-width pass, then the exact kernel), so the walk back needs nothing but its code
+// lines.  14 rows (band rows 24 .. 37, offsets -7 .. +6 from the generative row) miss 1.9 % of the bulk and 5.4 % of the
+// polyA-tailed alignments (tools/band_rows.py on the CPU oracle; 16 rows: 0.9 % / 3.1 %); those are redone with all 64 rows stored
+// (two u64 per iteration, shift in their top bits) from the redo list.
+// HBM traffic per column: 2 B slot codes + 0.25 B planes in, 4 B codes out and 4 B in again = 10.25 B
+// (k_job + k_aln: 2.25 + 2 and 2 + 4 + 4 + 2 = 16.25 B).
+constexpr uint32_t ENT_EMPTY = 0xF0000000u, ENT_ESC = 0xFFFFFFFFu;
+constexpr int BACKLOG_DRAIN = 20;
+struct AlnJobF {
+    bool act; int p0, n;
+    const uint16_t* nb;                 // the read's slot codes (start of its row)
+    const ulonglong2* fp; int wlast;    // the read's fragment planes, {lo, hi} per 64 positions; index of the last pair
+    unsigned long long* popd8;          // q-score jobs: the job's op bytes
+};
+struct AlnResF { uint32_t mt, cols; int m; bool fail, needfull, overflow; uint32_t why; };
+
+template <int MODE, int ROWS>
+DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls, int mcap) {
+    static_assert(ROWS == 14 || ROWS == 64, "14 stored rows, or all of them");
+    constexpr int NC = ROWS == 14 ? 16 : 4;                       // iterations per 64-byte line of codes
+    constexpr int LPC = 32 / NC;                                  // lines per chunk of 32 iterations
+    constexpr int ST = ROWS == 14 ? 24 : 0;                       // first stored band row once the window moves
+    constexpr int RAMP0 = 31 - ST;
+    const bool act = J.act;
+    const int n = act ? J.n : 0;
+    const int base = J.p0 & ~1, skip = J.p0 - base;               // slot codes are fetched from an even position
+    const int nmax = wave_max(act ? n + skip : 0);
+    // ---- fragment planes as a stream aligned to `base` (x = position - base): word j = x in [64 j, 64 j + 64)
+    const int wb = base >> 6, bsh = base & 63;
+    auto fpw = [&](int w) { return J.fp[min(max(w, 0), J.wlast)]; };
+    auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 v; v.x = funnel128(a.x, b.x, bsh); v.y = funnel128(a.y, b.y, bsh); return v; };
+    ulonglong2 Wc, Wn, Rl, Rn;                                    // words jc, jc + 1 (jc = s0 >> 6); raw word behind Wn; next raw word (in flight)
+    {
+        const ulonglong2 r0 = fpw(wb), r1 = fpw(wb + 1), r2 = fpw(wb + 2);
+        Wc = aligned(r0, r1); Wn = aligned(r1, r2);
+        Rl = r2; Rn = fpw(wb + 3);
+    }
+    int jc = 0;
+    // the window's 64 rows (x in [skip, skip + 64)) and the reservoir of the rows below it (x from 64 + skip on: `ev` of them valid);
+    // planes kept COMPLEMENTED (see aln_fast).  At the end of the 32 slots from s0 the reservoir takes x in [64 + s0, 96 + s0) --
+    // half a word of the aligned stream, the same for every lane (the first time a lane with skip = 1 drops the row its window
+    // has already) -- so that the rows a column can need (x <= slot + 32) are always there.
+    unsigned long long A = ~funnel128(Wc.x, Wn.x, skip), B = ~funnel128(Wc.y, Wn.y, skip);
+    unsigned long long EA = 0ull, EB = 0ull;
+    int ev = 0;
+    unsigned long long Pv = ~0ull, Mv = 0ull;
+    int t = 1, t32 = 1;
+    // ---- queues
+    uint32_t qlo = 0u, qhi = 0u;
+    unsigned long long U = 0ull;
+    int npend = 0, upos = 0, pcol = -1 - skip, col = 0, col32 = 0, shmax = 0;
+    bool bad = false;
+    uint32_t why = 0u;
+    // ---- slot codes: 16 slots (32 bytes) at a time, the next 16 in flight
+    struct __attribute__((packed, aligned(4))) U4b { uint32_t x, y, z, w; };
+    uint32_t cw[8], cwn[8];
+    auto load_codes = [&](int s, uint32_t (&d)[8]) {
+        const int src = (s <= n + skip) ? base + s : base;        // (lanes past their window re-read its start)
+        const U4b* cp = reinterpret_cast<const U4b*>(J.nb + src);
+        const U4b c0 = cp[0], c1 = cp[1];
+        d[0] = c0.x; d[1] = c0.y; d[2] = c0.z; d[3] = c0.w; d[4] = c1.x; d[5] = c1.y; d[6] = c1.z; d[7] = c1.w;
+    };
+    load_codes(0, cw);
+    constexpr int HS = 16;                                        // slots (iterations) per pass of the loop below
+    constexpr int LPH = HS / NC;                                  // lines of codes per pass
+    uint32_t tw[16], shw[4] = {0u, 0u, 0u, 0u};
+    int ql = 0;                                                   // lines written (wave-uniform)
+    bool ovf = false;
+    int s0 = 0;
+    for (;;) {
+        const bool more = s0 < nmax;
+        const bool drain = __ballot(npend > (more ? BACKLOG_DRAIN : 0)) != 0ull;
+        if (!more && !drain) break;
+        if (ql + LPH > (ROWS == 64 ? cl : tg - 1)) { ovf = true; break; }             // the job's lines are used up (drain passes of an insertion-heavy window)
+        if (!drain) load_codes(s0 + HS, cwn);
+        const uint32_t olo = (uint32_t)(Wc.x >> (s0 & 48)), ohi = (uint32_t)(Wc.y >> (s0 & 48));   // the 16 original bases
+        const int inc = drain ? 0 : 1;
+        // (idle lanes write the job's spare line: with the lines of fewer than 64 jobs interleaved -- the full-width pool -- theirs
+        // are another lane's)
+        uint4* const dl = trl + (size_t)(act ? ql : tg - 1) * ls;
+#pragma unroll
+        for (int q = 0; q < HS; q++) {
+            // ---- push slot s0 + q
+            const int p = s0 + q - skip;
+            const bool on = !drain && act && (uint32_t)p < (uint32_t)n;
+            const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+            const int len = on ? (code ? (int)((code >> 12) & 7u) : 1) : 0;
+            const uint32_t m5 = (1u << len) - 1u;
+            const uint32_t lo5 = (code ? code : olo >> q) & m5, hi5 = (code ? code >> 5 : ohi >> q) & m5;
+            bad |= npend > 26 || upos > 57;
+            why |= (npend > 26 ? 1u : 0u) | (upos > 57 ? 2u : 0u);
+            qlo |= lo5 << npend; qhi |= hi5 << npend;
+            U |= (unsigned long long)(m5 << 1) << upos;
+            upos += len + inc; npend += len;
+            // ---- pop: slot boundaries in front of the next column, then the column itself
+            const uint32_t zz = U ? (uint32_t)__builtin_ctzll(U) : 64u;
+            const int zc = (int)min(zz, (uint32_t)upos);
+            pcol += zc;
+            const bool have = npend > 0;
+            const int used = zc + (have ? 1 : 0);
+            U >>= used; upos -= used;
+            uint32_t ent0 = ENT_EMPTY, ent1 = 0u, ent2 = 0u, ent3 = 0u, shb = 0xffu;     // (all rows: the entry's four words; shift byte 0xff = no column)
+            if (have) {
+                const int tn = max(1, pcol - 30);
+                const uint32_t sh = (uint32_t)(tn - t);
+                t = tn;
+                shmax = max(shmax, (int)sh);
+                const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)qlo, 0u, 1u), ch = (uint32_t)__builtin_amdgcn_sbfe((int)qhi, 0u, 1u);
+                qlo >>= 1; qhi >>= 1; npend--; col++;
+                const bool g = t > 1;
+                const uint32_t f = (sh == 0u && g) ? 1u : 0u;     // window did not move: top row only from the left
+                Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh) & ~f);
+                Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh) | f);
+                A = mk64(alignbit(lo32(EA), hi32(A), sh), alignbit(hi32(A), lo32(A), sh));
+                B = mk64(alignbit(lo32(EB), hi32(B), sh), alignbit(hi32(B), lo32(B), sh));
+                EA = mk64(hi32(EA) >> sh, alignbit(hi32(EA), lo32(EA), sh));
+                EB = mk64(hi32(EB) >> sh, alignbit(hi32(EB), lo32(EB), sh));
+                ev -= (int)sh;
+                const unsigned long long clm = mk64(cl, cl), chm = mk64(ch, ch);
+                const unsigned long long Eq = bool3<BOOL3(TA & (TB ^ TC))>(A ^ clm, B, chm);
+                const unsigned long long Xv = Eq | Mv;
+                const unsigned long long Xh = bool3<BOOL3((TA ^ TB) | TC)>((Eq & Pv) + Pv, Pv, Eq);
+                const unsigned long long Ph = bool3<BOOL3(TA | ~(TB | TC))>(Mv, Xh, Pv);
+                const unsigned long long Mh = Pv & Xh;
+                const unsigned long long D0 = Xh | Mv;
+                const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
+                const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
+                Pv = bool3<BOOL3(TA | ~(TB | TC))>(Mhs, Xv, Phs);
+                Mv = Phs & Xv;
+                const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
+                const unsigned long long w1 = bool3<BOOL3(~(TA | TB))>(upv, Ph, 0ull);
+                const unsigned long long w0 = MODE ? bool3<BOOL3(TB | (~TA & TC))>(upv, Ph, D0) : bool3<BOOL3(~TA & (TB | TC))>(upv, Ph, D0);
+                const uint32_t sh4 = min(sh, 15u);
+                if constexpr (ROWS == 14) {
+                    // stored rows st .. st + 13, st = clamp(iteration - RAMP0, 0, ST): a function of the iteration alone
+                    const uint32_t st = (uint32_t)(min(max(ql * NC + q, RAMP0), 31) - RAMP0);
+                    const uint32_t c0 = alignbit(hi32(w0), lo32(w0), st) & 0x3fffu, c1 = alignbit(hi32(w1), lo32(w1), st) & 0x3fffu;
+                    ent0 = sh >= 15u ? ENT_ESC : (c0 | (c1 << 14) | (sh4 << 28));
+                } else {
+                    ent0 = lo32(w0); ent1 = hi32(w0); ent2 = lo32(w1); ent3 = hi32(w1);
+                    shb = min(sh, 254u);
+                }
+            }
+            if constexpr (ROWS == 14) {
+                tw[q & 7] = ent0;
+                if ((q & 7) == 7) {                               // half a line at a time
+                    uint4* d = dl + 2 * (q >> 3);
+                    d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
+                }
+            } else {
+                tw[4 * (q & 3)] = ent0; tw[4 * (q & 3) + 1] = ent1; tw[4 * (q & 3) + 2] = ent2; tw[4 * (q & 3) + 3] = ent3;
+                shw[q >> 2] = (q & 3) == 0 ? shb : shw[q >> 2] | (shb << (8 * (q & 3)));
+                if ((q & 3) == 3) {
+                    uint4* d = dl + (act ? (size_t)(q >> 2) * ls : (size_t)0);
+                    d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
+                    d[2] = make_uint4(tw[8], tw[9], tw[10], tw[11]); d[3] = make_uint4(tw[12], tw[13], tw[14], tw[15]);
+                }
+            }
+        }
+        if constexpr (ROWS == 64) {
+            // the pass's 16 shift bytes: one uint4 behind the job's code lines (line cl + pass / 4)
+            const int pi = ql / LPH;
+            uint4* d = act ? trl + (size_t)(cl + (pi >> 2)) * ls + (pi & 3) : trl + (size_t)(tg - 1) * ls;
+            *d = make_uint4(shw[0], shw[1], shw[2], shw[3]);
+        }
+        ql += LPH;
+        if (ql * NC == 32) { t32 = t; col32 = col; }              // window position / columns after iteration 31 (the walk's clamped start)
+        if (!drain) {
+            if (s0 & 16) {
+                // the reservoir takes the 32 rows x in [64 + s0 - 16, 96 + s0 - 16): a half of the next aligned word
+                bad |= ev > 32 && s0 + HS - skip < n;
+                why |= (ev > 32 && s0 + HS - skip < n) ? 4u : 0u;              // (a lane past its last slot takes nothing from the reservoir any more)
+                const bool upper = ((s0 - 16) & 32) != 0;
+                const bool first = s0 == 16;
+                const uint32_t drop = first ? (uint32_t)skip : 0u;
+                const uint32_t na = ~(upper ? hi32(Wn.x) : lo32(Wn.x)) >> drop, nb2 = ~(upper ? hi32(Wn.y) : lo32(Wn.y)) >> drop;
+                EA |= (unsigned long long)na << (ev & 63); EB |= (unsigned long long)nb2 << (ev & 63);
+                ev += 32 - (int)drop;
+                if (upper) {                                      // the plane words follow the slot position
+                    jc++;
+                    Wc = Wn; Wn = aligned(Rl, Rn);
+                    Rl = Rn; Rn = fpw(wb + jc + 3);
+                }
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < 8; i2++) cw[i2] = cwn[i2];
+            s0 += HS;
+        }
+    }
+    const int m = col;
+    ovf = ovf || m > mcap;                                        // (the job's op bytes / the read's output slot hold mcap columns)
+    // ---- walk back from (n, m): all lanes in lockstep over the ITERATIONS (see aln_fast for the walk itself); an entry without a
+    // column is skipped by its lane, a lane joins at its own last column
+    bad = bad || shmax > 31;
+    why |= (shmax > 31 ? 8u : 0u) | (shmax > 14 ? 16u : 0u) | ((act && m > 0 && (n - t > 63 || n - t < 0)) ? 32u : 0u);
+    bool fail = act && m > 0 && (n - t > 63 || n - t < 0 || bad), needfull = false;
+    bool live = act && !fail && m > 0 && !ovf;
+    uint32_t mt = 0, dg = 0;
+    int bs = n - t - ST;
+    int i = n, tt = t;                                            // used below iteration 32 only
+    int c = m - 1;                                                // the lane's current column (q-score jobs: where its op byte goes)
+    unsigned long long acc = 0ull;
+    auto walk_ent = [&](int it, auto ramp, auto lo, auto hi, uint32_t shc, bool is_col, bool is_esc) {
+        constexpr bool RAMP = decltype(ramp)::value;
+        if (live && is_col) {
+            if (RAMP) bs = i - tt - (min(max(it, RAMP0), 31) - RAMP0);
+            uint32_t run, extra = 0u;
+            if constexpr (ROWS == 64) { extra = (uint32_t)max(bs - 63, 0); bs -= (int)extra; }      // virtual cells below the band: up
+            if constexpr (ROWS == 64) {
+                const unsigned long long y = (lo | hi) << ((63 - bs) & 63);
+                run = y ? (uint32_t)__builtin_clzll(y) : 64u;
+            } else {
+                const uint32_t y = (lo | hi) << ((31 - bs) & 31); // (the fields above bit bs are shifted out)
+                run = y ? (uint32_t)__builtin_clz(y) : 32u;
+            }
+            bool ok = (uint32_t)bs < (uint32_t)ROWS;
+            bool zero = false;
+            if (RAMP) {
+                run = min(run, (uint32_t)(bs + 1));               // (the shift filled the word with "up" bits below bit 0)
+                if (i == 0) { run = 0u; extra = 0u; }
+                zero = (uint32_t)i == run + extra || i == 0;      // the path reaches (or is in) row 0: this column and all before it are left moves
+                ok |= i == 0;
+            }
+            const int bs2 = bs - (int)run;
+            ok &= (bs2 >= 0 || zero) && !is_esc;
+            const uint32_t lb = zero ? 1u : (uint32_t)(lo >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;
+            const uint32_t hb = zero ? 0u : (uint32_t)(hi >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;     // lb | hb << 1: 1 left, 2 diagonal mismatch, 3 diagonal match
+            needfull |= !ok;
+            live = ok && !zero;
+            mt += hb & lb;
+            dg += hb;
+            if (MODE) {
+                const uint32_t op = hb ? (lb ^ 1u) : 2u;          // 0 match, 1 mismatch, 2 read-only base; the run = fragment-only bases in front
+                acc |= (unsigned long long)(op | (min(run + extra, 63u) << 2)) << (8 * (c & 7));
+                if (zero) {
+                    // only left moves remain: the rest of this group and every group before it
+                    acc |= 0x0202020202020202ull & ((1ull << (8 * (c & 7))) - 1ull);
+                    J.popd8[c >> 3] = acc; acc = 0ull;
+                    for (int b2 = (c >> 3) - 1; b2 >= 0; b2--) J.popd8[b2] = 0x0202020202020202ull;
+                } else if ((c & 7) == 0) { J.popd8[c >> 3] = acc; acc = 0ull; }
+                c--;
+            }
+            if (RAMP) { i -= (int)(run + extra + hb); tt -= (int)shc; }
+            else bs = bs2 - (int)hb + (int)shc;
+        }
+    };
+    uint4 la0, la1, la2, la3, lb0, lb1, lb2, lb3;
+    auto load_line = [&](int q, uint4& l0, uint4& l1, uint4& l2, uint4& l3) {
+        const uint4* p = trl + (size_t)max(q, 0) * ls;
+        l0 = p[0]; l1 = p[1]; l2 = p[2]; l3 = p[3];
+    };
+    uint4 sw = make_uint4(0u, 0u, 0u, 0u), swn = sw;               // all rows: the shift bytes of the current pass, of the pass below it
+    auto load_shifts = [&](int pi) { return trl[(size_t)(cl + (max(pi, 0) >> 2)) * ls + (max(pi, 0) & 3)]; };
+    auto walk_line = [&](int q, const uint4& l0, const uint4& l1, const uint4& l2, const uint4& l3) {
+        const uint32_t w[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+        const int cq = q * NC;
+        uint32_t swq = 0u;
+        if constexpr (ROWS == 64) {
+            if ((q & 3) == 3) { sw = swn; swn = load_shifts((q >> 2) - 1); }
+            swq = (q & 3) == 0 ? sw.x : (q & 3) == 1 ? sw.y : (q & 3) == 2 ? sw.z : sw.w;
+        }
+        auto ents_of_line = [&](auto ramp) {
+#pragma unroll
+            for (int e = NC - 1; e >= 0; e--) {
+                if constexpr (ROWS == 14) {
+                    const uint32_t v = w[e];
+                    walk_ent(cq + e, ramp, v, v >> 14, v >> 28, v != ENT_EMPTY, v == ENT_ESC);
+                } else {
+                    const uint32_t shc = (swq >> (8 * e)) & 0xffu;
+                    walk_ent(cq + e, ramp, mk64(w[4 * e + 1], w[4 * e]), mk64(w[4 * e + 3], w[4 * e + 2]), shc, shc != 0xffu, false);
+                }
+            }
+        };
+        if (cq >= 32) ents_of_line(std::false_type{});
+        else {
+            if (cq == 32 - NC && m > col32) { tt = t32; i = bs + t32 + ST; }      // leaving the iterations where only bs is tracked
+            ents_of_line(std::true_type{});
+        }
+    };
+    if (ql > 0) {
+        const int topq = ql - 1;
+        if constexpr (ROWS == 64) swn = load_shifts(topq >> 2);
+        load_line(topq, la0, la1, la2, la3);
+        for (int q = topq; q >= 0; q -= 2) {
+            load_line(q - 1, lb0, lb1, lb2, lb3);
+            walk_line(q, la0, la1, la2, la3);
+            if (q > 0) {
+                load_line(q - 2, la0, la1, la2, la3);
+                walk_line(q - 1, lb0, lb1, lb2, lb3);
+            }
+        }
+    }
+    AlnResF R;
+    R.mt = mt; R.cols = (uint32_t)(n + m) - dg; R.m = m;
+    R.fail = fail || (ROWS == 64 && needfull); R.needfull = ROWS != 64 && needfull; R.overflow = act && ovf;
+    R.why = why | (needfull ? 64u : 0u) | ((uint32_t)min(max(bs + 8, 0), 255) << 8);
+    return R;
+}
+
+DEV void load_job_f(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act, AlnJobF& J, uint32_t& r, int& mcap) {
+    J.act = act;
+    r = 0;
+    J.p0 = 0; J.n = 0;
+    if (act) {
+        const uint4 meta = *reinterpret_cast<const uint4*>(FB.job_meta + 4ull * job);
+        r = meta.x; J.p0 = (int)meta.y; J.n = (int)(meta.z & 0x7fffffffu);
+    }
+    const RangeGeo G = FB.geo_cur[rng];
+    const uint32_t rel = job - FB.base_cur[rng];
+    J.nb = nb_row(FB, r);
+    J.fp = reinterpret_cast<const ulonglong2*>(planes_row(FB, r));
+    J.wlast = planes_words(FB, r) - 1;
+    J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + G.popd_off + (size_t)rel * G.ncap);
+    mcap = (int)G.ncap;
+}
+// what k_job did for a window that outgrew its rows (insertion-heavy read): the host reruns the batch with larger slots
+DEV void job_overflow(const FastBuffers& FB, const SimBuffers& O, uint32_t r) {
+    O.status[r] |= 1u; O.out_len[r] = 0; O.rec_len[r] = 0; O.identity[r] = 0.0;
+    FB.state[r].stage = 2;
+}
+DEV void store_result_f(const FastBuffers& FB, uint32_t r, const AlnResF& R) {
+    ReadState* st = FB.state + r;
+    st->res_mt = R.mt; st->res_cols = R.cols; st->res_fail = (R.fail || R.needfull) ? 1u : 0u;
+}
+
+// Alignment passes of a round (launch_alnf): pass 1 = every job with 14 stored rows (ROWS 14, LIST false); pass 2 = the jobs whose
+// path left them (counters[10] of them in redo_list) with all 64 rows, lines in the full-width pool: a fixed grid whose waves loop over
+// the list.  Rounds with few jobs are bound by the latency of one lane's pass: all their jobs go straight to the 64-row version
+// (LIST false; counters[3] allocates pool lines per wave).
+template <int MODE, int ROWS, bool LIST>
+__global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
+    const int lane = threadIdx.x;
+    if (!LIST) {
+        const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
+        const uint32_t rng = range_of_job(FB, job0);
+        const uint32_t rbase = FB.base_cur[rng];
+        const uint32_t in_rng = FB.job_cnt[rng * 32u];
+        if (in_rng <= job0 - rbase) return;                           // whole wave beyond the range's job count
+        AlnJobF J;
+        uint32_t r;
+        bool act = job < n_jobs && job - rbase < in_rng;
+        uint4* trl;
+        int tg, mcap;
+        bool norow = false;
+        uint32_t ls = 256u;
+        if (ROWS == 64) {
+            // pool lines for the wave's jobs only (long molecules: a job's lines are megabytes)
+            const unsigned long long wm = __ballot(act);
+            const uint32_t na = (uint32_t)__popcll(wm);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&FB.counters[3], na);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + na > FB.full_rows) { norow = act; act = false; base = 0; }    // no pool lines left: reported as failures (the wave-wide kernel takes the reads)
+            tg = (int)FB.full_tg;
+            ls = 4u * max(na, 1u);
+            trl = reinterpret_cast<uint4*>(FB.trace_full) + ((size_t)base * FB.full_tg + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull)) % max(na, 1u)) * 4;
+        } else {
+            const RangeGeo G = FB.geo_cur[rng];
+            const uint32_t rel = job - rbase;
+            tg = (int)G.tstride;
+            trl = reinterpret_cast<uint4*>(FB.trace) + (G.trace_off + (size_t)(rel >> 6) * G.tstride * 64 + (rel & 63u)) * 4;
+        }
+        load_job_f(FB, job, rng, act || norow, J, r, mcap);
+        J.act = act;
+        AlnResF R = aln_fused<MODE, ROWS>(J, trl, tg, (int)FB.full_cl, ls, mcap);
+        if (norow) { R.fail = true; R.needfull = false; R.overflow = false; }
+        if (act && R.overflow) { job_overflow(FB, O, r); return; }
+        if (ROWS != 64) list_append(FB.redo_list, FB.counters + 10, act && R.needfull, job, lane);
+        if ((act || norow) && !R.needfull) store_result_f(FB, r, R);
+        if (act && R.fail) { atomicAdd(&FB.counters[12], 1u); atomicOr(&FB.counters[13], R.why & 255u); FB.counters[14] = R.why; FB.counters[15] = (uint32_t)J.n | ((uint32_t)R.m << 16);
+              for (int b = 0; b < 8; b++) if ((R.why >> b) & 1u) atomicAdd(&FB.counters[16 + b], 1u); if (MODE) atomicAdd(&FB.counters[24], 1u); if (LIST) atomicAdd(&FB.counters[25], 1u); }
+    } else {
+        static_assert(!LIST || ROWS == 64, "the list holds the jobs of the full-width pass");
+        const uint32_t n_list = FB.counters[10];
+        if (lane == 0 && blockIdx.x == 0 && n_list) { atomicAdd(&FB.counters[8], n_list); atomicAdd(&FB.counters[9], (n_list + 63u) / 64u); }   // diagnostics
+        const uint32_t* list = FB.redo_list;
+        const int tg = (int)FB.full_tg;
+        uint4* trl = reinterpret_cast<uint4*>(FB.trace_full) + ((size_t)blockIdx.x * tg * 64 + (uint32_t)lane) * 4;
+        for (uint32_t base = blockIdx.x * 64u; base < n_list; base += gridDim.x * 64u) {     // wave-uniform: every wave ends
+            const uint32_t idx = base + (uint32_t)lane;
+            const bool act = idx < n_list;
+            const uint32_t job = list[min(idx, n_list - 1u)];                               // (idle lanes shadow the last job)
+            const uint32_t rng = range_of_job(FB, job);
+            AlnJobF J;
+            uint32_t r;
+            int mcap;
+            load_job_f(FB, job, rng, act, J, r, mcap);
+            const AlnResF R = aln_fused<MODE, ROWS>(J, trl, tg, (int)FB.full_cl, 256u, mcap);
+            if (act && R.overflow) job_overflow(FB, O, r);
+            else if (act) store_result_f(FB, r, R);
+            if (act && R.fail) { atomicAdd(&FB.counters[12], 1u); atomicOr(&FB.counters[13], R.why & 255u); FB.counters[14] = R.why; FB.counters[15] = (uint32_t)J.n | ((uint32_t)R.m << 16);
+              for (int b = 0; b < 8; b++) if ((R.why >> b) & 1u) atomicAdd(&FB.counters[16 + b], 1u); if (MODE) atomicAdd(&FB.counters[24], 1u); if (LIST) atomicAdd(&FB.counters[25], 1u); }
         }
     }
 }
@@ -2890,6 +3302,24 @@ hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs
     } else {
         hipLaunchKernelGGL((k_aln<0, 16, false>), dim3(waves), dim3(64), lds_pad, s, p, fb, n_jobs);
         hipLaunchKernelGGL((k_aln<0, 64, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_alnf(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s) {
+    if (!n_jobs) return hipSuccess;
+    const uint32_t waves = (n_jobs + 63) / 64;
+    if (full_only) {
+        if (mode) hipLaunchKernelGGL((k_alnf<1, 64, false>), dim3(waves), dim3(64), 0, s, p, fb, o, n_jobs);
+        else hipLaunchKernelGGL((k_alnf<0, 64, false>), dim3(waves), dim3(64), 0, s, p, fb, o, n_jobs);
+        return hipGetLastError();
+    }
+    const uint32_t g2 = std::max<uint32_t>(1u, std::min<uint32_t>((waves + 7) / 8, std::max<uint32_t>(1u, fb.full_rows / 64)));
+    if (mode) {
+        hipLaunchKernelGGL((k_alnf<1, 14, false>), dim3(waves), dim3(64), lds_pad, s, p, fb, o, n_jobs);
+        hipLaunchKernelGGL((k_alnf<1, 64, true>), dim3(g2), dim3(64), 0, s, p, fb, o, n_jobs);
+    } else {
+        hipLaunchKernelGGL((k_alnf<0, 14, false>), dim3(waves), dim3(64), lds_pad, s, p, fb, o, n_jobs);
+        hipLaunchKernelGGL((k_alnf<0, 64, true>), dim3(g2), dim3(64), 0, s, p, fb, o, n_jobs);
     }
     return hipGetLastError();
 }
