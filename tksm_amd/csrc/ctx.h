@@ -127,7 +127,7 @@ struct tksmseq_ctx : ContigLookup {
     bool fused = true;          // windows decoded inside the alignment kernel (k_alnf); false: k_job + k_aln (round 2), for A/B runs
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t wave_loop = 16384;           // rounds with at most this many reads left run the error loop one wave per read (k_loopw)
-    unsigned aln_lds_pad = 16384;         // LDS the first alignment pass asks for without using it: caps its waves per CU (kernels.hip launch_aln)
+    unsigned aln_lds_pad = 0;             // LDS the first alignment pass asks for without using it: caps its waves per CU (kernels.hip launch_aln)
     uint32_t small_round = 16384, small_aln = 131072;   // rounds with fewer reads are latency-bound: merged launches, full-width alignment
     uint32_t n_buckets = 16;
     int defer_len = 0;          // reads longer than this align for their q-scores after the regular rounds, all together

@@ -139,6 +139,7 @@ DEV uint8_t ref_base(const RefView& R, uint64_t g) {
     return base_char((int)(w >> ((g & 15) * 2)));
 }
 
+// (k_simulate's own LDS slot codes; the fast pipeline's st_nb: 0x1000 | planar symbol while pristine, bit 15 set once changed)
 // slot code (u16) of new_fragment_bases[p]: 0 = pristine (the original byte).  Otherwise
 // bit15 = 1, bits 14..12 = length (0..5), bits 11..10 = 1 + index of the symbol that is the
 // ORIGINAL byte (0 = none), bits 9..0 = 2-bit base codes, symbol x at bits 2x.
@@ -991,6 +992,27 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
         c.x = ((c.x >> 1) ^ (c.x >> 2)) & 0x03030303u; c.y = ((c.y >> 1) ^ (c.y >> 2)) & 0x03030303u;
         *reinterpret_cast<uint2*>(gfrag + t) = c;
     }
+    // the slot codes start out pristine: length 1, the original base as the slot's only symbol, bit 15 (changed) clear -- so that the
+    // alignment kernel decodes every slot the same way (k_alnf); 8 slots (16 bytes) per lane and step
+    {
+        uint16_t* gnb0 = nb_row(FB, r);
+        for (int t = 8 * lane; t < L; t += 512) {
+            uint2 c = *reinterpret_cast<const uint2*>(frag + t);
+            c.x = ((c.x >> 1) ^ (c.x >> 2)) & 0x03030303u; c.y = ((c.y >> 1) ^ (c.y >> 2)) & 0x03030303u;
+            auto two = [](uint32_t b0, uint32_t b1) {            // two slot codes from two 2-bit base codes: 0x1000 | low bit | high bit << 5
+                return (0x1000u | (b0 & 1u) | ((b0 >> 1) << 5)) | ((0x1000u | (b1 & 1u) | ((b1 >> 1) << 5)) << 16);
+            };
+            uint4 o;
+            o.x = two(c.x & 3u, (c.x >> 8) & 3u); o.y = two((c.x >> 16) & 3u, (c.x >> 24) & 3u);
+            o.z = two(c.y & 3u, (c.y >> 8) & 3u); o.w = two((c.y >> 16) & 3u, (c.y >> 24) & 3u);
+            if (t + 8 > L) {                                      // slots past the fragment stay zero
+                const int keep = L - t;
+                uint32_t* ow = &o.x;
+                for (int x2 = 0; x2 < 8; x2++) if (x2 >= keep) ow[x2 >> 1] &= (x2 & 1) ? 0x0000ffffu : 0xffff0000u;
+            }
+            *reinterpret_cast<uint4*>(gnb0 + t) = o;
+        }
+    }
     // ... and once more packed, 16 bases per word with the first base in the top bits, for the error loop (k_loop cuts a
     // k-mer's table index out of two consecutive words); bases past L are zero
     {
@@ -1100,7 +1122,7 @@ DEV SlotEval eval_draw(const uint16_t* nb, int k, int i, const uint4& A, bool ac
         for (int jj = 0; jj < 8; jj++) {
             if (jj < k) {
                 const uint32_t e = draw_slot(A, jj);
-                if ((e >> 15) && nb[i + jj] == 0) r.am |= 1u << jj;
+                if ((e >> 15) && (nb[i + jj] & 0x8000u) == 0) r.am |= 1u << jj;
                 r.lens |= ((e >> 12) & 7u) << (3 * jj);
             }
         }
@@ -1351,7 +1373,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                         dm &= dm - 1u;
                         const int ent = jj + odd, wi = ent >> 1;
                         const uint32_t cw2 = wi == 0 ? nbw[b].v[0] : wi == 1 ? nbw[b].v[1] : wi == 2 ? nbw[b].v[2] : wi == 3 ? nbw[b].v[3] : nbw[b].v[4];
-                        if (((cw2 >> (16 * (ent & 1))) & 0xffffu) == 0u) {
+                        if (((cw2 >> (16 * (ent & 1))) & 0x8000u) == 0u) {              // still pristine (bit 15: changed)
                             const uint32_t e = draw_slot(A, jj);
                             gnb[di[b] + jj] = (uint16_t)(e | 0x8000u);
                             wrote |= 1u << b;
@@ -1552,7 +1574,7 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
             while (dms) {
                 const int jj = __builtin_ctz(dms);
                 dms &= dms - 1u;
-                if (nbl[ai + jj] == 0) {
+                if ((nbl[ai + jj] & 0x8000u) == 0) {
                     const uint32_t e = draw_slot(As, jj);
                     if (lane == 0) { nbl[ai + jj] = (uint16_t)(e | 0x8000u); gnb[ai + jj] = (uint16_t)(e | 0x8000u); }
                     change_count++;
@@ -2409,10 +2431,13 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     const int wb = base >> 6, bsh = base & 63;
     auto fpw = [&](int w) { return J.fp[min(max(w, 0), J.wlast)]; };
     auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 v; v.x = funnel128(a.x, b.x, bsh); v.y = funnel128(a.y, b.y, bsh); return v; };
-    ulonglong2 Wc, Wn, Rl, Rn;                                    // words jc, jc + 1 (jc = s0 >> 6); raw word behind Wn; next raw word (in flight)
+    ulonglong2 Wn, Rl, Rn;                                        // word jc + 1 (jc = s0 >> 6); raw word behind it; next raw word (in flight)
+    unsigned long long A, B;
     {
         const ulonglong2 r0 = fpw(wb), r1 = fpw(wb + 1), r2 = fpw(wb + 2);
-        Wc = aligned(r0, r1); Wn = aligned(r1, r2);
+        const ulonglong2 W0 = aligned(r0, r1);
+        Wn = aligned(r1, r2);
+        A = ~funnel128(W0.x, Wn.x, skip); B = ~funnel128(W0.y, Wn.y, skip);
         Rl = r2; Rn = fpw(wb + 3);
     }
     int jc = 0;
@@ -2420,7 +2445,6 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     // planes kept COMPLEMENTED (see aln_fast).  At the end of the 32 slots from s0 the reservoir takes x in [64 + s0, 96 + s0) --
     // half a word of the aligned stream, the same for every lane (the first time a lane with skip = 1 drops the row its window
     // has already) -- so that the rows a column can need (x <= slot + 32) are always there.
-    unsigned long long A = ~funnel128(Wc.x, Wn.x, skip), B = ~funnel128(Wc.y, Wn.y, skip);
     unsigned long long EA = 0ull, EB = 0ull;
     int ev = 0;
     unsigned long long Pv = ~0ull, Mv = 0ull;
@@ -2453,20 +2477,20 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
         if (!more && !drain) break;
         if (ql + LPH > (ROWS == 64 ? cl : tg - 1)) { ovf = true; break; }             // the job's lines are used up (drain passes of an insertion-heavy window)
         if (!drain) load_codes(s0 + HS, cwn);
-        const uint32_t olo = (uint32_t)(Wc.x >> (s0 & 48)), ohi = (uint32_t)(Wc.y >> (s0 & 48));   // the 16 original bases
         const int inc = drain ? 0 : 1;
         // (idle lanes write the job's spare line: with the lines of fewer than 64 jobs interleaved -- the full-width pool -- theirs
         // are another lane's)
         uint4* const dl = trl + (size_t)(act ? ql : tg - 1) * ls;
+        const int it0 = __builtin_amdgcn_readfirstlane(ql * NC);  // the pass's first iteration (scalar)
 #pragma unroll
         for (int q = 0; q < HS; q++) {
             // ---- push slot s0 + q
             const int p = s0 + q - skip;
             const bool on = !drain && act && (uint32_t)p < (uint32_t)n;
             const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-            const int len = on ? (code ? (int)((code >> 12) & 7u) : 1) : 0;
+            const int len = on ? (int)((code >> 12) & 7u) : 0;    // (a pristine slot: length 1, its symbol the original base -- k_init)
             const uint32_t m5 = (1u << len) - 1u;
-            const uint32_t lo5 = (code ? code : olo >> q) & m5, hi5 = (code ? code >> 5 : ohi >> q) & m5;
+            const uint32_t lo5 = code & m5, hi5 = (code >> 5) & m5;
             bad |= npend > 26 || upos > 57;
             why |= (npend > 26 ? 1u : 0u) | (upos > 57 ? 2u : 0u);
             qlo |= lo5 << npend; qhi |= hi5 << npend;
@@ -2513,9 +2537,10 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 const uint32_t sh4 = min(sh, 15u);
                 if constexpr (ROWS == 14) {
                     // stored rows st .. st + 13, st = clamp(iteration - RAMP0, 0, ST): a function of the iteration alone
-                    const uint32_t st = (uint32_t)(min(max(ql * NC + q, RAMP0), 31) - RAMP0);
-                    const uint32_t c0 = alignbit(hi32(w0), lo32(w0), st) & 0x3fffu, c1 = alignbit(hi32(w1), lo32(w1), st) & 0x3fffu;
-                    ent0 = sh >= 15u ? ENT_ESC : (c0 | (c1 << 14) | (sh4 << 28));
+                    const uint32_t st = (uint32_t)(min(max(it0 + q, RAMP0), 31) - RAMP0);
+                    const uint32_t c0 = alignbit(hi32(w0), lo32(w0), st), c1 = alignbit(hi32(w1), lo32(w1), st);
+                    const uint32_t c01 = (c0 & 0x3fffu) | (__builtin_amdgcn_ubfe(c1, 0u, 14u) << 14);
+                    ent0 = sh >= 15u ? ENT_ESC : (c01 | (sh4 << 28));
                 } else {
                     ent0 = lo32(w0); ent1 = hi32(w0); ent2 = lo32(w1); ent3 = hi32(w1);
                     shb = min(sh, 254u);
@@ -2558,7 +2583,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 ev += 32 - (int)drop;
                 if (upper) {                                      // the plane words follow the slot position
                     jc++;
-                    Wc = Wn; Wn = aligned(Rl, Rn);
+                    Wn = aligned(Rl, Rn);
                     Rl = Rn; Rn = fpw(wb + jc + 3);
                 }
             }
