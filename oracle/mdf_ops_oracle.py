@@ -165,9 +165,11 @@ def pcr_mutations(seed, u, mask, rate, size):
     return sorted(chosen, key=lambda c: c[0])
 
 
-def pcr_spec(mols, cycles, efficiency, error_rate, target, seed):
+def pcr_spec(mols, cycles, efficiency, error_rate, target, seed, only=None):
     """The specification the HIP kernels implement: only the branches that lead to a written copy are walked (kernels:
-    tksm_amd/csrc/mdf_kernels.hip, pcr_walk); written set, ancestry and substitutions have the reference's distribution."""
+    tksm_amd/csrc/mdf_kernels.hip, pcr_walk); written set, ancestry and substitutions have the reference's distribution.
+    only = (lo, hi): the copies of the templates with index lo <= u < hi alone (the templates are independent given the
+    drop ratio, so the tests compute a large output in slices, side by side)."""
     n = len(mols)
     keep = list(range(n))
     if n > 2 * target:
@@ -179,6 +181,8 @@ def pcr_spec(mols, cycles, efficiency, error_rate, target, seed):
     q, A = pcr_tables(cycles, efficiency, drop)
     out = []
     for u in keep:
+        if only is not None and not only[0] <= u < only[1]:
+            continue
         md, size = mols[u], mol_size(mols[u])
         stack = [[0, 0, True]]                                          # mask, next cycle, satisfied
         while stack:

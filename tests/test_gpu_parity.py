@@ -503,6 +503,33 @@ def test_band_failure_falls_back_to_the_unbanded_alignment(oracle_models, po, mo
 TAIL_MODEL = os.path.join(GOLDEN, "tail_model_synth.json")
 
 
+def test_reference_written_tail_model_bit_exact_vs_oracle(oracle_models, po):
+    """tests/golden/tail_model_reference.json was built and written by the reference's own KDE_noise_generator.from_data /
+    .save (py/tksm_badread.py:888-901, :935-942; tests/golden/make_kde_golden.py).  Loaded as it is through
+    tksmseq_load_tail_model: whole records equal the oracle's with the same file (incl. fragments past the last label)."""
+    path = os.path.join(GOLDEN, "tail_model_reference.json")
+    s, ref, rs = _random_genome_seqr()
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    s.load_tail_model(path)
+    tm = po.TailModel(path)
+    mols = _make_molecules(rs, ref, 160, 900) + _make_molecules(rs, ref, 16, 2300)
+    text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
+    batch = s.batch_from_mdf(text)
+    ident = po.Identities(84.0, 5.5, 99.0)
+    em, qm = oracle_models["em"], oracle_models["qm"]
+    recs = s.run(batch, target="badread", fastq=True, compute_qual=True, seed=SEED, first_read_index=9).records()
+    n_tail = 0
+    for i, (mid, ivs) in enumerate(mols):
+        raw = po.splice(ref, ivs)
+        want, st = po.badread_record(True, SEED, 9 + i, raw, ident, em, qm, True, mid, tail_model=tm)
+        assert recs[i] == want, (i, mid)
+        n_tail += st.frag_len != len(raw) + 2 * em.k
+    assert n_tail > 30                                         # ratio 0.40 of 176 reads
+    s.close()
+
+
 @pytest.mark.parametrize("path", ["fast", "slow"])
 def test_tail_noise_bit_exact_vs_oracle(oracle_models, po, monkeypatch, path):
     """tail-noise model (KDE_noise_generator, py/tksm_badread.py:886-962; appended at :335-339): whole records against

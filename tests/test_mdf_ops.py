@@ -56,13 +56,19 @@ def test_mdf_reader_writer_known_answers(mo):
         assert mo.write_mdf(mo.stream_mdf(case["in"], unroll=True)) == case["out"], case["name"]
 
 
-def test_pcr_specification_has_the_reference_distribution(mo):
-    """The branch-pruned, counter-based PCR (what the kernels run) against the reference's full-tree recursion: number of written
-    copies per template, generation of a written copy, substitutions per written copy, and the share of written pairs of one
-    template that share a substitution (ancestry) -- chi-square / z tests over 3 000 templates, two parameter sets."""
+@pytest.mark.parametrize("cycles,eff,er,per_template,seed,n", [
+    (3, 0.56, 3e-4, 2.0, 5, 3000), (6, 0.7, 4e-4, 3.0, 9, 3000),
+    # BASELINE config 5's depth: 20 cycles.  The full tree has (1 + efficiency)^cycles nodes per template, so the depth the
+    # pipeline is configured for is enumerated with the Taq-setting2 preset (src/pcr.cpp:136-140: efficiency 0.36, 470 nodes per
+    # template), and the Taq-setting1 efficiency (0.88) at 12 cycles (1 950 nodes per template) -- where the closed-form branch
+    # pruning (pcr_tables: q[t] -> 1, pm / (1 - A[t])) is furthest from the shallow cases above
+    (20, 0.36, 7.2e-5, 3.0, 13, 800), (12, 0.88, 2e-4, 4.0, 17, 300), (20, 0.36, 2.5e-3, 0.5, 19, 800)])
+def test_pcr_specification_has_the_reference_distribution(mo, cycles, eff, er, per_template, seed, n):
+    """The branch-pruned, counter-based PCR (what the kernels run) against the reference's full-tree recursion
+    (src/pcr.cpp:40-89): number of written copies per template, generation of a written copy, substitutions per written copy,
+    and the share of written pairs of one template that share a substitution (ancestry) -- chi-square / z tests."""
     from scipy.stats import chi2
-    for cycles, eff, er, per_template, seed in ((3, 0.56, 3e-4, 2.0, 5), (6, 0.7, 4e-4, 3.0, 9)):
-        n = 3000
+    for _ in (0,):
         mols = [_mol([("1", 0, 700, True, []), ("2", 50, 350, False, [])], mid=f"t{u}") for u in range(n)]
         target = int(n * per_template)
         ref = mo.pcr_reference(mols, cycles, eff, er, target, np.random.RandomState(seed))
@@ -105,6 +111,32 @@ def test_pcr_specification_has_the_reference_distribution(mo):
         for md in got[:200]:
             steps = [int(x) for x in md["id"].split(".")[1:]]
             assert steps == sorted(set(steps)) and steps and steps[-1] < cycles
+
+
+def test_reference_written_kde_model_in_the_oracle(mo):
+    """tests/golden/kde_truncation_model.json was written by the reference's own py/truncate_kde.py (main -> printModelJson,
+    :298-320) from synthetic mappings (tests/golden/make_kde_golden.py).  The oracle's loader (custom_distribution2D / end_mtx,
+    src/truncate.cpp:148-203, :362-381) must take it as it is: 30 x 30 grid transposed row by row, labels x[1:] + y[1:], 100
+    end-ratio bins with float labels; truncation through it keeps every molecule within its size, cuts both ends by the drawn
+    ratio and records TR=."""
+    parts = json.load(open(os.path.join(GOLDEN, "kde_truncation_model.json")))
+    assert [p["name"] for p in parts] == ["KDE_mtx", "end_mtx"] and parts[0]["shape"] == [30, 30] and len(parts[1]["data"]) == 100
+    model = mo.TruncationModel(parts)
+    assert model.x == list(range(100, 3001, 100)) == model.y and len(model.rows) == 30 and model.sider is not None
+    assert [len(r.pdf) for r in model.rows] == list(range(1, 31))           # row i: truncation lengths up to the molecule size
+    assert abs(model.sider.cdf[-1] - 1.0) < 1e-12 and model.sider.bins[0] == 0.01 and model.sider.bins[-1] == 1.0
+    rs = np.random.RandomState(5)
+    cut5 = cut3 = 0
+    for g in range(400):
+        size = int(rs.randint(300, 2800))
+        md = _mol([("1", 1000, 1000 + size // 2, True, [(7, "A")]), ("2", 50, 50 + size - size // 2, False, [])], mid=f"m{g}")
+        out = mo.trc_spec(md, g, 31, model=model)
+        tl, side = out["meta"]["TR"][0].split(",")
+        assert 100 <= mo.mol_size(out) <= size
+        assert abs(mo.mol_size(out) - max(100.0, size - float(tl))) <= 2.0 or mo.mol_size(out) == 100
+        cut3 += out["segments"][-1]["start"] != 50 or len(out["segments"]) == 1
+        cut5 += out["segments"][0]["start"] != 1000
+    assert cut3 > 100 and cut5 > 100                                         # both ends get their share (end_mtx)
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -163,6 +195,38 @@ def test_pcr_kernels_match_the_oracle(gseq, mo, cycles, eff, er, target, seed):
     out.free(); b.free()
 
 
+def _pcr_slice(job):
+    import mdf_ops_oracle as mo2
+    text, cycles, eff, er, target, seed, lo, hi = job
+    return mo2.write_mdf(mo2.pcr_spec(mo2.stream_mdf(text, unroll=True), cycles, eff, er, target, seed, only=(lo, hi)))
+
+
+@pytest.mark.gpu
+def test_pcr_kernels_at_the_configured_depth(gseq, mo):
+    """BASELINE config 5: 20 cycles with the Taq-setting1 preset (src/pcr.cpp:136-140), 30 000 templates -> ~300 000 molecules,
+    tksmseq_pcr -> MDF text == oracle pcr_spec, text for text (the oracle's copies computed in slices of the templates, side by
+    side; ids carry up to 20 copy steps)."""
+    from multiprocessing import Pool
+    s, _ = gseq
+    er, eff = mo.PRESETS["Taq-setting1"]
+    cycles, target, seed = 20, 300_000, 11
+    text = _mdf(np.random.RandomState(seed), 24_000)
+    b = s.batch_from_mdf(text)
+    out = s.pcr(b, cycles, target, error_rate=er, efficiency=eff, seed=seed)
+    got = s.to_mdf_text(out)
+    n_t = len(mo.stream_mdf(text, unroll=True))
+    assert n_t <= 2 * target
+    procs = max(1, min(16, len(os.sched_getaffinity(0))))
+    step = (n_t + 4 * procs - 1) // (4 * procs)
+    with Pool(procs) as pool:
+        parts = pool.map(_pcr_slice, [(text, cycles, eff, er, target, seed, lo, min(n_t, lo + step)) for lo in range(0, n_t, step)], chunksize=1)
+    want = "".join(parts)
+    assert abs(out.n_reads - target) < 6 * np.sqrt(target) + 10
+    assert max(len(l.split("\t")[0].split(".")) - 1 for l in got.splitlines() if l.startswith("+")) >= 12      # deep copy paths occur
+    assert got == want
+    out.free(); b.free()
+
+
 @pytest.mark.gpu
 def test_truncation_kernels_match_the_oracle(gseq, mo, tmp_path):
     """tksmseq_truncate -> MDF text == the oracle's literal truncate() / flip_molecule() sequence (the kernels compute the kept
@@ -196,6 +260,14 @@ def test_truncation_kernels_match_the_oracle(gseq, mo, tmp_path):
         out.free()
     with pytest.raises(Exception):
         s.truncate(b, kde_model=tmp_path / "model_False_True.json", always_end=False)       # no end_mtx and not --always-end
+    # ... and the model file the REFERENCE wrote (py/truncate_kde.py printModelJson, tests/golden/make_kde_golden.py), as it is
+    ref_model = os.path.join(GOLDEN, "kde_truncation_model.json")
+    model = mo.TruncationModel(json.load(open(ref_model)))
+    for always_end, ml in ((False, False), (False, True)):
+        out = s.truncate(b, kde_model=ref_model, always_end=always_end, kde_models_length=ml, seed=29)
+        want = mo.write_mdf([mo.trc_spec(md, g, 29, model=model, always_end=always_end, models_length=ml) for g, md in enumerate(mols)])
+        assert s.to_mdf_text(out) == want, ("reference-written model", always_end, ml)
+        out.free()
     b.free()
 
 
