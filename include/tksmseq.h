@@ -237,7 +237,15 @@ typedef struct {
     int32_t reserved;
     double error_rate;            /* --error-rate, before the 4/3 adjustment of src/pcr.cpp:36 */
     double efficiency;            /* --efficiency */
+    /* the copies of the input molecules template_begin <= u < template_end only (0, 0: all of them).  The drop ratio and the
+     * 2 x target_count subsample are those of the WHOLE input either way, and a copy depends on (seed, u, its path of cycles)
+     * alone, so the outputs of consecutive slices, one after the other, are the output of the whole: how `tksm pcr` streams
+     * 200 M molecules through bounded memory and spreads them over several devices */
+    uint64_t template_begin, template_end;
 } tksmseq_pcr_params;
+/* written copies per input molecule (counts[n_reads of the batch]; 0 for a molecule outside the subsample): what a caller needs
+ * to number the molecules of a slice's output before the slices before it have been made */
+int tksmseq_pcr_template_counts(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* params, uint64_t* counts);
 int tksmseq_pcr_preset(const char* name, double* error_rate, double* efficiency);   /* -x/--preset, src/pcr.cpp:136-140 */
 int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* params, tksmseq_batch** out);
 

@@ -40,7 +40,7 @@ class TailModelDesc(C.Structure):            # tksmseq_tail_model
 # every symbol include/tksmseq.h declares (checked by tests/test_abi.py without a GPU)
 class PcrParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("target_count", C.c_uint64), ("cycles", C.c_int32), ("reserved", C.c_int32),
-                ("error_rate", C.c_double), ("efficiency", C.c_double)]
+                ("error_rate", C.c_double), ("efficiency", C.c_double), ("template_begin", C.c_uint64), ("template_end", C.c_uint64)]
 
 
 class TrcParams(C.Structure):
@@ -61,7 +61,7 @@ SYMBOLS = [
     "tksmseq_prefetch_model", "tksmseq_prefetch_identity", "tksmseq_result_download", "tksmseq_result_download_range", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
     "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
     "tksmseq_set_host_threads", "tksmseq_model_available",
-    "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
+    "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_pcr_template_counts", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
     "tksmseq_molecules_from_mdf_text", "tksmseq_pcr_main", "tksmseq_truncate_main",
 ]
 
@@ -76,9 +76,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C tksm_amd/csrc).  tksm_amd has no CPU fallback.")
-    # a hardware queue per stream in flight (the runtime's default of 4 serialises the kernels of contexts whose streams share
-    # one); read when the HIP runtime starts, so this only helps when nothing has touched the device yet
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (Several contexts in flight want a hardware queue each -- GPU_MAX_HW_QUEUES=16, read when the HIP runtime starts: the CLI and
+    # bench.py set it for their own processes; a library import does not touch the environment of the application that embeds it --
+    # INTEGRATION.md)
     lib = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     P = C.POINTER
@@ -103,6 +103,7 @@ def load():
         "tksmseq_set_host_threads": (C.c_int, [vp, C.c_int]),
         "tksmseq_pcr_preset": (C.c_int, [C.c_char_p, P(C.c_double), P(C.c_double)]),
         "tksmseq_pcr": (C.c_int, [vp, vp, vp, P(vp)]),
+        "tksmseq_pcr_template_counts": (C.c_int, [vp, vp, vp, P(C.c_uint64)]),
         "tksmseq_truncate": (C.c_int, [vp, vp, vp, P(vp)]),
         "tksmseq_batch_to_mdf_text": (C.c_int, [vp, vp, P(vp), P(u64)]),
         "tksmseq_text_free": (None, [vp]),

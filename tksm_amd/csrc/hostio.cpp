@@ -139,6 +139,7 @@ bool parse_mdf(const char* text, uint64_t len, const ContigLookup& contigs, Batc
         p = nl ? nl + 1 : end;
     }
     flush();
+    if (out.id_pool.size() >= 0xffffffffull || out.comment_pool.size() >= 0xffffffffull) { err = "batch too large (split it: < 4 GB of ids / header comments per batch)"; return false; }
     return true;
 }
 
@@ -187,9 +188,10 @@ bool parse_mdf_mt(const char* text, uint64_t len, const ContigLookup& contigs, B
             return false;
         }
     out = BatchHost();
-    size_t nr = 0, ni = 0, nm = 0, nl = 0, nlp = 0, nip = 0;
-    for (auto& b : parts) { nr += b.reads.size(); ni += b.intervals.size(); nm += b.mods.size(); nl += b.literals.size(); nlp += b.literal_pool.size(); nip += b.id_pool.size(); }
-    if (ni / 4 >= 0x7fffffffull || nm / 2 >= 0x7fffffffull || nip >= 0xffffffffull) { err = "batch too large (split it: < 2^31 intervals/mods per batch)"; return false; }
+    size_t nr = 0, ni = 0, nm = 0, nl = 0, nlp = 0, nip = 0, ncp = 0;
+    for (auto& b : parts) { nr += b.reads.size(); ni += b.intervals.size(); nm += b.mods.size(); nl += b.literals.size(); nlp += b.literal_pool.size(); nip += b.id_pool.size(); ncp += b.comment_pool.size(); }
+    // (ids and header comments are addressed with 32-bit offsets)
+    if (ni / 4 >= 0x7fffffffull || nm / 2 >= 0x7fffffffull || nip >= 0xffffffffull || ncp >= 0xffffffffull) { err = "batch too large (split it: < 2^31 intervals/mods, < 4 GB of ids / header comments per batch)"; return false; }
     out.reads.reserve(nr); out.ids.reserve(nr); out.intervals.reserve(ni); out.mods.reserve(nm); out.literals.reserve(nl);
     out.literal_pool.reserve(nlp); out.id_pool.reserve(nip);
     for (auto& b : parts) {

@@ -2,24 +2,35 @@
 //
 // Mirrors (file:line into vpc-ccg/tksm):
 //   PCR_module::impl        src/pcr.cpp:91-260       flags -i -o --molecule-count --cycles --error-rate --efficiency -x/--preset,
-//                                                    mandatory-argument and preset checks, whole input read into memory (:215)
+//                                                    mandatory-argument and preset checks; the whole input is held (:215: the drop
+//                                                    ratio needs the number of templates), the output is streamed
 //   Truncate_module::impl   src/truncate.cpp:236-451 flags -i -o --kde-model --always-end --kde-models-length --normal --lognormal,
-//                                                    "exactly one of kde-model, normal or lognormal"
+//                                                    "exactly one of kde-model, normal or lognormal"; a stream transform (:322-351)
 //   utility flags           src/module.h:75-104      -s/--seed (default 42), --verbosity, --log-file, -h
+// Both stream: `truncate` reads the input in batches of whole molecules (--batch-bytes), `pcr` amplifies its templates in slices
+// of about --slice-molecules output molecules (tksmseq_pcr_params::template_begin / _end); the pieces go round the entries of
+// --devices D[,D...] (two contexts per entry: one formats its text while the other computes) and are written in input order, so the
+// output does not depend on the device list or the piece size.
 // Exit codes as the reference's run(): 0 ok (also for --help), 1 for missing / inconsistent arguments and runtime errors.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <algorithm>
 #include <vector>
 
 #include "../../include/tksmseq.h"
+#include "module_log.h"
 #include "sequencer_module.h"
 
 namespace {
+
+using tkmod::Logger;
 
 bool read_file(const std::string& path, std::string& out) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -31,9 +42,16 @@ bool read_file(const std::string& path, std::string& out) {
     return true;
 }
 
-struct Common { std::string input, output; long long seed = 42; int device = 0; bool help = false; };
+struct Common {
+    std::string input, output, verbosity = "INFO", log_file = "stderr";
+    long long seed = 42;
+    std::vector<int> devices{0};
+    uint64_t batch_bytes = 64ull << 20;          // truncate: MDF text per batch
+    uint64_t slice_molecules = 2000000;          // pcr: output molecules per slice of templates
+    bool help = false;
+};
 
-// returns 1 if the flag was one of the common ones (i advanced), 0 if not, -1 on a missing value
+// returns 1 if the flag was one of the common ones (i advanced), 0 if not, -1 on a missing / malformed value
 int common_flag(int argc, char** argv, int& i, Common& c) {
     const std::string o = argv[i];
     auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -42,52 +60,91 @@ int common_flag(int argc, char** argv, int& i, Common& c) {
     if (o == "-i" || o == "--input") { if (!(v = val())) return -1; c.input = v; return 1; }
     if (o == "-o" || o == "--output") { if (!(v = val())) return -1; c.output = v; return 1; }
     if (o == "-s" || o == "--seed") { if (!(v = val())) return -1; c.seed = atoll(v); return 1; }
-    if (o == "--devices") { if (!(v = val())) return -1; c.device = atoi(v); return 1; }
-    if (o == "--verbosity" || o == "--log-file") { if (!val()) return -1; return 1; }
+    if (o == "--devices") { if (!(v = val()) || !tkmod::parse_device_list(v, c.devices)) return -1; return 1; }
+    if (o == "--verbosity") { if (!(v = val())) return -1; c.verbosity = v; return 1; }
+    if (o == "--log-file") { if (!(v = val())) return -1; c.log_file = v; return 1; }
+    if (o == "--batch-bytes") { if (!(v = val()) || strtoull(v, nullptr, 10) < 1) return -1; c.batch_bytes = strtoull(v, nullptr, 10); return 1; }
+    if (o == "--slice-molecules") { if (!(v = val()) || strtoull(v, nullptr, 10) < 1) return -1; c.slice_molecules = strtoull(v, nullptr, 10); return 1; }
     return 0;
 }
 
-int run_transform(const Common& c, const char* what, int (*apply)(tksmseq_ctx*, const tksmseq_batch*, void*, tksmseq_batch**), void* arg) {
-    const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char* name) {
-        const auto t = std::chrono::steady_clock::now();
-        if (verbose) fprintf(stderr, "[%s] %s %.3f s\n", what, name, std::chrono::duration<double>(t - t_last).count());
-        t_last = t;
-    };
-    std::string text;
-    if (!read_file(c.input, text)) { fprintf(stderr, "Could not open file %s\n", c.input.c_str()); return 1; }
-    lap("input read");
-    tksmseq_ctx* ctx = nullptr;
-    if (tksmseq_create(c.device, &ctx)) { fprintf(stderr, "Error: %s\n", tksmseq_last_error(nullptr)); return 1; }
-    lap("device ready");
-    // host threads for the MDF parser and writer (the reference's modules are single-threaded; results do not depend on it)
-    tksmseq_set_host_threads(ctx, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
-    tksmseq_batch *in = nullptr, *out = nullptr;
-    char* otext = nullptr; uint64_t olen = 0;
-    int rc = tksmseq_molecules_from_mdf_text(ctx, text.data(), text.size(), &in);
-    lap("molecules parsed and uploaded");
-    if (!rc) rc = apply(ctx, in, arg, &out);
-    lap("device pass");
-    if (!rc) rc = tksmseq_batch_to_mdf_text(ctx, out, &otext, &olen);
-    lap("MDF text written");
-    int status = 0;
-    if (rc) { fprintf(stderr, "Error: %s: %s\n", what, tksmseq_last_error(ctx)); status = 1; }
-    else {
-        FILE* f = fopen(c.output.c_str(), "wb");
-        if (!f || fwrite(otext, 1, olen, f) != olen || fclose(f)) { fprintf(stderr, "Error: cannot write %s\n", c.output.c_str()); status = 1; }
-    }
-    lap("output file written");
-    tksmseq_text_free(otext);
-    if (out) tksmseq_batch_free(ctx, out);
-    if (in) tksmseq_batch_free(ctx, in);
-    tksmseq_destroy(ctx);
-    lap("released");
-    return status;
+bool open_log(const Common& c, const char* module, Logger& log) {
+    log.module = module;
+    const int lv = Logger::parse(c.verbosity);
+    if (lv < 0) { fprintf(stderr, "Error: unknown verbosity level '%s' (choose from DEBUG, INFO, WARN, ERROR, OFF)\n", c.verbosity.c_str()); return false; }
+    log.level = lv;
+    if (!log.open(c.log_file)) { fprintf(stderr, "Error: cannot open log file %s\n", c.log_file.c_str()); return false; }
+    return true;
 }
 
-int apply_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, void* arg, tksmseq_batch** out) { return tksmseq_pcr(ctx, in, (const tksmseq_pcr_params*)arg, out); }
-int apply_trc(tksmseq_ctx* ctx, const tksmseq_batch* in, void* arg, tksmseq_batch** out) { return tksmseq_truncate(ctx, in, (const tksmseq_trc_params*)arg, out); }
+// pieces of output text, written in the order of their numbers whatever the order in which they are finished
+struct OrderedOut {
+    FILE* f = nullptr; std::mutex m; std::condition_variable cv; uint64_t next = 0; bool failed = false;
+    bool put(uint64_t k, const char* text, uint64_t len) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return next == k || failed; });
+        if (failed) return false;
+        if (len && fwrite(text, 1, len, f) != len) failed = true;
+        next++;
+        cv.notify_all();
+        return !failed;
+    }
+    void fail() { std::lock_guard<std::mutex> l(m); failed = true; cv.notify_all(); }
+};
+
+struct Piece { uint64_t seq = 0, first = 0, begin = 0, end = 0; std::vector<char> text; };   // truncate: text + first molecule index; pcr: template slice
+
+// The common engine: `n_ctx` worker threads (two per entry of --devices), each with a context of its own; prepare() runs once per
+// context (pcr: parse the templates), pieces come from next_piece() (serialised), work() turns one into a batch, whose MDF text is
+// written in piece order.
+template <class Prepare, class Next, class Work>
+int run_pieces(const Common& c, Logger& log, const char* what, Prepare prepare, Next next_piece, Work work) {
+    OrderedOut out;
+    out.f = fopen(c.output.c_str(), "wb");
+    if (!out.f) { fprintf(stderr, "Error: cannot write %s\n", c.output.c_str()); return 1; }
+    const int per_device = 2, n_ctx = (int)c.devices.size() * per_device;
+    std::mutex err_m, next_m; std::string first_error; std::atomic<bool> failed{false};
+    auto set_error = [&](const std::string& e) { std::lock_guard<std::mutex> l(err_m); if (!failed.exchange(true)) first_error = e; out.fail(); };
+    std::atomic<uint64_t> molecules{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int wi) {
+        tksmseq_ctx* ctx = nullptr;
+        if (tksmseq_create(c.devices[(size_t)(wi / per_device)], &ctx)) { set_error(tksmseq_last_error(nullptr)); return; }
+        // host threads for the MDF parser and writer (the reference's modules are single-threaded; results do not depend on it)
+        tksmseq_set_host_threads(ctx, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / (unsigned)std::max(1, n_ctx / 2))));
+        void* state = nullptr;
+        if (!prepare(ctx, &state)) set_error(tksmseq_last_error(ctx));
+        while (!failed) {
+            Piece p;
+            { std::lock_guard<std::mutex> l(next_m); if (failed || !next_piece(p)) break; }
+            tksmseq_batch* b = nullptr;
+            char* text = nullptr; uint64_t len = 0;
+            int rc = work(ctx, state, p, &b);
+            if (!rc) rc = tksmseq_batch_to_mdf_text(ctx, b, &text, &len);
+            if (rc) set_error(std::string(what) + ": " + tksmseq_last_error(ctx));
+            else {
+                uint64_t n = 0;
+                tksmseq_batch_info(b, &n, nullptr, nullptr);
+                molecules += n;
+                log.log(Logger::DEBUG, "piece %llu: %llu molecules, %.1f MB of text (context %d)", (unsigned long long)p.seq, (unsigned long long)n, len / 1e6, wi);
+                if (!out.put(p.seq, text, len) && !failed) set_error("cannot write " + c.output);
+            }
+            tksmseq_text_free(text);
+            if (b) tksmseq_batch_free(ctx, b);
+        }
+        if (state) prepare(ctx, &state);                        // (second call: releases what the first one made)
+        tksmseq_destroy(ctx);
+    };
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_ctx; w++) th.emplace_back(worker, w);
+    for (auto& t : th) t.join();
+    const bool close_ok = fclose(out.f) == 0;
+    if (failed) { fprintf(stderr, "Error: %s\n", first_error.c_str()); return 1; }
+    if (!close_ok || out.failed) { fprintf(stderr, "Error: cannot write %s\n", c.output.c_str()); return 1; }
+    log.log(Logger::INFO, "%s: %llu molecules written in %.2f s (%d device group(s))", what, (unsigned long long)molecules.load(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (int)c.devices.size());
+    return 0;
+}
 
 }  // namespace
 
@@ -98,7 +155,7 @@ extern "C" int tksmseq_pcr_main(int argc, char** argv) {
     tksmseq_pcr_params p{};
     for (int i = 1; i < argc; i++) {
         const int k = common_flag(argc, argv, i, c);
-        if (k < 0) { fprintf(stderr, "Option '%s' is missing an argument\n", argv[i]); return 1; }
+        if (k < 0) { fprintf(stderr, "Option '%s' is missing an argument or has a malformed one\n", argv[i]); return 1; }
         if (k) continue;
         const std::string o = argv[i];
         const char* v = i + 1 < argc ? argv[i + 1] : nullptr;
@@ -109,7 +166,8 @@ extern "C" int tksmseq_pcr_main(int argc, char** argv) {
         else if ((o == "-x" || o == "--preset") && v) { preset = v; i++; }
         else { fprintf(stderr, "Option '%s' does not exist or is missing an argument\n", argv[i]); return 1; }
     }
-    if (c.help) { printf("PCR amplification module\nusage: pcr -i INPUT -o OUTPUT --molecule-count N --cycles C [-x PRESET | --error-rate E --efficiency F] [-s SEED]\n"); return 0; }
+    if (c.help) { printf("PCR amplification module\nusage: pcr -i INPUT -o OUTPUT --molecule-count N --cycles C [-x PRESET | --error-rate E --efficiency F] [-s SEED]\n"
+                         "           [--devices D[,D...]] [--slice-molecules N] [--verbosity L] [--log-file F]\n"); return 0; }
     int missing = 0;
     if (c.input.empty()) { fprintf(stderr, "input is required!\n"); missing++; }
     if (c.output.empty()) { fprintf(stderr, "output is required!\n"); missing++; }
@@ -124,8 +182,54 @@ extern "C" int tksmseq_pcr_main(int argc, char** argv) {
         if (!have_ef) { fprintf(stderr, "Efficiency is required!\n"); missing++; }
     }
     if (missing) return 1;
+    Logger log;
+    if (!open_log(c, "pcr", log)) return 1;
     p.seed = (uint64_t)c.seed;
-    return run_transform(c, "PCR", apply_pcr, &p);
+    std::string text;
+    if (!read_file(c.input, text)) { fprintf(stderr, "Could not open file %s\n", c.input.c_str()); return 1; }
+    // the slices of templates: consecutive runs that write about slice_molecules copies each, from the per-template counts
+    std::vector<uint64_t> cuts;                                  // template index where slice k begins; cuts.back() = number of templates
+    std::mutex cuts_m; bool cuts_done = false, cuts_failed = false; std::condition_variable cuts_cv;
+    uint64_t next_slice = 0;
+    auto prepare = [&](tksmseq_ctx* ctx, void** state) -> bool {
+        if (*state) { tksmseq_batch_free(ctx, (tksmseq_batch*)*state); *state = nullptr; return true; }
+        tksmseq_batch* T = nullptr;
+        if (tksmseq_molecules_from_mdf_text(ctx, text.data(), text.size(), &T)) return false;
+        *state = T;
+        bool mine = false;
+        { std::lock_guard<std::mutex> l(cuts_m); if (cuts.empty()) { cuts.push_back(0); mine = true; } }
+        if (mine) {
+            uint64_t n = 0;
+            tksmseq_batch_info(T, &n, nullptr, nullptr);
+            std::vector<uint64_t> counts(n);
+            const bool ok = tksmseq_pcr_template_counts(ctx, T, &p, counts.data()) == 0;
+            std::lock_guard<std::mutex> l(cuts_m);
+            uint64_t acc = 0, total = 0;
+            for (uint64_t u = 0; u < n && ok; u++) { acc += counts[u]; total += counts[u]; if (acc >= c.slice_molecules && u + 1 < n) { cuts.push_back(u + 1); acc = 0; } }
+            cuts.push_back(n);
+            cuts_done = true; cuts_failed = !ok;
+            cuts_cv.notify_all();
+            if (ok) log.log(Logger::INFO, "%llu templates -> %llu molecules in %zu slice(s)", (unsigned long long)n, (unsigned long long)total, cuts.size() - 1);
+            return ok;
+        }
+        std::unique_lock<std::mutex> l(cuts_m);
+        cuts_cv.wait(l, [&] { return cuts_done; });
+        return !cuts_failed;
+    };
+    auto next_piece = [&](Piece& pc) -> bool {
+        std::lock_guard<std::mutex> l(cuts_m);
+        if (next_slice + 1 >= cuts.size()) return false;
+        pc.seq = next_slice; pc.begin = cuts[next_slice]; pc.end = cuts[next_slice + 1];
+        next_slice++;
+        return true;
+    };
+    auto work = [&](tksmseq_ctx* ctx, void* state, const Piece& pc, tksmseq_batch** out) -> int {
+        tksmseq_pcr_params q = p;
+        q.template_begin = pc.begin; q.template_end = pc.end;
+        if (pc.begin == pc.end) { q.template_begin = 0; q.template_end = 0; q.cycles = 0; }     // (an input without molecules: one empty piece)
+        return tksmseq_pcr(ctx, (const tksmseq_batch*)state, &q, out);
+    };
+    return run_pieces(c, log, "PCR", prepare, next_piece, work);
 }
 
 extern "C" int tksmseq_truncate_main(int argc, char** argv) {
@@ -136,7 +240,7 @@ extern "C" int tksmseq_truncate_main(int argc, char** argv) {
     auto two = [](const char* v, double& a, double& b) { char* e = nullptr; a = strtod(v, &e); if (!e || *e != ',') return false; b = strtod(e + 1, &e); return e && !*e; };
     for (int i = 1; i < argc; i++) {
         const int k = common_flag(argc, argv, i, c);
-        if (k < 0) { fprintf(stderr, "Option '%s' is missing an argument\n", argv[i]); return 1; }
+        if (k < 0) { fprintf(stderr, "Option '%s' is missing an argument or has a malformed one\n", argv[i]); return 1; }
         if (k) continue;
         const std::string o = argv[i];
         const char* v = i + 1 < argc ? argv[i + 1] : nullptr;
@@ -147,14 +251,44 @@ extern "C" int tksmseq_truncate_main(int argc, char** argv) {
         else if (o == "--lognormal" && v) { if (!two(v, p.mu, p.sigma)) { fprintf(stderr, "--lognormal needs mu,sigma\n"); return 1; } p.mode = TKSMSEQ_TRC_LOGNORMAL; n_dist++; i++; }
         else { fprintf(stderr, "Option '%s' does not exist or is missing an argument\n", argv[i]); return 1; }
     }
-    if (c.help) { printf("Truncate module\nusage: truncate -i INPUT -o OUTPUT (--kde-model M.json [--always-end] [--kde-models-length] | --normal MU,SIGMA | --lognormal MU,SIGMA) [-s SEED]\n"); return 0; }
+    if (c.help) { printf("Truncate module\nusage: truncate -i INPUT -o OUTPUT (--kde-model M.json [--always-end] [--kde-models-length] | --normal MU,SIGMA | --lognormal MU,SIGMA) [-s SEED]\n"
+                         "                [--devices D[,D...]] [--batch-bytes B] [--verbosity L] [--log-file F]\n"); return 0; }
     int missing = 0;
     if (c.input.empty()) { fprintf(stderr, "input is required!\n"); missing++; }
     if (c.output.empty()) { fprintf(stderr, "output is required!\n"); missing++; }
     if (n_dist == 0) { fprintf(stderr, "One of kde-model, normal or lognormal is required!\n"); missing++; }
     if (n_dist > 1) { fprintf(stderr, "Only one of kde-model, normal or lognormal is allowed!\n"); missing++; }
     if (missing) return 1;
+    Logger log;
+    if (!open_log(c, "truncate", log)) return 1;
     if (!kde.empty()) { p.mode = TKSMSEQ_TRC_KDE; p.kde_model_path = kde.c_str(); }
     p.seed = (uint64_t)c.seed;
-    return run_transform(c, "truncate", apply_trc, &p);
+    tkmod::ChunkReader rd;
+    rd.in = fopen(c.input.c_str(), "rb");
+    if (!rd.in) { fprintf(stderr, "Could not open file %s\n", c.input.c_str()); return 1; }
+    rd.bytes = c.batch_bytes;
+    uint64_t seq = 0, first = 0;
+    auto prepare = [&](tksmseq_ctx*, void**) -> bool { return true; };
+    auto next_piece = [&](Piece& pc) -> bool {                   // (serialised by the engine: the molecules are numbered in input order)
+        if (!rd.next(pc.text)) {
+            if (seq) return false;
+            pc.text.clear();                                      // an empty input still makes an (empty) output
+        }
+        pc.seq = seq++; pc.first = first;
+        first += tkmod::count_reads(pc.text.data(), pc.text.size());
+        return true;
+    };
+    auto work = [&](tksmseq_ctx* ctx, void*, const Piece& pc, tksmseq_batch** out) -> int {
+        tksmseq_batch* in = nullptr;
+        int rc = tksmseq_molecules_from_mdf_text(ctx, pc.text.data(), pc.text.size(), &in);
+        if (rc) return rc;
+        tksmseq_trc_params q = p;
+        q.first_molecule_index = pc.first;
+        rc = tksmseq_truncate(ctx, in, &q, out);
+        tksmseq_batch_free(ctx, in);
+        return rc;
+    };
+    const int rc = run_pieces(c, log, "truncate", prepare, next_piece, work);
+    fclose(rd.in);
+    return rc;
 }

@@ -96,11 +96,20 @@ std::string normalize_comment(const char* c, size_t n, const std::vector<std::pa
     return out;
 }
 
-std::string fmt_double(double v) {                        // fmt's "{}" of a double: shortest representation that round-trips
+// fmt's "{}" of a double: the shortest digits that round-trip, in FIXED notation while the decimal exponent is in [-4, 16) and in
+// exponent notation outside (like Python's repr; std::to_chars alone would switch to "1e+05" as soon as that is shorter)
+std::string fmt_double(double v) {
     char buf[64];
-    auto r = std::to_chars(buf, buf + sizeof buf, v);
-    std::string s(buf, r.ptr);
-    return s;
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+    std::string sci(buf, r.ptr);                          // d[.ddd]e[+-]XX: read the exponent off it
+    const size_t e = sci.find('e');
+    const int ex = e == std::string::npos ? 0 : atoi(sci.c_str() + e + 1);
+    if (!std::isfinite(v) || ex < -4 || ex >= 16) {
+        r = std::to_chars(buf, buf + sizeof buf, v);
+        return std::string(buf, r.ptr);
+    }
+    r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
 }
 
 }  // namespace
@@ -112,7 +121,7 @@ int finalize_device_batch(tksmseq_ctx* ctx, tksmseq_batch* b) {
     b->raw_len.assign(n, 0); b->order.resize(n); b->max_raw = 0; b->total_raw = 0;
     b->splice_len.clear(); b->tail_on = false; b->cache_k = -1;
     HIPCHK(ctx, b->d_order.ensure(n * 4 + 64));
-    if (!n) return TKSMSEQ_OK;
+    if (!n) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return TKSMSEQ_OK; }      // (the callers' copies from stack / local buffers have run)
     HIPCHK(ctx, ctx->w_rawlen.ensure(n * 4 + 16));
     HIPCHK(ctx, ctx->w_slotcap.ensure(n * 8 + 16));
     HIPCHK(ctx, ctx->w_status.ensure(n * 4 + 16));
@@ -142,17 +151,16 @@ int tksmseq_pcr_preset(const char* name, double* error_rate, double* efficiency)
     return TKSMSEQ_EINVAL;
 }
 
-int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* p, tksmseq_batch** out) {
-    if (!ctx || !in || !p || !out) return TKSMSEQ_EINVAL;
-    *out = nullptr;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+// The templates of a PCR call and its kernel parameters.  Templates: every (depth-unrolled) molecule, or 2 x target of them when
+// there are more (src/pcr.cpp:217-220 shuffles and cuts; here: the 2 x target molecules with the smallest Philox keys, in input
+// order); of those, the ones inside [template_begin, template_end) when the caller asks for a slice.  keep empty = every molecule.
+static int pcr_setup(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* p, std::vector<uint32_t>& keep, uint64_t& n_local, tk::PcrParams& P) {
     if (p->cycles < 0 || p->cycles > tk::PCR_MAX_CYCLES) { ctx->err = "PCR: between 0 and " + std::to_string(tk::PCR_MAX_CYCLES) + " cycles are supported"; return TKSMSEQ_ELIMIT; }
     if (!(p->efficiency >= 0.0) || !(p->error_rate >= 0.0)) { ctx->err = "PCR: efficiency and error rate must be non-negative"; return TKSMSEQ_EINVAL; }
-    hipStream_t s = ctx->stream;
     const uint64_t n = in->n_reads;
-    // templates: every (depth-unrolled) molecule, or 2 x target of them when there are more (src/pcr.cpp:217-220 shuffles and
-    // cuts; here: the 2 x target molecules with the smallest Philox keys, in input order)
-    std::vector<uint32_t> keep;
+    const bool sliced = p->template_begin != 0 || p->template_end != 0;
+    if (sliced && (p->template_begin > p->template_end || p->template_end > n)) { ctx->err = "PCR: template slice outside the batch"; return TKSMSEQ_EINVAL; }
+    keep.clear();
     uint64_t n_kept = n;
     if (n > 2 * p->target_count) {
         n_kept = 2 * p->target_count;
@@ -163,21 +171,76 @@ int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_par
         for (uint64_t i = 0; i < n_kept; i++) keep[i] = key[i].second;
         std::sort(keep.begin(), keep.end());
     }
-    tk::PcrParams P{};
-    P.seed = p->seed; P.cycles = p->cycles; P.efficiency = p->efficiency; P.rate = (4 * p->error_rate) / 3;
-    {
-        // drop ratio (src/pcr.cpp:68-76), then the probabilities that a subtree of copies emits nothing
-        const double expected_after = std::pow(1 + p->efficiency, p->cycles) * (double)n_kept;
-        P.drop = expected_after > 0.0 ? (double)p->target_count / expected_after : 0.0;
-        if (P.drop > 1.0) P.drop = 1.0;
-        const int c = p->cycles;
-        P.A[c] = 1.0; P.A[c + 1] = 1.0;
-        for (int t = c - 1; t >= 0; t--) {
-            P.q[t] = (1.0 - P.drop) * P.A[t + 1];
-            P.A[t] = P.A[t + 1] * (1.0 - P.efficiency * (1.0 - P.q[t]));
+    n_local = n_kept;
+    if (sliced) {
+        if (keep.empty()) {
+            if (p->template_begin != 0 || p->template_end != n) { keep.resize(p->template_end - p->template_begin); for (size_t i = 0; i < keep.size(); i++) keep[i] = (uint32_t)(p->template_begin + i); }
+        } else {
+            const auto lo = std::lower_bound(keep.begin(), keep.end(), (uint32_t)p->template_begin);
+            const auto hi = p->template_end > 0xffffffffull ? keep.end() : std::lower_bound(keep.begin(), keep.end(), (uint32_t)p->template_end);
+            keep = std::vector<uint32_t>(lo, hi);
         }
-        P.q[c] = 1.0;
+        n_local = (keep.empty() && p->template_begin == 0 && p->template_end == n) ? n : keep.size();
+        if (n_local == 0) keep.assign(1, 0u);                     // (an empty slice: a list that is not "every molecule")
     }
+    P = tk::PcrParams{};
+    P.seed = p->seed; P.cycles = p->cycles; P.efficiency = p->efficiency; P.rate = (4 * p->error_rate) / 3;
+    // drop ratio (src/pcr.cpp:68-76) of the whole input, then the probabilities that a subtree of copies emits nothing
+    const double expected_after = std::pow(1 + p->efficiency, p->cycles) * (double)n_kept;
+    P.drop = expected_after > 0.0 ? (double)p->target_count / expected_after : 0.0;
+    if (P.drop > 1.0) P.drop = 1.0;
+    const int c = p->cycles;
+    P.A[c] = 1.0; P.A[c + 1] = 1.0;
+    for (int t = c - 1; t >= 0; t--) {
+        P.q[t] = (1.0 - P.drop) * P.A[t + 1];
+        P.A[t] = P.A[t + 1] * (1.0 - P.efficiency * (1.0 - P.q[t]));
+    }
+    P.q[c] = 1.0;
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_pcr_template_counts(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* p, uint64_t* counts) {
+    if (!ctx || !in || !p || (!counts && in->n_reads)) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<uint32_t> keep;
+    uint64_t n_kept = 0;
+    tk::PcrParams P{};
+    tksmseq_pcr_params whole = *p;
+    whole.template_begin = whole.template_end = 0;
+    int rc = pcr_setup(ctx, in, &whole, keep, n_kept, P);
+    if (rc) return rc;
+    DevBuf d_keep, d_cnt, d_status;
+    if (!keep.empty()) { HIPCHK(ctx, d_keep.ensure(n_kept * 4 + 16)); HIPCHK(ctx, hipMemcpyAsync(d_keep.p, keep.data(), n_kept * 4, hipMemcpyHostToDevice, s)); }
+    tk::MolView M{view_of(in), in->d_dup.p ? in->d_dup.as<uint32_t>() : nullptr, in->n_intervals, in->n_mods, keep.empty() ? nullptr : d_keep.as<uint32_t>(), n_kept};
+    HIPCHK(ctx, d_cnt.ensure(n_kept * 8 + 16));
+    HIPCHK(ctx, d_status.ensure(64));
+    HIPCHK(ctx, hipMemsetAsync(d_status.p, 0, 64, s));
+    HIPCHK(ctx, tk::launch_pcr_count(M, P, d_cnt.as<uint64_t>(), d_status.as<uint32_t>(), s));
+    std::vector<uint64_t> h(n_kept);
+    uint32_t st = 0;
+    if (n_kept) HIPCHK(ctx, hipMemcpyAsync(h.data(), d_cnt.p, n_kept * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(&st, d_status.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (st & 1u) { ctx->err = "PCR: more than " + std::to_string(tk::PCR_MAX_MUT) + " substitutions per copy (error rate x molecule length) are not supported"; return TKSMSEQ_ELIMIT; }
+    std::fill(counts, counts + in->n_reads, 0ull);
+    for (uint64_t i = 0; i < n_kept; i++) counts[keep.empty() ? i : keep[i]] = h[i];
+    return TKSMSEQ_OK;
+}
+
+int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* p, tksmseq_batch** out) {
+    if (!ctx || !in || !p || !out) return TKSMSEQ_EINVAL;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<uint32_t> keep;
+    uint64_t n_kept = 0;
+    tk::PcrParams P{};
+    {
+        const int rc0 = pcr_setup(ctx, in, p, keep, n_kept, P);
+        if (rc0) return rc0;
+    }
+
     DevBuf d_keep, d_cnt, d_off, d_status, n_mol, n_mask, n_ivl, n_mod, n_idl, o_ivl, o_mod, o_id;
     if (!keep.empty()) { HIPCHK(ctx, d_keep.ensure(n_kept * 4 + 16)); HIPCHK(ctx, hipMemcpyAsync(d_keep.p, keep.data(), n_kept * 4, hipMemcpyHostToDevice, s)); }
     tk::MolView M{view_of(in), in->d_dup.p ? in->d_dup.as<uint32_t>() : nullptr, in->n_intervals, in->n_mods,
@@ -224,6 +287,7 @@ int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_par
             const uint32_t u = mol[j];
             if (u != last) {
                 const std::string c = normalize_comment(in->h_comment_pool.data() + in->h_comments[2 * (size_t)u], in->h_comments[2 * (size_t)u + 1], {});
+                if (b->h_comment_pool.size() + c.size() >= 0xffffffffull) { ctx->err = "PCR: more than 4 GB of header comments in one batch (use template slices)"; return TKSMSEQ_ELIMIT; }
                 off = (uint32_t)b->h_comment_pool.size(); len = (uint32_t)c.size();
                 b->h_comment_pool.insert(b->h_comment_pool.end(), c.begin(), c.end());
                 last = u;
@@ -264,6 +328,7 @@ int tksmseq_truncate(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_tr
         T.xlab = d_x.as<long long>(); T.ylab = d_y.as<long long>(); T.cdf = d_cdf.as<double>(); T.row_n = d_rn.as<int>();
         T.slab = d_sl.as<double>(); T.scdf = d_sc.as<double>();
     } else if (p->mode != TKSMSEQ_TRC_NORMAL && p->mode != TKSMSEQ_TRC_LOGNORMAL) { ctx->err = "truncate: unknown mode"; return TKSMSEQ_EINVAL; }
+    else if (!std::isfinite(p->mu) || !std::isfinite(p->sigma)) { ctx->err = "truncate: mu and sigma must be finite"; return TKSMSEQ_EINVAL; }
     tk::MolView M{view_of(in), in->d_dup.p ? in->d_dup.as<uint32_t>() : nullptr, in->n_intervals, in->n_mods, nullptr, n};
     DevBuf kf, kt, tl, ts, n_ivl, n_mod, n_idl, o_ivl, o_mod, o_id;
     HIPCHK(ctx, kf.ensure(n * 4 + 16)); HIPCHK(ctx, kt.ensure(n * 4 + 16));
@@ -355,6 +420,7 @@ int tksmseq_truncate(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_tr
                 extra.push_back({"TR", fmt_double(htl[r]) + "," + sr});
             }
             const std::string cmt = normalize_comment(in->h_comment_pool.data() + in->h_comments[2 * r], in->h_comments[2 * r + 1], extra);
+            if (b->h_comment_pool.size() + cmt.size() >= 0xffffffffull) { ctx->err = "truncate: more than 4 GB of header comments in one batch (split the input)"; return TKSMSEQ_ELIMIT; }
             b->h_comments.push_back((uint32_t)b->h_comment_pool.size()); b->h_comments.push_back((uint32_t)cmt.size());
             b->h_comment_pool.insert(b->h_comment_pool.end(), cmt.begin(), cmt.end());
         }

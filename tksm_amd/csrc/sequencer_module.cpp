@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/tksmseq.h"
+#include "module_log.h"
 
 namespace {
 
@@ -52,6 +53,15 @@ struct Args {
     long long seed = 42;
     uint64_t batch_bytes = 64ull << 20;
     std::string verbosity = "INFO", log_file = "stderr";
+    // chained stages (BASELINE config 5): `tksm pcr` and / or `tksm truncate` in front of the sequencer, molecule tables staying on
+    // the device -- same results as the three-module route over MDF files with the same -s (src/pcr.cpp:91-260, src/truncate.cpp:236-451)
+    bool pcr_on = false, pcr_have_cycles = false, pcr_have_count = false, pcr_have_er = false, pcr_have_ef = false;
+    tksmseq_pcr_params pcr{};
+    std::string pcr_preset;
+    uint64_t pcr_slice = 2000000;
+    int trc_n = 0;
+    tksmseq_trc_params trc{};
+    std::string trc_kde;
 };
 
 const char* OPTION_DESTS[] = {"help", "input", "references", "badread", "perfect", "skip_qual_compute", "output_format",
@@ -63,7 +73,10 @@ void usage(FILE* f) {
             "usage: sequence [-h] -i INPUT [-r REFERENCES [REFERENCES ...]] [-o BADREAD] [--perfect PERFECT]\n"
             "                [--skip-qual-compute] [-O {fastq,fasta}] [-t THREADS] [--badread-identity BADREAD_IDENTITY]\n"
             "                [--badread-error-model M] [--badread-qscore-model M] [--badread-tail-model M] [--list]\n"
-            "                [-s SEED] [--devices D[,D...]] [--batch-bytes B] [--in-flight N] [--verbosity L] [--log-file F]\n");
+            "                [-s SEED] [--devices D[,D...]] [--batch-bytes B] [--in-flight N] [--verbosity L] [--log-file F]\n"
+            "                [--pcr-cycles C --pcr-molecule-count N (--pcr-preset X | --pcr-error-rate E --pcr-efficiency F)]\n"
+            "                [--truncate-normal MU,SIGMA | --truncate-lognormal MU,SIGMA | --truncate-kde-model M.json\n"
+            "                 [--truncate-always-end] [--truncate-kde-models-length]]\n");
 }
 
 // one gzip member (RFC 1952) holding d[0..n): members simply follow each other in a .gz file, so batches -- and pieces of
@@ -121,55 +134,13 @@ struct Writer {
     }
 };
 
-// --verbosity / --log-file (src/module.h:95-122, src/util.h:94-120): levels DEBUG < INFO < WARN < ERROR < OFF; the file is
-// "stderr", "stdout" or a path.  What the reference's Python prints unconditionally (model loading progress, "Loading
-// reference") stays unconditional; the module's own diagnostics go through here.
-struct Logger {
-    enum Level { DEBUG = 0, INFO = 1, WARN = 2, ERROR = 3, OFF = 4 };
-    int level = INFO; FILE* f = stderr; bool own = false; std::mutex m;
-    static int parse(const std::string& v) {
-        static const char* names[] = {"DEBUG", "INFO", "WARN", "ERROR", "OFF"};
-        for (int i = 0; i < 5; i++) if (v == names[i]) return i;
-        return -1;
-    }
-    bool open(const std::string& path) {
-        if (path == "stderr") { f = stderr; return true; }
-        if (path == "stdout") { f = stdout; return true; }
-        FILE* g = fopen(path.c_str(), "a");
-        if (!g) return false;
-        f = g; own = true;
-        return true;
-    }
-    void log(int lv, const char* fmt, ...) __attribute__((format(printf, 3, 4))) {
-        if (lv < level || level == OFF) return;
-        static const char* tag[] = {"DBG", "INF", "WRN", "ERR"};
-        std::lock_guard<std::mutex> l(m);
-        fprintf(f, "[sequence %s] ", tag[lv]);
-        va_list ap; va_start(ap, fmt); vfprintf(f, fmt, ap); va_end(ap);
-        fputc('\n', f); fflush(f);
-    }
-    ~Logger() { if (own) fclose(f); }
-};
+// --verbosity / --log-file: module_log.h.  What the reference's Python prints unconditionally (model loading progress, "Loading
+// reference") stays unconditional; the module's own diagnostics go through the logger.
+using tkmod::Logger;
 
-// reads a batch of MDF text will produce: the depth column of every molecule header (mdf_generator, py/sequence.py:206-213)
-uint64_t count_reads(const char* p, size_t len) {
-    uint64_t n = 0;
-    const char* end = p + len;
-    while (p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* le = nl ? nl : end;
-        if (*p == '+') {
-            const char* t = (const char*)memchr(p, '\t', (size_t)(le - p));
-            long long d = 0;
-            if (t) { const char* q = t + 1; bool neg = false; if (q < le && *q == '-') { neg = true; q++; } while (q < le && *q >= '0' && *q <= '9') d = d * 10 + (*q++ - '0'); if (neg) d = 0; }
-            n += (uint64_t)d;
-        }
-        p = nl ? nl + 1 : end;
-    }
-    return n;
-}
+using tkmod::count_reads;
 
-struct Chunk { uint64_t seq = 0, first_read = 0, n_reads = 0; std::vector<char> text; };
+struct Chunk { uint64_t seq = 0, first_read = 0, n_reads = 0; std::vector<char> text; uint64_t t_begin = 0, t_end = 0; };   // text, or (chained PCR) a slice of the templates
 
 struct ChunkQueue {                                       // bounded, closed by the reader at end of input
     std::mutex m; std::condition_variable cv_put, cv_get; std::deque<Chunk> q; size_t cap = 2; bool closed = false;
@@ -252,16 +223,7 @@ class Sequencer_module::impl {
             else if (o == "--devices") {
                 // comma-separated device list: one group of --in-flight contexts per entry (an entry may repeat)
                 if (!(v = need(i))) return 2;
-                a.devices.clear();
-                const char* q = v;
-                for (;;) {
-                    char* e = nullptr;
-                    const long d = strtol(q, &e, 10);
-                    if (e == q || d < 0 || (*e && *e != ',')) { usage(stderr); fprintf(stderr, "sequence: error: argument --devices: invalid device list: '%s'\n", v); return 2; }
-                    a.devices.push_back((int)d);
-                    if (!*e) break;
-                    q = e + 1;
-                }
+                if (!tkmod::parse_device_list(v, a.devices)) { usage(stderr); fprintf(stderr, "sequence: error: argument --devices: invalid device list: '%s'\n", v); return 2; }
             }
             else if (o == "--batch-bytes") {
                 if (!(v = need(i))) return 2;
@@ -274,6 +236,24 @@ class Sequencer_module::impl {
                 a.in_flight = atoi(v);
                 if (a.in_flight < 1) { usage(stderr); fprintf(stderr, "sequence: error: argument --in-flight: expected a positive integer, got '%s'\n", v); return 2; }
             }
+            else if (o == "--pcr-cycles") { if (!(v = need(i))) return 2; a.pcr.cycles = atoi(v); a.pcr_have_cycles = true; }
+            else if (o == "--pcr-molecule-count") { if (!(v = need(i))) return 2; a.pcr.target_count = strtoull(v, nullptr, 10); a.pcr_have_count = true; }
+            else if (o == "--pcr-error-rate") { if (!(v = need(i))) return 2; a.pcr.error_rate = atof(v); a.pcr_have_er = true; }
+            else if (o == "--pcr-efficiency") { if (!(v = need(i))) return 2; a.pcr.efficiency = atof(v); a.pcr_have_ef = true; }
+            else if (o == "--pcr-preset") { if (!(v = need(i))) return 2; a.pcr_preset = v; }
+            else if (o == "--pcr-slice-molecules") { if (!(v = need(i))) return 2; a.pcr_slice = std::max<uint64_t>(1, strtoull(v, nullptr, 10)); }
+            else if (o == "--truncate-normal" || o == "--truncate-lognormal") {
+                if (!(v = need(i))) return 2;
+                char* e = nullptr;
+                a.trc.mu = strtod(v, &e);
+                if (!e || *e != ',') { usage(stderr); fprintf(stderr, "sequence: error: argument %s: expected MU,SIGMA\n", o.c_str()); return 2; }
+                a.trc.sigma = strtod(e + 1, &e);
+                if (!e || *e) { usage(stderr); fprintf(stderr, "sequence: error: argument %s: expected MU,SIGMA\n", o.c_str()); return 2; }
+                a.trc.mode = o == "--truncate-normal" ? TKSMSEQ_TRC_NORMAL : TKSMSEQ_TRC_LOGNORMAL; a.trc_n++;
+            }
+            else if (o == "--truncate-kde-model") { if (!(v = need(i))) return 2; a.trc_kde = v; a.trc.mode = TKSMSEQ_TRC_KDE; a.trc_n++; }
+            else if (o == "--truncate-always-end") a.trc.always_end = 1;
+            else if (o == "--truncate-kde-models-length") a.trc.kde_models_length = 1;
             else if (o == "--verbosity") { if (!(v = need(i))) return 2; a.verbosity = v; }
             else if (o == "--log-file") { if (!(v = need(i))) return 2; a.log_file = v; }
             else { usage(stderr); fprintf(stderr, "sequence: error: unrecognized arguments: %s\n", argv[i]); return 2; }
@@ -317,6 +297,25 @@ public:
         if (mean > maxi) { char b[200]; snprintf(b, sizeof b, "Error: mean identity (%g) cannot be larger than max identity (%g)", mean, maxi); return die(b); }
         if (sd < 0.0) return die("Error: read identity stdev cannot be negative");
         if (a.badread.empty() && a.perfect.empty()) { usage(stderr); fprintf(stderr, "sequence: error: Must specify either --output or --perfect.\n"); return 2; }
+        // the chained stages' own argument checks (src/pcr.cpp:148-185, src/truncate.cpp:278-300)
+        a.pcr_on = a.pcr_have_cycles || a.pcr_have_count || a.pcr_have_er || a.pcr_have_ef || !a.pcr_preset.empty();
+        if (a.pcr_on) {
+            int missing = 0;
+            if (!a.pcr_have_count) { fprintf(stderr, "molecule-count is required!\n"); missing++; }
+            if (!a.pcr_have_cycles) { fprintf(stderr, "cycles is required!\n"); missing++; }
+            if (!a.pcr_preset.empty()) {
+                double er = 0, ef = 0;
+                if (tksmseq_pcr_preset(a.pcr_preset.c_str(), &er, &ef)) { fprintf(stderr, "Preset %s not found\n", a.pcr_preset.c_str()); missing++; }
+                else { if (!a.pcr_have_er) a.pcr.error_rate = er; if (!a.pcr_have_ef) a.pcr.efficiency = ef; }
+            } else {
+                if (!a.pcr_have_er) { fprintf(stderr, "Error rate is required!\n"); missing++; }
+                if (!a.pcr_have_ef) { fprintf(stderr, "Efficiency is required!\n"); missing++; }
+            }
+            if (missing) return 1;
+            a.pcr.seed = (uint64_t)a.seed;
+        }
+        if (a.trc_n > 1) return die("Only one of kde-model, normal or lognormal is allowed!");
+        if (a.trc_n == 1) { a.trc.seed = (uint64_t)a.seed; if (a.trc.mode == TKSMSEQ_TRC_KDE) a.trc.kde_model_path = a.trc_kde.c_str(); }
 
         // utility flags (src/module.h:106-125)
         Logger log;
@@ -461,6 +460,7 @@ public:
         if (verbose) fprintf(stderr, "[sequence] device, reference and models ready after %.2f s\n", std::chrono::duration<double>(t_start - t_begin).count());
         uint64_t total_reads = 0;
 
+        std::vector<tksmseq_batch*> templates((size_t)n_groups, nullptr);        // chained PCR: the whole input, one batch per device group
         auto parse_ahead = [&](int pi) {
             tksmseq_ctx* pc = pctx[(size_t)pi];
             ParsedQueue& out = *pq[(size_t)(pi / parsers_per_group)];
@@ -472,7 +472,21 @@ public:
                 bool ok = !failed;
                 if (ok) {
                     const auto t_parse = now();
-                    if (tksmseq_batch_from_mdf_text(pc, c.text.data(), c.text.size(), &pr.b)) { set_error(tksmseq_last_error(pc)); ok = false; }
+                    if (a.pcr_on) {
+                        // a slice of the templates amplified on the device: its copies are numbered from c.first_read on
+                        tksmseq_pcr_params q = a.pcr;
+                        q.template_begin = c.t_begin; q.template_end = c.t_end;
+                        if (c.t_begin == c.t_end) { q.template_begin = q.template_end = 0; q.cycles = 0; }
+                        if (tksmseq_pcr(pc, templates[(size_t)(pi / parsers_per_group)], &q, &pr.b)) { set_error(tksmseq_last_error(pc)); ok = false; }
+                    } else if ((a.trc_n ? tksmseq_molecules_from_mdf_text : tksmseq_batch_from_mdf_text)(pc, c.text.data(), c.text.size(), &pr.b)) { set_error(tksmseq_last_error(pc)); ok = false; }
+                    if (ok && a.trc_n) {
+                        tksmseq_trc_params q = a.trc;
+                        q.first_molecule_index = c.first_read;
+                        tksmseq_batch* cut = nullptr;
+                        if (tksmseq_truncate(pc, pr.b, &q, &cut)) { set_error(tksmseq_last_error(pc)); ok = false; }
+                        tksmseq_batch_free(pc, pr.b);
+                        pr.b = cut;
+                    }
                     add_clk(0, t_parse);
                 }
                 std::unique_lock<std::mutex> l(out.order_m);
@@ -634,6 +648,35 @@ public:
         uint64_t read_index = 0, seq = 0;
         bool eof = false;
         size_t have = 0;
+        if (a.pcr_on) {
+            // chained PCR (src/pcr.cpp:215: the module holds its whole input): the templates go to every device group once; the
+            // copies per template (tksmseq_pcr_template_counts) cut them into slices of about --pcr-slice-molecules copies, which
+            // the parser threads amplify (and truncate) in place of parsing text
+            std::vector<char> all;
+            { char tmp[1 << 16]; size_t n2; while ((n2 = fread(tmp, 1, sizeof tmp, in)) > 0) all.insert(all.end(), tmp, tmp + n2); }
+            for (int g = 0; g < n_groups && !failed; g++)
+                if (tksmseq_molecules_from_mdf_text(pctx[(size_t)g * parsers_per_group], all.data(), all.size(), &templates[(size_t)g])) set_error(tksmseq_last_error(pctx[(size_t)g * parsers_per_group]));
+            uint64_t nt = 0;
+            std::vector<uint64_t> counts;
+            if (!failed) {
+                tksmseq_batch_info(templates[0], &nt, nullptr, nullptr);
+                counts.resize(nt);
+                if (tksmseq_pcr_template_counts(pctx[0], templates[0], &a.pcr, counts.data())) set_error(tksmseq_last_error(pctx[0]));
+            }
+            uint64_t u0 = 0, acc = 0;
+            auto emit_slice = [&](uint64_t b0, uint64_t e0, uint64_t n_out) {
+                Chunk c;
+                c.seq = seq++; c.first_read = read_index; c.n_reads = n_out; c.t_begin = b0; c.t_end = e0;
+                read_index += n_out;
+                queue.push(std::move(c));
+            };
+            for (uint64_t u = 0; u < nt && !failed; u++) {
+                acc += counts[u];
+                if (acc >= a.pcr_slice && u + 1 < nt) { emit_slice(u0, u + 1, acc); u0 = u + 1; acc = 0; }
+            }
+            if (!failed) emit_slice(u0, nt, acc);                   // the last slice (the only, empty one of an input without molecules)
+            eof = true; have = 0;
+        }
         while ((!eof || have) && !failed) {
             // fill up to batch_bytes, then cut at the last molecule header so a batch holds whole molecules
             const auto t_read = now();
@@ -665,6 +708,7 @@ public:
         for (auto& t : parsers) t.join();
         for (auto& q2 : pq) q2->close();                                                           // (the workers take what is still queued)
         for (auto& t : threads) t.join();
+        for (int g = 0; g < n_groups; g++) if (templates[(size_t)g]) tksmseq_batch_free(pctx[(size_t)g * parsers_per_group], templates[(size_t)g]);
         done_cv.notify_all();
         if (writer.joinable()) writer.join();
         if (positional && !failed) { wb.wrote = place[0] != 0; wp.wrote = place[1] != 0; }

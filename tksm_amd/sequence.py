@@ -226,8 +226,9 @@ class Sequencer:
         return Batch(self, h)
 
     # ---- molecule-description transforms upstream of Seq (device to device)
-    def pcr(self, batch, cycles, target_count, error_rate=None, efficiency=None, preset=None, seed=42):
-        """PCR::perform (src/pcr.cpp:66-89) on the device; preset: one of the names of src/pcr.cpp:136-140."""
+    def pcr(self, batch, cycles, target_count, error_rate=None, efficiency=None, preset=None, seed=42, templates=None):
+        """PCR::perform (src/pcr.cpp:66-89) on the device; preset: one of the names of src/pcr.cpp:136-140; templates = (begin,
+        end): the copies of that slice of the input molecules only (slices, one after the other = the whole)."""
         if preset is not None:
             er, ef = C.c_double(), C.c_double()
             if self._lib.tksmseq_pcr_preset(preset.encode(), C.byref(er), C.byref(ef)):
@@ -236,10 +237,19 @@ class Sequencer:
             efficiency = ef.value if efficiency is None else efficiency
         if error_rate is None or efficiency is None:
             raise ValueError("Error rate is required!" if error_rate is None else "Efficiency is required!")
-        p = L.PcrParams(seed, target_count, cycles, 0, error_rate, efficiency)
+        tb, te = templates if templates is not None else (0, 0)
+        p = L.PcrParams(seed, target_count, cycles, 0, error_rate, efficiency, tb, te)
         h = C.c_void_p()
         self._chk(self._lib.tksmseq_pcr(self._ctx, batch._h, C.byref(p), C.byref(h)))
         return Batch(self, h)
+
+    def pcr_template_counts(self, batch, cycles, target_count, error_rate, efficiency, seed=42):
+        """written copies per input molecule (tksmseq_pcr_template_counts)"""
+        import numpy as np
+        p = L.PcrParams(seed, target_count, cycles, 0, error_rate, efficiency, 0, 0)
+        out = np.zeros(batch.n_reads, np.uint64)
+        self._chk(self._lib.tksmseq_pcr_template_counts(self._ctx, batch._h, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def truncate(self, batch, normal=None, lognormal=None, kde_model=None, always_end=False, kde_models_length=False, seed=42,
                  first_molecule_index=0):
