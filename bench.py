@@ -162,6 +162,10 @@ def main():
     ap.add_argument("--lognormal-sigma", type=float, default=0.0, help="transcript-like skewed lengths: lognormal, median --mean-len")
     ap.add_argument("--pipeline", type=int, default=3, help="contexts in flight per GPU (1 = one batch at a time)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg")
+    ap.add_argument("--ordering", default="gather", choices=["gather", "offsets"],
+                    help="N > 1: gather = exact-size send / recv of every rank's records to rank 0 + device interleave (north_star); "
+                         "offsets = all_gather of record lengths only, every rank learns its records' final file offsets (tksm_amd/ordering.py)")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the short legs on the other workloads (scRNA-like, PCR-like, lognormal lengths)")
     ap.add_argument("--e2e-molecules", type=int, default=8_000_000)
     args = ap.parse_args()
 
@@ -254,32 +258,39 @@ def main():
         c.free = threading.Semaphore(c.n_out)    # output buffers of the context that may be overwritten
     m = ctxs[0].m
 
-    gathered = None
+    from tksm_amd import ordering
     xstream = torch.cuda.Stream(device=dev) if exchange_on else None
 
     def run_step(c, t):
         return c.seqr.run(c.batch, target=target, fastq=True, compute_qual=compute_q, seed=42,
                           first_read_index=t * args.batch * world + rank, stride=world)
 
-    xseq = first.seqr.clone() if exchange_on else None       # its own context (stream, work buffers) for the interleave on rank 0
+    # rank 0's interleave runs on the exchange stream itself (a context of its own on that stream): it follows the receives in
+    # stream order, no host synchronisation in between
+    xseq = first.seqr.clone(stream=xstream.cuda_stream) if exchange_on else None
+    xbuf = {"bytes": None, "offs": None, "out": None, "keep": None}
 
-    def exchange(out_t, off_t):
-        """FASTQ ordering (N > 1): gather of the per-rank record streams (fixed width: a rank's output capacity) and their record
-        offsets to rank 0 over RCCL, then the device-side interleave into global read order -- on the exchange thread, on its
-        own stream and context, while the compute contexts run their next steps."""
-        nonlocal gathered
+    def exchange(out_t, off_t, n_bytes):
+        """FASTQ ordering (N > 1, tksm_amd/ordering.py) on the exchange thread and stream, while the compute contexts run their next
+        steps.  gather: the ranks' byte counts (all_gather), then exactly the record bytes and offsets of every rank to rank 0
+        (send / recv over RCCL), and the device interleave into global read order.  offsets: the ranks' record lengths only."""
         with torch.cuda.stream(xstream):
-            if rank == 0 and gathered is None:
-                gathered = ([torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)],
-                            [torch.empty(args.batch + 1, dtype=torch.int64, device=dev) for _ in range(world)],
-                            torch.empty(int(cap * world), dtype=torch.uint8, device=dev))
-            dist.gather(out_t, gathered[0] if rank == 0 else None, dst=0)
-            dist.gather(off_t, gathered[1] if rank == 0 else None, dst=0)
-            xstream.synchronize()
+            if args.ordering == "offsets":
+                xbuf["keep"] = ordering.global_offsets(off_t[1:] - off_t[:-1], [args.batch] * world, rank, world)
+                return
+            sizes = ordering.exchange_sizes(n_bytes, args.batch, world, dev)
             if rank == 0:
-                xseq.interleave_records([g.data_ptr() for g in gathered[0]], [g.data_ptr() for g in gathered[1]],
-                                        [args.batch] * world, gathered[2].data_ptr(), gathered[2].numel())
-                xseq.synchronize()
+                need_b, need_o = int(sizes[:, 0].sum()), int(sizes[:, 1].sum()) + world
+                if xbuf["bytes"] is None or xbuf["bytes"].numel() < need_b:
+                    xbuf["bytes"] = torch.empty(int(need_b * 1.02) + 4096, dtype=torch.uint8, device=dev)
+                    xbuf["out"] = torch.empty(int(need_b * 1.02) + 4096, dtype=torch.uint8, device=dev)
+                if xbuf["offs"] is None or xbuf["offs"].numel() < need_o:
+                    xbuf["offs"] = torch.empty(need_o, dtype=torch.int64, device=dev)
+            got = ordering.gather_exact(out_t[:n_bytes], off_t, sizes, rank, world, xbuf["bytes"], xbuf["offs"])
+            if rank == 0:
+                fb, bstart, fo, ostart = got
+                xseq.interleave_records([fb.data_ptr() + int(bstart[p]) for p in range(world)], [fo.data_ptr() + 8 * int(ostart[p]) for p in range(world)],
+                                        [args.batch] * world, xbuf["out"].data_ptr(), xbuf["out"].numel())
 
     def run_steps(first, count):
         """steps first .. first+count-1: context t mod n_ctx runs step t on its own thread; with N > 1 the main thread
@@ -303,7 +314,7 @@ def main():
                         off_t = c.off_ts[c.turn]
                         results[j].copy_to_device(None, off_t.data_ptr())
                         c.seqr.synchronize()
-                        handed[j] = (c.out_ts[c.turn], off_t)
+                        handed[j] = (c.out_ts[c.turn], off_t, int(results[j].records_bytes))
                         c.turn = (c.turn + 1) % c.n_out
                         c.seqr.set_output_buffer(c.out_ts[c.turn].data_ptr(), cap)
                     done[j].set()
@@ -409,7 +420,7 @@ def main():
                    "kind": args.kind, "molecules_per_gpu_per_step": args.batch, "mean_len": args.mean_len,
                    "length_distribution": f"lognormal(median {args.mean_len}, sigma {args.lognormal_sigma})" if args.lognormal_sigma else f"normal({args.mean_len}, {args.mean_len * 0.2:.0f})",
                    "compute_qual": bool(compute_q and not args.perfect), "sharding": f"round-robin x{world}",
-                   "ordering_gather": exchange_on, "contexts_in_flight_per_gpu": n_ctx},
+                   "ordering": (args.ordering if exchange_on else None), "contexts_in_flight_per_gpu": n_ctx},
         "gbases_per_s": bases_in_all / elapsed / 1e9,
         "gbases_out_per_s": bases_out_all / elapsed / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -419,6 +430,42 @@ def main():
                      "exclusive_ms_per_step": exclusive, "overlapped_ms_per_step": overlapped,
                      "overlapped_all_kernels_ms": float(np.mean(tot_ms)), "overlapped_simulate_stage_ms": float(np.mean(sim_ms))},
     }
+    if world == 1 and not exchange_on and not args.no_side_legs and not args.perfect and args.kind == "bulk" and not args.lognormal_sigma:
+        # short driver-timed legs on the other workloads (same contexts, models and genome; 1 warm-up round + 3 timed steps each;
+        # never `value`): BASELINE config 3's scRNA-like molecules, config 5's substitution-heavy molecules, transcript-like lengths
+        side = {}
+        legs = (("scrna", dict(kind="scrna"), args.batch), ("pcr", dict(kind="pcr"), args.batch),
+                ("lognormal_sigma_0.6", dict(kind="bulk", lognormal_sigma=0.6), min(args.batch, 1048576)))
+        for name, kw, nb in legs:
+            try:
+                for i, c in enumerate(ctxs):
+                    c.batch.free()
+                    rs = np.random.RandomState(7000 + 10 * i + len(name))
+                    mm = synthetic.make_molecules(rs, [clen] * args.genome_contigs, nb, args.mean_len, args.mean_len * 0.2, id_prefix="s", **kw)
+                    c.batch = c.seqr.batch_from_arrays(mm["reads"], mm["intervals"], mm["mods"], mm["literals"], mm["literal_pool"], mm["ids"], mm["id_pool"])
+                    c.seqr.set_output_buffer(0, 0)             # (records of other sizes: the context's own buffer)
+                def leg_step(c, t):
+                    return c.seqr.run(c.batch, target=target, fastq=True, compute_qual=compute_q, seed=42, first_read_index=t * nb, stride=1)
+                def leg_steps(t0, count):
+                    res = [None] * count
+                    def w(i):
+                        torch.cuda.set_device(local_rank)
+                        for j in range(i, count, n_ctx):
+                            res[j] = leg_step(ctxs[i], t0 + j)
+                    th = [threading.Thread(target=w, args=(i,)) for i in range(min(n_ctx, count))]
+                    [x.start() for x in th]; [x.join() for x in th]
+                    return res
+                leg_steps(0, n_ctx)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rr = leg_steps(n_ctx, 3)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                side[name] = {"reads_per_s": 3 * nb / dt, "gbases_per_s": sum(r.bases_in for r in rr) / dt / 1e9, "steps": 3, "molecules_per_step": nb,
+                              "ms_per_step": dt / 3 * 1e3}
+            except Exception as e:                   # a side leg never costs the bench line
+                side[name] = {"reads_per_s": None, "error": repr(e)[:300]}
+        out["side_legs"] = side
     if world == 1 and not args.no_e2e and not args.perfect and args.kind == "bulk":
         # the CLI is another process on the same GPU: release this one's contexts and buffers first
         if xseq is not None:

@@ -3136,7 +3136,11 @@ __global__ __launch_bounds__(256) void k_interleave_copy(int P_, PtrPack streams
     const uint8_t* s = (const uint8_t*)streams.p[p] + o[i];
     const uint64_t len = o[i + 1] - o[i];
     uint8_t* d = dst + dst_off[gi];
-    for (uint64_t t = lane; t < len; t += 64) d[t] = s[t];
+    // 16 bytes per lane and step (neither side is aligned: records have any length), the last bytes one at a time
+    struct __attribute__((packed, aligned(1))) U16 { uint4 v; };
+    const uint64_t body = len & ~15ull;
+    for (uint64_t t = 16ull * lane; t < body; t += 1024) *reinterpret_cast<U16*>(d + t) = *reinterpret_cast<const U16*>(s + t);
+    if (body + lane < len) d[body + lane] = s[body + lane];
 }
 
 // ------------------------------------------------------------------------------------------------
