@@ -16,8 +16,8 @@ RNG keyed by g), per-GPU batch fixed (weak scaling); every step ends with the RC
 streams to rank 0 and the device-side interleave into global read order (the FASTQ-order exchange step).
 
 Prints ONE JSON line on rank 0 (contract in the round instructions), including
-  `roofline`      dominant kernel = the largest of k_loop (error loop, one lane per read; with k_loopw, its wave-per-read form for the late rounds), k_job (alignment windows packed, one lane
-                  per job) and k_aln (bit-parallel alignments, one lane per alignment) by EXCLUSIVE time: after the timed steps one
+  `roofline`      dominant kernel = the larger of k_loop (error loop, one lane per read; with k_loopw, its wave-per-read form for the late rounds) and k_alnf (alignment windows
+                  decoded and aligned bit-parallel, one lane per alignment; all its instantiations: 14-row pass, full-width redo and small rounds, q-score round) by EXCLUSIVE time: after the timed steps one
                   more step runs on one context alone (nothing else on the GPU) with HIP events around every launch on its stream;
                   achieved = algorithmic bytes of a step / that kernel's summed launch durations in that step.  The overlapped
                   sums measured during the timed steps (three contexts sharing the GPU) are reported next to it.
@@ -360,14 +360,13 @@ def main():
     rec_bytes = sum(r.records_bytes for r in results)
     bases_in = sum(r.bases_in for r in results)
     bases_out = sum(r.bases_out for r in results)
-    overlapped = {"k_loop": float(np.mean([r.kernel_ms[5] for r in results])), "k_aln": float(np.mean([r.kernel_ms[6] for r in results])),
-                  "k_job": float(np.mean([r.kernel_ms[7] for r in results]))}
+    overlapped = {"k_loop": float(np.mean([r.kernel_ms[5] for r in results])), "k_alnf": float(np.mean([r.kernel_ms[6] for r in results]))}
     # exclusive per-kernel time: one more step on one context with the GPU to itself (untimed for `value`)
     fence()
     rx = run_step(ctxs[0], args.warmup * n_ctx + args.steps)
     ctxs[0].seqr.synchronize()
     fence()
-    exclusive = {"k_loop": float(rx.kernel_ms[5]), "k_aln": float(rx.kernel_ms[6]), "k_job": float(rx.kernel_ms[7]),
+    exclusive = {"k_loop": float(rx.kernel_ms[5]), "k_alnf": float(rx.kernel_ms[6]),
                  "simulate_stage_total": float(rx.kernel_ms[1]), "all_kernels": float(rx.kernel_ms[4])}
     if exchange_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -393,10 +392,10 @@ def main():
         dom, dom_ms = "k_perfect", float(rx.kernel_ms[3])
         overlapped = {"k_perfect": float(np.mean([r.kernel_ms[3] for r in results]))}
         exclusive = {"k_perfect": dom_ms, "all_kernels": float(rx.kernel_ms[4])}
-    elif exclusive["k_loop"] + exclusive["k_aln"] == 0.0:
+    elif exclusive["k_loop"] + exclusive["k_alnf"] == 0.0:
         dom, dom_ms = "k_simulate", exclusive["simulate_stage_total"]
     else:
-        dom = max(("k_loop", "k_aln", "k_job"), key=lambda k: exclusive[k])
+        dom = max(("k_loop", "k_alnf"), key=lambda k: exclusive[k])
         dom_ms = exclusive[dom]
     achieved = alg / (dom_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None

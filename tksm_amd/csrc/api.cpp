@@ -44,7 +44,6 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_SMALL_ROUND")) c->small_round = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_WAVE_LOOP")) c->wave_loop = (uint32_t)atoi(tc);
-    if (const char* tc = getenv("TKSMSEQ_FUSED")) c->fused = tc[0] != '0';
     if (const char* tc = getenv("TKSMSEQ_ALN_LDS_PAD")) c->aln_lds_pad = (unsigned)std::min(60000, std::max(0, atoi(tc)));
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
@@ -693,15 +692,14 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.n_ranges = (uint32_t)((n + FB.rs - 1) / FB.rs);
         const uint64_t jcap = (uint64_t)FB.n_ranges * FB.rs;     // job slots (>= n)
         // rows of a range's jobs are sized by the range's longest read
-        std::vector<uint32_t> r_ncap(FB.n_ranges), r_cw(FB.n_ranges);
+        std::vector<uint32_t> r_ncap(FB.n_ranges);
         std::vector<uint32_t> r_tg(FB.n_ranges);              // 64-byte lines of predecessor codes per job (16 columns each, one spare)
-        uint64_t tot_trace = 0, tot_jc = 0, tot_popd = 0;
+        uint64_t tot_trace = 0, tot_popd = 0;
         for (uint32_t c = 0; c < FB.n_ranges; c++) {
             const uint64_t last = std::min<uint64_t>((uint64_t)(c + 1) * FB.rs, n) - 1;
             r_ncap[c] = (uint32_t)capf(b->raw_len[b->order[last]]);
-            r_cw[c] = (r_ncap[c] / 8 + 8 + 3) & ~3u;
             r_tg[c] = ((r_ncap[c] + 31) & ~31u) / 16 + 1;
-            tot_trace += (uint64_t)FB.rs * r_tg[c]; tot_jc += (uint64_t)FB.rs * r_cw[c]; tot_popd += (uint64_t)FB.rs * r_ncap[c];
+            tot_trace += (uint64_t)FB.rs * r_tg[c]; tot_popd += (uint64_t)FB.rs * r_ncap[c];
         }
         HIPCHK(ctx, ctx->f_state.ensure(n * sizeof(tk::ReadState) + 64));
         // ragged per-read state rows: whole 64-position blocks, the padded fragment + at least one spare block
@@ -720,8 +718,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             HIPCHK(ctx, ctx->f_jmeta[z].ensure(jcap * 16 + 64));
             if (z == 0) {
                 // (one set: only the meta records and the counts of the previous round are read again)
-                HIPCHK(ctx, ctx->f_jcols[z].ensure(tot_jc * 16 + 64));
-                HIPCHK(ctx, ctx->f_jwin[z].ensure(jcap * 16 + 64));
                 HIPCHK(ctx, ctx->f_jpopd[z].ensure(tot_popd + 64));
             }
         }
@@ -749,12 +745,9 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         HIPCHK(ctx, ctx->f_trace.ensure(tot_trace * 64 + 64));                     // predecessor codes of the first alignment pass
         HIPCHK(ctx, ctx->f_redo.ensure(jcap * 4 + 64));
         // pool of full-width rows: as many as a round can ask for, at most 4 GB (homopolymer-rich batches need many)
-        FB.full_tg = (((uint32_t)ncap + 31) & ~31u) / 4 + 1;
-        if (ctx->fused) {
-            // code lines (4 iterations each; whole passes of 16 iterations, some room for drain passes), one uint4 of shift bytes per pass, a spare line
-            FB.full_cl = ((((uint32_t)ncap + 31) & ~31u) / 4 + 16 + 3) & ~3u;
-            FB.full_tg = FB.full_cl + (FB.full_cl / 4 + 3) / 4 + 1;
-        }
+        // code lines (4 iterations each; whole passes of 16 iterations, some room for drain passes), one uint4 of shift bytes per pass, a spare line
+        FB.full_cl = ((((uint32_t)ncap + 31) & ~31u) / 4 + 16 + 3) & ~3u;
+        FB.full_tg = FB.full_cl + (FB.full_cl / 4 + 3) / 4 + 1;
         FB.full_rows = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(jcap, (4ull << 30) / ((uint64_t)FB.full_tg * 64)) & ~63ull);
         HIPCHK(ctx, ctx->f_tracefull.ensure((size_t)FB.full_rows * FB.full_tg * 64 + 64));
         HIPCHK(ctx, ctx->f_slow.ensure(n * 4 + 64));
@@ -772,7 +765,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.geo_cur = reinterpret_cast<tk::RangeGeo*>(ctx->f_geoall.as<uint8_t>() + geo_off); FB.geo_prev = FB.geo_cur + FB.n_ranges;
         auto select_set = [&](uint32_t round) {
             const int z = round & 1, y = z ^ 1;
-            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>(); FB.job_cols = ctx->f_jcols[0].as<uint4>(); FB.job_win = ctx->f_jwin[0].as<unsigned long long>();
+            FB.job_meta = ctx->f_jmeta[z].as<uint32_t>();
             FB.job_popd = ctx->f_jpopd[0].as<uint8_t>(); FB.job_cnt = reinterpret_cast<uint32_t*>(d_round + (z ? nrb + 1024 : 0));
             FB.prev_meta = ctx->f_jmeta[y].as<uint32_t>(); FB.prev_popd = ctx->f_jpopd[0].as<uint8_t>();
         };
@@ -796,9 +789,9 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 const uint64_t slots = hbase_cur[c + 1] - hbase_cur[c];
                 tk::RangeGeo g{};
                 g.trace_off = ot; g.jc_off = oj; g.popd_off = op;
-                g.tstride = r_tg[c]; g.cw = r_cw[c]; g.ncap = r_ncap[c];
+                g.tstride = r_tg[c]; g.ncap = r_ncap[c];
                 hrg[c] = g;
-                ot += slots * g.tstride; oj += slots * g.cw; op += slots * g.ncap;
+                ot += slots * g.tstride; op += slots * g.ncap;
             }
             return hipMemcpyAsync(ctx->f_geoall.p, ctx->h_geo, geo_bytes, hipMemcpyHostToDevice, s);      // {prefix, bases} go along
         };
@@ -890,7 +883,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 // against the whole fragment (k_qjobs + k_job, then k_aln below); without: their output, in this one round
                 if (P.compute_q) {
                     HIPCHK(ctx, tk::launch_qjobs(FB, k, n_deferred, s));
-                    if (!ctx->fused) HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
                 } else {
                     const Bucket& bk = buckets.back();
                     HIPCHK(ctx, tk::launch_err(B, EM, QM, P, O, FB, b->d_order.as<uint32_t>(), 0, n_deferred, bk.lcap, bk.ncap, 2, 0, FB.n_ranges, bk.wpw, bk.hbm, s));
@@ -924,7 +916,6 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 else HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
                 if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
                 kinds.push_back(1);
-                if (!ctx->fused) HIPCHK(ctx, tk::launch_job(P, FB, O, hbase_cur[FB.n_ranges], s));
                 regular = true;
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
@@ -974,8 +965,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             {
                 const uint32_t n_jobs = hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u);
                 const bool full_only = cnt[0] <= std::min(ctx->small_aln, FB.full_rows);
-                if (ctx->fused) HIPCHK(ctx, tk::launch_alnf(P, FB, O, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, s));
-                else HIPCHK(ctx, tk::launch_aln(P, FB, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, s));
+                HIPCHK(ctx, tk::launch_alnf(P, FB, O, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, s));
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);

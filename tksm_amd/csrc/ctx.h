@@ -116,7 +116,7 @@ struct tksmseq_ctx : ContigLookup {
         w_scratch, w_records, w_istats, w_dstats, w_sums, w_fullpool, w_biglist, w_bigscratch, w_bigtrace;
     unsigned long long full_pool_bytes = 1ull << 30;
     // fast Badread pipeline state (see kernels.h FastBuffers)
-    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_jcols[2], f_jwin[2], f_redo, f_jpopd[2], f_trace, f_tracefull, f_slow, f_defer, f_defercnt, f_frag2, f_row64;
+    DevBuf f_state, f_frag, f_nb, f_fplanes, f_jmeta[2], f_redo, f_jpopd[2], f_trace, f_tracefull, f_slow, f_defer, f_defercnt, f_frag2, f_row64;
     std::vector<uint32_t> h_row64;        // host copy of the state-row offsets of the current run
     // what the host and the device exchange in every round, in one copy each way: f_round = {job counts of the even rounds,
     // counters, job counts of the odd rounds} -> h_round; h_geo = {prefix, bases, range geometry} -> f_geoall (page-locked)
@@ -124,7 +124,6 @@ struct tksmseq_ctx : ContigLookup {
     uint32_t* h_round = nullptr; size_t h_round_bytes = 0;
     uint8_t* h_geo = nullptr; size_t h_geo_bytes = 0;
     bool force_slow = false;
-    bool fused = true;          // windows decoded inside the alignment kernel (k_alnf); false: k_job + k_aln (round 2), for A/B runs
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
     uint32_t wave_loop = 16384;           // rounds with at most this many reads left run the error loop one wave per read (k_loopw)
     unsigned aln_lds_pad = 0;             // LDS the first alignment pass asks for without using it: caps its waves per CU (kernels.hip launch_aln)

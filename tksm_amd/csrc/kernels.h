@@ -131,11 +131,11 @@ struct ReadState {
 // read of the range needs (a batch's longest read is twice its mean), and ranges are packed one after the other.
 struct RangeGeo {
     uint64_t trace_off;   // 64-byte lines into trace
-    uint64_t jc_off;      // records into job_cols
+    uint64_t jc_off;      // (unused since the block records went: round 3)
     uint64_t popd_off;    // bytes into job_popd
     uint64_t unused;
     uint32_t tstride;     // lines of predecessor codes per job (16 columns each; the last one is spare)
-    uint32_t cw;          // block records per job row
+    uint32_t cw;          // (unused)
     uint32_t ncap;        // joined-window capacity of the range (multiple of 16)
     uint32_t pad;
 };
@@ -148,17 +148,12 @@ struct FastBuffers {
     unsigned long long* st_fplanes;   // [blocks + 8 n_reads][2] 2-bit planes of the padded fragments, {lo, hi} word pairs
     uint32_t* st_frag2;               // [4 blocks + 4 n_reads] the padded fragments, 16 bases per word, first base in the top bits: what the
                                       // error loop (k_loop, one LANE per read) keeps in LDS and cuts its k-mers from
-    uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, m}
-    // [n_reads][cw] one 16-byte record per 8 columns of the joined window: {bits 0-3 of the columns' window shifts,
-    // low | high << 8 bits of the columns' 2-bit base codes | bit 4 of the shifts << 16, low / high code bit of the 32 fragment rows that follow
-    // the window at the start of the block}: k_aln never touches the per-read fragment planes again
-    uint4* job_cols;
-    unsigned long long* job_win;      // [n_reads][2] code planes of the first 64 window rows
+    uint32_t* job_meta;               // [n_reads][4] {read, p0, n | mode << 31, -}
     uint8_t* job_popd;                // [n_reads][ncap] per read position: op | D-run << 2 (q-score jobs)
-    void* trace;                      // predecessor codes of the first alignment pass (16 band rows, 4 bytes per column): 64-byte lines of 16
-                                      // columns, per range [wave][line][lane] (RangeGeo::trace_off / tstride)
+    void* trace;                      // predecessor codes of the first alignment pass (14 band rows + the column's shift: 4 bytes per iteration):
+                                      // 64-byte lines of 16 iterations, per range [wave][line][lane] (RangeGeo::trace_off / tstride)
     uint32_t* redo_list;              // jobs whose path left the stored rows of pass 1 (counters[10] of them): 64-row pass
-    void* trace_full;                 // pool of the passes that store all 64 rows (16 bytes per column, 4 columns per line): [wave][full_tg lines][lane]; counters[3] allocates
+    void* trace_full;                 // pool of the passes that store all 64 rows (16 bytes per iteration, 4 per line; shift bytes behind them): [wave][full_tg lines][lane]; counters[3] allocates
     uint32_t full_rows, full_tg;      // jobs the full-width pool holds (multiple of 64), lines per job (4 columns each)
     uint32_t full_cl;                 // fused alignment (k_alnf): of a job's full_tg lines the first full_cl hold codes, the shift bytes follow, the last one is spare
     uint32_t* counters;               // [2] reads on the slow list, [3] rows taken from the full-width pool, [4..9] diagnostics, [10] jobs on redo_list
@@ -207,15 +202,12 @@ hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuf
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,
                       const FastBuffers& fb, const uint32_t* order, uint32_t begin, uint32_t count, int lds_lcap, int lds_ncap,
                       int from_jobs, uint32_t c0, uint32_t c1, int waves_per_wg, bool state_in_hbm, hipStream_t s);
-// this round's alignment jobs (ids below n_jobs; per-range counts in fb.job_cnt) packed into block records, one lane per job
 // q-score jobs for the first `count` reads of fb.defer_list (after the last regular round)
 hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s);
-hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s);
 hipError_t launch_round_reset(const FastBuffers& fb, hipStream_t s);
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s);
-// mode: 0 = the round's jobs are identity re-estimations, 1 = q-score alignments (all jobs of a round have one mode)
-hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s);
-// the fused form (round 3): windows decoded from the slot codes inside the alignment kernel, no k_job
+// this round's alignment jobs (ids below n_jobs; per-range counts in fb.job_cnt): windows decoded from the slot codes and aligned, one
+// lane per job.  mode: 0 = the round's jobs are identity re-estimations, 1 = q-score alignments (all jobs of a round have one mode)
 hipError_t launch_alnf(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s);
 hipError_t launch_perfect_lengths(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, hipStream_t s);
 hipError_t launch_perfect(const BatchView& b, const RefView& r, const SimParams& p, const SimBuffers& o, const uint64_t* rec_off, uint8_t* records,

@@ -2,8 +2,8 @@
 //
 // Two implementations of the Badread path share the stage code below:
 //   * the fast pipeline: k_init, then rounds of k_loop (one LANE per read: error loop up to the next identity re-estimation;
-//     k_loopw, one wave per read, when few reads are left), k_job (one lane per alignment job: window packed into block
-//     records) and k_aln (one lane per alignment, bit-parallel), then the last visit k_err (one wave per read) -- ACGT reads;
+//     k_loopw, one wave per read, when few reads are left) and k_alnf (one lane per alignment job: the window decoded from the
+//     read's slot codes and aligned, bit-parallel), then the last visit k_err (one wave per read) -- ACGT reads;
 //   * k_simulate: one wavefront owns one read from splice to finished sequence/qualities, alignment done across the
 //     wave -- byte-exact for any alphabet; the exact fallback and the --perfect path.
 // Reference behaviour restated per stage (file:line into vpc-ccg/tksm):
@@ -880,8 +880,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_simulate(BatchView B, Ref
 
 // ================================================================================================
 // Fast Badread pipeline: k_init -> rounds of { k_loop / k_loopw (error loop up to the next identity
-// re-estimation) -> k_job (windows packed) -> k_aln (bit-parallel banded alignment, one LANE per
-// alignment) } -> k_qjobs + k_job + k_aln (q-score alignments) -> k_err (q-scores, trims, output).
+// re-estimation) -> k_alnf (windows decoded and aligned, bit-parallel banded, one LANE per alignment) }
+// -> k_qjobs + k_alnf (q-score alignments) -> k_err (q-scores, trims, output).
 // Reads whose fragment holds a non-ACGT byte (or whose alignment leaves the band representation)
 // are routed to the byte-exact wave-wide path (k_simulate over slow_list).  Same specification,
 // same results, bit for bit.
@@ -1171,7 +1171,7 @@ DEV void join_out(const uint8_t* frag, const uint16_t* nb, int n, uint8_t* out_s
 // follows a stop (re-estimation point, end of the loop) is dropped and drawn again on the next visit.
 // Per lane in LDS: the first Wl words of the padded fragment at 2 bits per base (longer fragments read the rest from HBM); the
 // slot codes stay in HBM (read and written only by the draws that change something).
-// A read that stops at a re-estimation point gets an alignment job here (id, meta record: k_job packs its window, k_aln aligns
+// A read that stops at a re-estimation point gets an alignment job here (id, meta record: k_alnf decodes and aligns its window
 // it; pending = 1); one whose loop has ended waits in stage 3 for its q-score job and its last visit (k_qjobs, k_err).
 constexpr int LOOP_B = 4;
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
         }
     }
     // ---- a read at a re-estimation point gets an alignment job: id from its range's counter (one atomic per range and wave),
-    // meta record for k_job (which packs the window) and k_aln.  Window: the whole fragment, or a random 1000-base window of a
+    // meta record for k_alnf.  Window: the whole fragment, or a random 1000-base window of a
     // longer one (py/tksm_badread.py:405-432).
     int st_aligns = S.st_aligns;
     uint32_t job = 0;
@@ -1830,266 +1830,14 @@ __global__ void k_collect_unfinished(FastBuffers FB, uint64_t n_reads) {
     }
 }
 
-// ---- k_aln: bit-parallel (Myers / Hyyro) banded global alignment, one lane per job.
-// Column j of the joined sequence owns fragment rows t_j .. t_j+63 (bit b = row t_j + b); t advances by the
-// 5-bit shift the job carries.  Entering rows take vertical delta +1 (virtual cells below the previous window),
-// the row above the window is unreachable (horizontal delta in = +1), and when the window does not move the
-// top row can only be reached from the left (vertical delta forced to -1).  Per column the resolved predecessor
-// of every cell is stored as 2 bits {w0, w1}: 0 up, 1 left, 2 diagonal mismatch, 3 diagonal match; the walk
-// back from (n, m) yields matches / columns (identity) and, for q-score jobs, the per-read-position ops.
-struct AlnJob {
-    bool act; int p0, n, m, mode;
-    const unsigned long long* fp;    // fragment planes of the read, {lo, hi} word pairs (blocks flagged in their record only)
-    const uint4* jcl;                // the job's block records: 64-byte lines of 4 records (32 columns), the lines of a wave's 64 jobs
-                                     // interleaved -- record b at jcl[(b >> 2) * 256 + (b & 3)]
-    ulonglong2 win;                  // code planes of the first 64 window rows
-    unsigned long long* trace;       // full-width pass: the job's row of (ncap + 16) 16-byte columns
-    unsigned long long* popd8;
-};
-DEV const uint4* job_rec_ptr(const AlnJob& J, int b) { return J.jcl + (size_t)(b >> 2) * 256 + (b & 3); }
-struct AlnRes { uint32_t mt, cols; bool fail, needfull; };
-
-// ---- the common case: the predecessor codes of a few band rows around the generative row per column -- the path practically
-// never leaves them: 16 rows (4 bytes per column: pass 1; 1 % of bulk and 5 % of polyA-tailed jobs leave them and are redone
-// with all 64 rows stored, 16 bytes per column: pass 2, from a list; ROWS 64, the same code).  The kernel is bound by
-// HBM traffic first (records 2 B per column in, codes 4 B out and 4 + 2 B in again for the walk) and vector instructions second
-// (~72 per column forward, ~24 in the walk), so:
-//  * everything a lane moves is a whole 64-byte line of its own -- 4 block records (32 columns), 16 columns of codes -- and the lines
-//    of a wave's 64 jobs are neighbours in memory (4 KB per wave and line index): no transposition through LDS, no partial lines,
-//    DRAM pages are used in whole;
-//  * every per-column shift is by 0..31, so the 64-bit words are moved with v_alignbit on their halves; the fragment window slides,
-//    fed by the 32 entering rows each block record carries, instead of being re-extracted from the per-read planes;
-//  * the loop body is branch-free and every memory operation is unconditional (a lane past its job's end writes a spare line), so
-//    the waits on the prefetches do not have to drain the stores (gfx9 counts loads and stores in one counter, in issue order); the
-//    one exception, a block whose window moves by more rows than its record carries, is a wave-uniform branch that ends with nothing
-//    in flight.
-// A lane whose walk needs a row outside the stored ones reports needfull.
-// MODE: 0 = identity jobs of the error loop (preference up, left, diagonal; only matches / columns come back), 1 = q-score jobs
-// (left, up, diagonal; per-position ops written).  All jobs of a launch have the same mode.
-// trl: the lane's line of column group 0; group q at trl + ls q (uint4 units; ls = 4 x the jobs whose lines are interleaved, 256 as a
-// rule); tg groups per job, the last one spare.
-template <int MODE, int ROWS>
-DEV AlnRes aln_fast(const AlnJob& J, int mmax, uint4* trl, int tg, uint32_t ls, int ablate) {
-    static_assert(ROWS == 16 || ROWS == 64, "16 stored rows, or all of them");
-    constexpr int NC = ROWS == 16 ? 16 : 4;                       // columns per line of codes
-    constexpr int ST = ROWS == 16 ? 23 : 0;                       // first stored band row once the window moves
-    constexpr int RAMP0 = 31 - ST;
-    const bool act = J.act;
-    const int n = J.n, m = act ? J.m : 0;
-    unsigned long long Pv = ~0ull, Mv = 0ull;
-    int t = 1, t32 = 1;
-    // the window rows' code planes are kept COMPLEMENTED: Eq = (~A ^ cl) & (~B ^ ch) saves the two inversions per column
-    unsigned long long A = ~J.win.x, B = ~J.win.y;
-    const uint4* rcl = J.jcl;
-    const size_t spare = (size_t)(tg - 1) * ls;
-    uint4 rn0 = rcl[0], rn1 = rcl[1], rn2 = rcl[2], rn3 = rcl[3];
-    uint32_t tw[16];                                              // codes on their way out (16 rows: half a line; all rows: a line)
-    auto put_line = [&](int q, int half) {                        // half: -1 whole line, 0 / 1 its first / second 32 bytes
-#ifdef TKSM_ABLATE
-        if (ablate == 12 || ablate == 14) { if (tw[0] == 0x1234567u) trl[spare] = make_uint4(tw[1], tw[2], tw[3], tw[4]); return; }
-#endif
-        uint4* d = trl + (q * NC < m ? (size_t)q * ls : spare);
-        if (half < 0) {
-            d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
-            d[2] = make_uint4(tw[8], tw[9], tw[10], tw[11]); d[3] = make_uint4(tw[12], tw[13], tw[14], tw[15]);
-        } else {
-            d[2 * half] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[2 * half + 1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
-        }
-    };
-    auto fwd_block = [&](int c0, int bq, uint4 rec) {
-        const int cb = c0 + 8 * bq;
-        if (!(cb < m)) { rec.x = 0u; rec.y = 0u; rec.z = 0u; rec.w = 0u; }
-        const uint32_t shw = rec.x, nbits = rec.y;
-        uint32_t EA = ~rec.z, EB = ~rec.w;                        // the 32 rows after the window (complemented, like A and B)
-        const bool esc = (nbits >> 24) & 1u;                      // ... are not enough in this block (rare)
-        const bool esc_any = __ballot(esc) != 0ull;
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const uint32_t sh = ((shw >> (4 * x)) & 15u) | (((nbits >> (16 + x)) & 1u) << 4);
-            t += (int)sh;
-            const bool g = t > 1;
-            // window moves down by sh rows: entering rows take vertical delta +1
-            const uint32_t f = (sh == 0u && g) ? 1u : 0u;         // window did not move: top row only from the left
-            Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh) & ~f);
-            Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh) | f);
-            A = mk64(alignbit(EA, hi32(A), sh), alignbit(hi32(A), lo32(A), sh)); EA >>= sh;
-            B = mk64(alignbit(EB, hi32(B), sh), alignbit(hi32(B), lo32(B), sh)); EB >>= sh;
-            if (esc_any) {
-                if (esc) {
-                    const int o = J.p0 + t - 1, w = o >> 6;
-                    const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w);
-                    const ulonglong2 q1 = *reinterpret_cast<const ulonglong2*>(J.fp + 2 * w + 2);
-                    A = ~funnel128(q0.x, q1.x, o & 63); B = ~funnel128(q0.y, q1.y, o & 63);
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing of this rare path stays in flight (exact waits elsewhere)
-            }
-            const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)x, 1u);
-            const uint32_t ch = (uint32_t)__builtin_amdgcn_sbfe((int)nbits, (uint32_t)(8 + x), 1u);
-            // rows below the fragment (i > n) are not masked: they never feed a row above them
-            // (three-input boolean instructions throughout: 31 instead of 44 vector instructions for the logic of a column)
-            const unsigned long long clm = mk64(cl, cl), chm = mk64(ch, ch);
-            const unsigned long long Eq = bool3<BOOL3(TA & (TB ^ TC))>(A ^ clm, B, chm);
-            const unsigned long long Xv = Eq | Mv;
-            const unsigned long long Xh = bool3<BOOL3((TA ^ TB) | TC)>((Eq & Pv) + Pv, Pv, Eq);
-            const unsigned long long Ph = bool3<BOOL3(TA | ~(TB | TC))>(Mv, Xh, Pv);
-            const unsigned long long Mh = Pv & Xh;
-            const unsigned long long D0 = Xh | Mv;
-            const unsigned long long Phs = mk64(alignbit(hi32(Ph), lo32(Ph), 31u), (lo32(Ph) << 1) | 1u);
-            const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
-            Pv = bool3<BOOL3(TA | ~(TB | TC))>(Mhs, Xv, Phs);
-            Mv = Phs & Xv;
-            const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
-            // codes: mode 0 prefers up, left, diagonal; mode 1 left, up, diagonal.  w1 = neither up nor left; w0 = left, or a
-            // diagonal that is a match: (Ph & (~upv | M64)) | (w1 & D0), i.e. ~upv & (Ph | D0) in mode 0 and Ph | (~upv & D0) in mode 1
-            const unsigned long long w1 = bool3<BOOL3(~(TA | TB))>(upv, Ph, 0ull);
-            const unsigned long long w0 = MODE ? bool3<BOOL3(TB | (~TA & TC))>(upv, Ph, D0) : bool3<BOOL3(~TA & (TB | TC))>(upv, Ph, D0);
-            // stored rows: ROWS around the generative row, which sits at bit 31 once the window moves (t > 1) and climbs from
-            // bit 0 with the column index while the window is still clamped at row 1: band rows st .. st + ROWS - 1,
-            // st = clamp(column - (31 - ST), 0, ST), a function of the column alone (scalar here, a constant in the walk).
-            // More rows above the generative row than below: co-optimal paths take the deletions of a homopolymer run at
-            // its end, i.e. run above the generative row (measured on 1-kb bulk / polyA-tailed jobs: rows 23..38 miss
-            // 0.9 % / 5 %, rows 12..43 0.02 % / 0.14 %)
-            if constexpr (ROWS == 64) {
-                tw[4 * (x & 3)] = lo32(w0); tw[4 * (x & 3) + 1] = hi32(w0); tw[4 * (x & 3) + 2] = lo32(w1); tw[4 * (x & 3) + 3] = hi32(w1);
-                if ((x & 3) == 3) put_line((cb + x) >> 2, -1);
-            } else {
-                const uint32_t st = (uint32_t)(min(max(cb + x, RAMP0), 31) - RAMP0);
-                const uint32_t s0 = alignbit(hi32(w0), lo32(w0), st), s1 = alignbit(hi32(w1), lo32(w1), st);
-                tw[x] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);                                // w1 rows in the high half
-            }
-        }
-        if constexpr (ROWS == 16) put_line(cb >> 4, bq & 1);
-    };
-    for (int c0 = 0; c0 < mmax; c0 += 32) {
-        // every record is requested again as soon as its block is done: 24 columns ahead of its use (a row has 8 spare records)
-        const uint4* nx = rcl + (size_t)((c0 >> 5) + 1) * 256;
-        fwd_block(c0, 0, rn0); rn0 = nx[0];
-        fwd_block(c0, 1, rn1); rn1 = nx[1];
-        fwd_block(c0, 2, rn2); rn2 = nx[2];
-        fwd_block(c0, 3, rn3); rn3 = nx[3];
-        if (c0 == 0) t32 = t;                                     // window position of column 31 (the walk's clamped start)
-    }
-#ifdef TKSM_ABLATE
-    if (ablate >= 11 && ablate <= 19) { AlnRes R0; R0.mt = (uint32_t)(Pv ^ Mv); R0.cols = (uint32_t)t; R0.fail = false; R0.needfull = false; return R0; }
-#endif
-    // ---- walk back from (n, m).  Every column is left exactly once (by a left or a diagonal move), so all lanes of the wave
-    // walk in LOCKSTEP: line and column are wave-uniform (registers and shift fields are compile-time picks), a lane joins at its
-    // own last column.  Inside a column the run of up moves is counted with one find-first-bit on the column's "not up" bits, so
-    // a column costs ~24 vector instructions, branch-free.  Nothing but the stored-row index `bs` of the current cell is
-    // tracked in columns >= 32 (st = ST there): matches and diagonal moves are counted, columns = n + m - diagonals.  A path
-    // that leaves the stored rows sets needfull (with all 64 rows stored: a cell below the band is virtual, the path moves up
-    // from it; one above the band fails the job).  Columns < 32 (window possibly clamped at row 1, st ramps) track row and window
-    // position as well: there the path may reach row 0, after which only left moves remain.
-    bool fail = act && m > 0 && (n - t > 63 || n - t < 0), needfull = false;
-    bool live = act && !fail && m > 0;
-    uint32_t mt = 0, dg = 0;
-    int bs = n - t - (min(max(m - 1, RAMP0), 31) - RAMP0);
-    int i = n, tt = t;                                            // used below column 32 only
-    // one column; RAMP: columns < 32.  lo / hi: the column's codes (u32, or u64 with all rows stored)
-    auto walk_col = [&](int col, auto ramp, auto lo, auto hi, uint2 shw, unsigned long long& pp, bool& touched) {
-        constexpr bool RAMP = decltype(ramp)::value;
-        const int c8 = col & 7;
-        if (live && col < m) {
-            const uint32_t shc = ((shw.x >> (4 * c8)) & 15u) | (((shw.y >> (16 + c8)) & 1u) << 4);   // this column's shift
-            if (RAMP) bs = i - tt - (min(max(col, RAMP0), 31) - RAMP0);
-            uint32_t extra = 0u;
-            if constexpr (ROWS == 64) { extra = (uint32_t)max(bs - 63, 0); bs -= (int)extra; }      // virtual cells below the band: up
-            // run of up moves from the current cell: bits of neither plane set, from bit bs downwards
-            uint32_t run;
-            if constexpr (ROWS == 64) {
-                const unsigned long long y = (lo | hi) << ((63 - bs) & 63);
-                run = y ? (uint32_t)__builtin_clzll(y) : 64u;
-            } else {
-                const uint32_t y = (lo | hi) << ((31 - bs) & 31); // (16 rows: hi = lo >> 16, the halves above bit 15 are shifted out)
-                run = y ? (uint32_t)__builtin_clz(y) : 32u;
-            }
-            bool ok = (uint32_t)bs < (uint32_t)ROWS;
-            bool zero = false;
-            if (RAMP) {
-                run = min(run, (uint32_t)(bs + 1));               // (the shift filled the word with "up" bits below bit 0)
-                if (i == 0) { run = 0u; extra = 0u; }
-                zero = (uint32_t)i == run + extra || i == 0;      // the path reaches (or is in) row 0: this column and all before it are left moves
-                ok |= i == 0;
-            }
-            const int bs2 = bs - (int)run;
-            ok &= bs2 >= 0 || zero;
-            const uint32_t lb = zero ? 1u : (uint32_t)(lo >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;
-            const uint32_t hb = zero ? 0u : (uint32_t)(hi >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;     // lb | hb << 1: 1 left, 2 diagonal mismatch, 3 diagonal match
-            needfull |= !ok;
-            live = ok && !zero;
-            mt += hb & lb;
-            dg += hb;
-            if (MODE) {
-                const uint32_t op = hb ? (lb ^ 1u) : 2u;          // 0 match, 1 mismatch, 2 read-only base; the run = fragment-only bases in front
-                pp |= (unsigned long long)(op | (min(run + extra, 63u) << 2)) << (8 * c8);
-                touched = true;
-                if (zero) {
-                    // only left moves remain: the rest of this group and every group before it
-                    pp |= 0x0202020202020202ull & ((1ull << (8 * c8)) - 1ull);
-                    for (int b2 = (col >> 3) - 1; b2 >= 0; b2--) J.popd8[b2] = 0x0202020202020202ull;
-                }
-            }
-            if (RAMP) { i -= (int)(run + extra + hb); tt -= (int)shc; }
-            else bs = bs2 - (int)hb + (int)shc;
-        }
-    };
-    // lines in flight: two register sets, one line ahead
-    uint4 la0, la1, la2, la3, lb0, lb1, lb2, lb3;
-    uint2 sa0, sa1, sb0, sb1;
-    auto load_line = [&](int q, uint4& l0, uint4& l1, uint4& l2, uint4& l3, uint2& s0, uint2& s1) {
-        q = max(q, 0);
-        const uint4* p = trl + (q * NC < m ? (size_t)q * ls : spare);
-        l0 = p[0]; l1 = p[1]; l2 = p[2]; l3 = p[3];
-        const int b = q * NC / 8;                                 // shift fields of the line's columns: the first 8 bytes of their block records
-        s0 = *reinterpret_cast<const uint2*>(job_rec_ptr(J, b));
-        if (ROWS == 16) s1 = *reinterpret_cast<const uint2*>(job_rec_ptr(J, b + 1)); else s1 = s0;
-    };
-    unsigned long long ppk = 0ull;                                // (all rows stored: a group of 8 columns spans two lines)
-    bool tk = false;
-    auto walk_line = [&](int q, const uint4& l0, const uint4& l1, const uint4& l2, const uint4& l3, uint2 s0, uint2 s1) {
-        const uint32_t w[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
-        unsigned long long pp0 = 0ull, pp1 = 0ull;                // op bytes of the line's one or two groups of 8 columns
-        bool touched0 = false, touched1 = false;
-        const int cq = q * NC;
-        auto cols_of_line = [&](auto ramp) {
-#pragma unroll
-            for (int c = NC - 1; c >= 0; c--) {
-                if constexpr (ROWS == 16) walk_col(cq + c, ramp, w[c], w[c] >> 16, c >= 8 ? s1 : s0, c >= 8 ? pp1 : pp0, c >= 8 ? touched1 : touched0);
-                else walk_col(cq + c, ramp, mk64(w[4 * c + 1], w[4 * c]), mk64(w[4 * c + 3], w[4 * c + 2]), s0, ppk, tk);
-            }
-        };
-        if (cq >= 32) cols_of_line(std::false_type{});
-        else {
-            if (cq == 32 - NC && m > 32) { tt = t32; i = bs + t32 + ST; }      // leaving the columns where only bs is tracked
-            cols_of_line(std::true_type{});
-        }
-        if (MODE) {
-            if constexpr (ROWS == 64) {
-                if ((q & 1) == 0) { if (tk) J.popd8[cq >> 3] = ppk; ppk = 0ull; tk = false; }
-            } else {
-                if (touched0) J.popd8[cq >> 3] = pp0;
-                if (ROWS == 16 && touched1) J.popd8[(cq >> 3) + 1] = pp1;
-            }
-        }
-    };
-    if (mmax > 0) {
-        const int topq = (mmax - 1) / NC;
-        load_line(topq, la0, la1, la2, la3, sa0, sa1);
-        for (int q = topq; q >= 0; q -= 2) {
-            load_line(q - 1, lb0, lb1, lb2, lb3, sb0, sb1);
-            walk_line(q, la0, la1, la2, la3, sa0, sa1);
-            if (q > 0) {
-                load_line(q - 2, la0, la1, la2, la3, sa0, sa1);
-                walk_line(q - 1, lb0, lb1, lb2, lb3, sb0, sb1);
-            }
-        }
-    }
-    AlnRes R;
-    R.mt = mt; R.cols = (uint32_t)(n + m) - dg;
-    R.fail = fail || (ROWS == 64 && needfull); R.needfull = ROWS != 64 && needfull;
-    return R;
-}
-
+// ---- Alignment of the re-estimation and q-score jobs: bit-parallel (Myers / Hyyro) banded global alignment, one LANE per job
+// (k_alnf below).  Column j of the joined sequence owns fragment rows t_j .. t_j+63 (bit b = row t_j + b); t advances by the
+// column's window shift.  Entering rows take vertical delta +1 (virtual cells below the previous window), the row above the
+// window is unreachable (horizontal delta in = +1), and when the window does not move the top row can only be reached from the
+// left (vertical delta forced to -1).  Per column the resolved predecessor of every cell is stored as 2 bits {w0, w1}: 0 up,
+// 1 left, 2 diagonal mismatch, 3 diagonal match; the walk back from (n, m) yields matches / columns (identity) and, for q-score
+// jobs, the per-read-position ops.  MODE: 0 = identity jobs of the error loop (preference up, left, diagonal; only matches /
+// columns come back), 1 = q-score jobs (left, up, diagonal; per-position ops written).  All jobs of a launch have the same mode.
 // Job geometry shared by the alignment kernels: `job0` is the first job id of the wave (all 64 lanes of a k_aln wave
 // belong to one range), `job` the lane's own.
 DEV uint32_t range_of_job(const FastBuffers& FB, uint32_t job0) {
@@ -2099,7 +1847,7 @@ DEV uint32_t range_of_job(const FastBuffers& FB, uint32_t job0) {
 }
 // ---- k_qjobs: after the last regular round every read waits in stage 3; with q-scores each of them gets one more alignment
 // job, its whole new sequence against its whole fragment with the path kept (get_qscores, py/tksm_badread.py:611-613): job ids
-// per range as in k_loop, windows packed by k_job, aligned by k_aln, looked up by the last visit of k_err.
+// per range as in k_loop, aligned by k_alnf, looked up by the last visit of k_err.
 __global__ __launch_bounds__(64) void k_qjobs(FastBuffers FB, int k, uint32_t count) {
     const int lane = threadIdx.x;
     const uint32_t widx = blockIdx.x * 64u + (uint32_t)lane;
@@ -2127,175 +1875,6 @@ __global__ __launch_bounds__(64) void k_qjobs(FastBuffers FB, int k, uint32_t co
     }
 }
 
-// ---- k_job: packs the windows of this round's alignment jobs into the block records k_aln reads, one LANE per job.
-// All lanes walk their windows slot by slot in lockstep (slot s of every window in iteration s), so everything a lane
-// reads comes at wave-uniform offsets of its own rows: 32 slot codes (64 bytes) per 32 iterations, one pair of fragment-plane
-// words per 64 -- unconditional, prefetched loads.  What differs between lanes is how many columns a slot emits (0 .. 5
-// symbols), i.e. when a block of 8 columns is complete; since in every iteration SOME lane completes one, the lanes do not
-// pack a block the moment it is full: a slot's columns join per-lane bit queues -- one queue per record field (low / high
-// symbol bit, low 4 bits / bit 4 of the window shift), which is why slot codes keep their symbols planar -- and every fourth
-// slot each lane packs at most one block, i.e. shifts 8 columns out of its queues (they hold 32; a lane that falls behind
-// packs at once, rarely).  The kernel is bound by its vector instructions: a record costs ~40 of them here (byte-wise column
-// queues and multiplicative bit gathers: ~125).  Plane words and finished records pass through LDS (dynamic per-lane
-// indexing without selects); records leave four at a time (one 64-byte line).  Record layout: FastBuffers::job_cols; the
-// shift of a slot's first column = rows the window top moves, top = max(1, slot + 1 - 31) (the guided band).
-struct __attribute__((packed, aligned(4))) U4a { uint32_t x, y, z, w; };
-__global__ __launch_bounds__(64) void k_job(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
-    __shared__ unsigned long long pl[4 * 2 * 64];                      // aligned plane words: [stream word & 3][plane][lane]
-    __shared__ uint4 rs[4 * 64];                                       // finished records: [record & 3][lane]
-    const int lane = threadIdx.x;
-    const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
-    const uint32_t rng = range_of_job(FB, job0);
-    const uint32_t rbase = FB.base_cur[rng];
-    const uint32_t in_rng = FB.job_cnt[rng * 32u];
-    if (in_rng <= job0 - rbase) return;                               // whole wave beyond the range's job count
-    const bool act = job < n_jobs && job - rbase < in_rng;
-    uint4 meta = make_uint4(0u, 0u, 0u, 0u);
-    if (act) meta = *reinterpret_cast<const uint4*>(FB.job_meta + 4ull * job);
-    const uint32_t r = meta.x;
-    const int p0 = (int)meta.y, n = (int)(meta.z & 0x7fffffffu);
-    const RangeGeo G = FB.geo_cur[rng];
-    // records leave as 64-byte lines of 4 (32 columns); the lines of the wave's 64 jobs are interleaved, so that k_aln's lanes read
-    // (and this kernel's lanes write) neighbouring lines: 4 KB per wave and group of 32 columns
-    uint4* jc = FB.job_cols + G.jc_off + (size_t)(job0 - rbase) * G.cw + (size_t)lane * 4;
-    const int ncap_l = (int)G.ncap;
-    const uint16_t* gnb = nb_row(FB, r);
-    const ulonglong2* fp = reinterpret_cast<const ulonglong2*>(planes_row(FB, r));   // {lo, hi} per 64 positions
-    const int base = p0 & ~1;                                         // slot codes are fetched from an even position
-    const int skip = p0 - base;
-    int nmax = act ? n + skip : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-    // fragment planes as a stream aligned to `base` (word j = positions base + 64 j ..), so that every lane is at the same bit of
-    // its own stream.  LDS keeps the words j - 1 .. j + 2 around the current slot's word j (a block is packed up to ~60 slots
-    // after it began, and its entering rows lie 33 .. 95 positions ahead of where it began); the next raw word is in flight.
-    const int wbase = base >> 6, bsh = base & 63;
-    const int wlast = planes_words(FB, r) - 1;
-    auto fpw = [&](int w) { return fp[min(max(w, 0), wlast)]; };
-    auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 v; v.x = funnel128(a.x, b.x, bsh); v.y = funnel128(a.y, b.y, bsh); return v; };
-    auto put_word = [&](int j, const ulonglong2& v) { pl[((j & 3) * 2 + 0) * 64 + lane] = v.x; pl[((j & 3) * 2 + 1) * 64 + lane] = v.y; };
-    ulonglong2 Rl, Rn, W0;                                            // last raw word used, next raw word; the current aligned word
-    {
-        const ulonglong2 r0 = fpw(wbase), r1 = fpw(wbase + 1), r2 = fpw(wbase + 2), r3 = fpw(wbase + 3);
-        W0 = aligned(r0, r1);
-        put_word(-1, make_ulonglong2(0ull, 0ull)); put_word(0, W0); put_word(1, aligned(r1, r2)); put_word(2, aligned(r2, r3));
-        Rl = r3; Rn = fpw(wbase + 4);
-    }
-    int jcur = 0;                                                     // stream index of the current slot's word
-    auto bits32 = [&](int rel, int plane) -> uint32_t {               // plane bits [rel, rel + 32) of the stream (rel: position - base)
-        const int jw = rel >> 6;
-        return lo32(funnel128(pl[((jw & 3) * 2 + plane) * 64 + lane], pl[(((jw + 1) & 3) * 2 + plane) * 64 + lane], rel & 63));
-    };
-    if (act) {                                                        // the first 64 window rows (positions p0 .. p0 + 63)
-        FB.job_win[2ull * job] = funnel128(pl[(0 * 2 + 0) * 64 + lane], pl[(1 * 2 + 0) * 64 + lane], skip);
-        FB.job_win[2ull * job + 1] = funnel128(pl[(0 * 2 + 1) * 64 + lane], pl[(1 * 2 + 1) * 64 + lane], skip);
-    }
-    int t = 1, col = 0;                                               // window top after the last column; columns emitted
-    int tk = 1, npend = 0, nrec = 0;                                  // top before the first queued column; queued columns; records packed
-    uint32_t qlo = 0u, qhi = 0u, qsx = 0u;                            // queues, one bit per column: symbol low / high bit, bit 4 of the shift
-    uint32_t qn0 = 0u, qn1 = 0u, qn2 = 0u, qn3 = 0u;                  // low 4 bits of the shift, 8 columns per word
-    bool fail = false;
-    auto pack_block = [&](int ncols) {                                // the first (up to 8) queued columns -> one record
-        const uint32_t shw = qn0, clo = qlo & 0xffu, chi = qhi & 0xffu, shx = qsx & 0xffu;
-        uint32_t a4 = (shw & 0x0f0f0f0fu) + ((shw >> 4) & 0x0f0f0f0fu);
-        a4 += a4 >> 16;
-        const int adv = (int)((a4 + (a4 >> 8)) & 0xffu) + 16 * __popc(shx);
-        const int rel = skip + tk - 1 + 64;                           // the 32 fragment rows after the window at the block's start
-        const uint4 rec = make_uint4(shw, clo | (chi << 8) | (shx << 16) | (adv > 32 ? 1u << 24 : 0u), bits32(rel, 0), bits32(rel, 1));
-        tk += adv;
-        qlo >>= 8; qhi >>= 8; qsx >>= 8; qn0 = qn1; qn1 = qn2; qn2 = qn3; qn3 = 0u; npend -= ncols;
-        const int tq = nrec++;
-        if (8 * tq < ncap_l) {
-            rs[(tq & 3) * 64 + lane] = rec;
-            if ((tq & 3) == 3) { uint4* d = jc + (size_t)(tq >> 2) * 256; d[0] = rs[lane]; d[1] = rs[64 + lane]; d[2] = rs[128 + lane]; d[3] = rs[192 + lane]; }
-        }
-    };
-    for (int s0 = 0; s0 < nmax; s0 += 32) {
-        // 32 slot codes of every lane (lanes past their window re-read its start), and every other time the next plane word
-        const int src = (s0 <= n + skip) ? base + s0 : base;
-        const U4a* cp = reinterpret_cast<const U4a*>(gnb + src);
-        const U4a c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-        const uint32_t cw[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
-        const int bit0 = s0 & 32;
-        const uint32_t olo = (uint32_t)(W0.x >> bit0), ohi = (uint32_t)(W0.y >> bit0);      // the chunk's 32 original bases
-#pragma unroll
-        for (int q = 0; q < 32; q++) {
-            const int p = s0 + q - skip;                              // slot within the window
-            const bool on = act && p >= 0 && p < n;
-            const uint32_t code = (cw[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-            const int len = on ? (code ? (int)((code >> 12) & 7u) : 1) : 0;
-            const uint32_t m5 = (1u << len) - 1u;
-            // the slot's symbols (a pristine slot: its original base) join the queues; its first column carries the shift of the
-            // window top, top = max(1, slot + 1 - 31)
-            const uint32_t lo5 = (code ? code & 31u : (olo >> q) & 1u) & m5, hi5 = (code ? (code >> 5) & 31u : (ohi >> q) & 1u) & m5;
-            const int tn = max(1, p + 1 - 31), sh = len > 0 ? tn - t : 0;
-            fail |= sh > 31;
-            t += sh;
-            qlo |= lo5 << npend; qhi |= hi5 << npend; qsx |= (uint32_t)(sh >> 4) << npend;
-            const uint32_t nib = (uint32_t)(sh & 15) << (4 * (npend & 7));
-            const int which = npend >> 3;
-            qn0 |= which == 0 ? nib : 0u; qn1 |= which == 1 ? nib : 0u; qn2 |= which == 2 ? nib : 0u; qn3 |= which == 3 ? nib : 0u;
-            npend += len; col += len;
-            // every fourth slot a lane packs one block if it has one; a lane whose queues could overflow with the next slot at once
-            if ((q & 3) == 3) { if (npend >= 8) pack_block(8); }
-            else if (__ballot(npend > 27) != 0ull) { if (npend > 27) pack_block(8); }
-        }
-        // the plane words follow the slot position: every lane moves on at the same slot
-        if (bit0) {
-            jcur++;
-            const ulonglong2 nw = aligned(Rl, Rn);
-            W0.x = pl[((jcur & 3) * 2 + 0) * 64 + lane]; W0.y = pl[((jcur & 3) * 2 + 1) * 64 + lane];
-            put_word(jcur + 2, nw);
-            Rl = Rn;
-            Rn = fpw(wbase + jcur + 4);
-        }
-    }
-    if (!act) return;
-    const int m = col;
-    while (npend >= 8) pack_block(8);
-    if (npend > 0) pack_block(npend);                                 // the last, partial block
-    if (m <= ncap_l) {
-        // the complete records still in LDS
-        const int cnt = nrec & 3;
-        uint4* d = jc + (size_t)(nrec >> 2) * 256;
-        if (cnt > 0) d[0] = rs[lane];
-        if (cnt > 1) d[1] = rs[64 + lane];
-        if (cnt > 2) d[2] = rs[128 + lane];
-    }
-    FB.job_meta[4ull * job + 3] = (uint32_t)(m > ncap_l ? 0 : m);
-    if (m > ncap_l) {
-        // the window outgrew the range's rows (insertion-heavy read): the host reruns the batch with larger slots
-        O.status[r] |= 1u; O.out_len[r] = 0; O.rec_len[r] = 0; O.identity[r] = 0.0;
-        FB.state[r].stage = 2;
-    } else if (fail) {
-        // a window shift above 31 rows between two columns: the byte-exact wave-wide kernel takes the read
-        FB.state[r].slow = 1;
-        atomicAdd(&FB.counters[5], 1u);
-        FB.slow_list[atomicAdd(&FB.counters[2], 1u)] = r;
-    }
-}
-
-DEV void load_job(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act, AlnJob& J, uint32_t& r) {
-    J.act = act;
-    r = 0;
-    J.p0 = 0; J.n = 0; J.m = 0; J.mode = 0;
-    if (act) {
-        const uint32_t* meta = FB.job_meta + 4ull * job;
-        r = meta[0]; J.p0 = (int)meta[1]; J.n = (int)(meta[2] & 0x7fffffffu); J.mode = (int)(meta[2] >> 31); J.m = (int)meta[3];
-    }
-    const RangeGeo G = FB.geo_cur[rng];
-    const uint32_t rel = job - FB.base_cur[rng];                      // (range bases are multiples of 64: rel & 63 = the job's lane in k_job)
-    J.fp = planes_row(FB, r);
-    J.jcl = FB.job_cols + G.jc_off + (size_t)(rel & ~63u) * G.cw + (size_t)(rel & 63u) * 4;
-    J.win.x = 0ull; J.win.y = 0ull;
-    if (act) J.win = *reinterpret_cast<const ulonglong2*>(FB.job_win + 2ull * job);
-    J.trace = nullptr;                                               // full-width rows come from a small pool
-    J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + G.popd_off + (size_t)rel * G.ncap);
-}
-DEV void store_result(const FastBuffers& FB, uint32_t r, const AlnRes& R) {
-    ReadState* st = FB.state + r;
-    st->res_mt = R.mt; st->res_cols = R.cols; st->res_fail = (R.fail || R.needfull) ? 1u : 0u;
-}
 DEV int wave_max(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
@@ -2311,101 +1890,35 @@ DEV void list_append(uint32_t* list, uint32_t* counter, bool want, uint32_t job,
     if (want) list[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = job;
 }
 
-// Alignment passes of a round (launch_aln): pass 1 = every job with 16 stored rows; pass 2 = the jobs whose path left them
-// (counters[10] of them in redo_list) with all 64 rows, lines in the full-width pool: a fixed grid whose waves loop over the list,
-// each on its own pool lines.  (A 32-row pass in between was measured: it takes 98 % of pass 1's misses, and costs a launch per
-// round that the direct way does not -- one context 3 % slower, three contexts no difference.)  Rounds with few jobs are bound by
-// the latency of one lane's pass: all their jobs go straight to the 64-row version (ROWS 64, LIST false; traffic is irrelevant;
-// counters[3] allocates pool lines per wave).
-#ifndef ALN_WAVES
-#define ALN_WAVES 4
-#endif
-#ifndef ALNF_WAVES
-#define ALNF_WAVES 3
-#endif
-template <int MODE, int ROWS, bool LIST>
-__global__ __launch_bounds__(64, ALN_WAVES) void k_aln(SimParams P, FastBuffers FB, uint32_t n_jobs) {
-    const int lane = threadIdx.x;
-    if (!LIST) {
-        const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
-        // job ids of a range start at its wave-aligned base (this round's bases are the packed counts of the previous round)
-        const uint32_t rng = range_of_job(FB, job0);
-        const uint32_t rbase = FB.base_cur[rng];
-        const uint32_t in_rng = FB.job_cnt[rng * 32u];
-        if (in_rng <= job0 - rbase) return;                           // whole wave beyond the range's job count
-        AlnJob J;
-        uint32_t r;
-        bool act = job < n_jobs && job - rbase < in_rng;
-        uint4* trl;
-        int tg;
-        bool norow = false;
-        uint32_t ls = 256u;
-        if (ROWS == 64) {
-            // pool lines for the wave's jobs only (long molecules: a job's lines are megabytes)
-            const unsigned long long wm = __ballot(act);
-            const uint32_t na = (uint32_t)__popcll(wm);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&FB.counters[3], na);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base + na > FB.full_rows) { norow = act; act = false; base = 0; }    // no pool lines left: reported as failures (the wave-wide kernel takes the reads)
-            tg = (int)FB.full_tg;
-            ls = 4u * max(na, 1u);
-            trl = reinterpret_cast<uint4*>(FB.trace_full) + ((size_t)base * FB.full_tg + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull)) % max(na, 1u)) * 4;
-        } else {
-            const RangeGeo G = FB.geo_cur[rng];
-            const uint32_t rel = job - rbase;
-            tg = (int)G.tstride;
-            trl = reinterpret_cast<uint4*>(FB.trace) + (G.trace_off + (size_t)(rel >> 6) * G.tstride * 64 + (rel & 63u)) * 4;
-        }
-        load_job(FB, job, rng, act || norow, J, r);
-        J.act = act;
-#ifdef TKSM_ABLATE
-        if (P.ablate == 10) return;
-#endif
-        AlnRes R = aln_fast<MODE, ROWS>(J, wave_max(act ? J.m : 0), trl, tg, ls, P.ablate);
-        if (norow) { R.fail = true; R.needfull = false; }
-        if (ROWS != 64) list_append(FB.redo_list, FB.counters + 10, act && R.needfull, job, lane);
-        if ((act || norow) && !R.needfull) store_result(FB, r, R);
-    } else {
-        static_assert(!LIST || ROWS == 64, "the list holds the jobs of the 64-row pass");
-        const uint32_t n_list = FB.counters[10];
-        if (lane == 0 && blockIdx.x == 0 && n_list) { atomicAdd(&FB.counters[8], n_list); atomicAdd(&FB.counters[9], (n_list + 63u) / 64u); }   // diagnostics
-        const uint32_t* list = FB.redo_list;
-        const int tg = (int)FB.full_tg;
-        uint4* trl = reinterpret_cast<uint4*>(FB.trace_full) + ((size_t)blockIdx.x * tg * 64 + (uint32_t)lane) * 4;
-        for (uint32_t base = blockIdx.x * 64u; base < n_list; base += gridDim.x * 64u) {     // wave-uniform: every wave ends
-            const uint32_t idx = base + (uint32_t)lane;
-            const bool act = idx < n_list;
-            const uint32_t job = list[min(idx, n_list - 1u)];                               // (idle lanes shadow the last job)
-            const uint32_t rng = range_of_job(FB, job);
-            AlnJob J;
-            uint32_t r;
-            load_job(FB, job, rng, act, J, r);
-            const AlnRes R = aln_fast<MODE, ROWS>(J, wave_max(act ? J.m : 0), trl, tg, 256u, P.ablate);
-            if (act) store_result(FB, r, R);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
-// k_alnf (round 3): window packing FUSED into the alignment -- no k_job, no block records, no job_win.
-// One lane per alignment job as in k_aln, but the lanes of a wave walk their windows SLOT BY SLOT in lockstep (as k_job did):
-// in iteration s every lane decodes slot s of its own window straight from the read's slot codes (32 codes = one 64-byte line
-// per 32 iterations, unconditional, prefetched one chunk ahead) and pushes the slot's 0 .. 5 columns into per-lane bit queues
-// (symbol low / high bit, and a unary slot stream: a 0 per slot boundary, a 1 per column); then it pops ONE column, if it has
-// one, and runs the bit-parallel column step on it.  The window shift of a column follows from the slot it belongs to
-// (top = max(1, slot + 1 - 31)), which the pop reads off the unary stream -- no shift queue.  Lanes whose windows hold more
-// columns than slots fall behind by their backlog (a few columns); a chunk of 32 pop-only iterations drains them when a
-// backlog passes BACKLOG_DRAIN columns and after the last slot.  The 32 .. 64 fragment rows below the window wait in a 64-bit
-// reservoir per plane, refilled by 32 rows at the end of every chunk (same position for all lanes: unconditional loads).
+// k_alnf: window packing FUSED into the alignment (round 3; rounds 1 - 2 packed the windows into block records with a kernel of
+// their own, k_job, and aligned column by column: 16.25 B of HBM traffic per column against 10.25 B here, two kernels' worth of
+// vector instructions against one -- DESIGN.md section 4.1).
+// The lanes of a wave walk their windows SLOT BY SLOT in lockstep: in iteration s every lane decodes slot s of its own window
+// straight from the read's slot codes (16 codes = 32 bytes per 16 iterations, unconditional, prefetched a pass ahead; a pristine
+// slot carries its original base as its only symbol, so every slot decodes the same way) and pushes the slot's 0 .. 5 columns
+// into per-lane bit queues (symbol low / high bit, and a unary slot stream: a 0 per slot boundary, a 1 per column); then it pops
+// ONE column, if it has one, and runs the bit-parallel column step on it.  The window shift of a column follows from the slot it
+// belongs to (top = max(1, slot + 1 - 31)), which the pop reads off the unary stream -- no shift queue.  Lanes whose windows hold
+// more columns than slots fall behind by their backlog (a reflected random walk: a few columns); passes of 16 pop-only
+// iterations drain them when a backlog passes BACKLOG_DRAIN columns and after the last slot.  The 32 .. 64 fragment rows below
+// the window wait in a 64-bit reservoir per plane, refilled by 32 rows every 32 slots (the same rows for all lanes: unconditional
+// loads).  The loop body is branch-free but for the pop's `if`, and every memory operation is unconditional.
 // Predecessor codes are stored PER ITERATION (the iteration index is wave-uniform, the column index is not): one u32 per
 // iteration = 14 band rows x 2 bits + the column's window shift (4 bits; 15 + codes 0 = no column in this iteration, all ones
-// = a shift the field cannot hold: full-width pass, then the exact kernel), so the walk back needs nothing but its code
-// lines.  14 rows (band rows 24 .. 37, offsets -7 .. +6 from the generative row) miss 1.9 % of the bulk and 5.4 % of the
-// polyA-tailed alignments (tools/band_rows.py on the CPU oracle; 16 rows: 0.9 % / 3.1 %); those are redone with all 64 rows stored
-// (two u64 per iteration, shift in their top bits) from the redo list.
-// HBM traffic per column: 2 B slot codes + 0.25 B planes in, 4 B codes out and 4 B in again = 10.25 B
-// (k_job + k_aln: 2.25 + 2 and 2 + 4 + 4 + 2 = 16.25 B).
+// = a shift the field cannot hold), 16 iterations per 64-byte line, the lines of a wave's 64 jobs interleaved ([wave][line][lane]),
+// so the walk back needs nothing but its code lines.  Stored rows: st .. st + 13 around the generative row, which sits at bit 31
+// once the window moves and climbs from bit 0 while it is still clamped at row 1 (st = clamp(iteration - 7, 0, 24)).  14 rows
+// (offsets -7 .. +6 from the generative row) miss 1.9 % of the bulk and 5.4 % of the polyA-tailed alignments (tools/band_rows.py
+// on the CPU oracle; 16 rows: 0.9 % / 3.1 %, 8 rows: 36 %: co-optimal paths take the deletions of a homopolymer run at its end);
+// those are redone with all 64 rows stored (two u64 per iteration, the shifts as a byte each behind the job's code lines) from the
+// redo list; a path that leaves even those (or a shift above 31 rows) sends the read to the exact wave-wide kernel.
+// The walk: every iteration's column is left exactly once, so all lanes walk back in LOCKSTEP over the iterations (an entry
+// without a column is skipped by its lane, a lane joins at its own last column); inside a column the run of up moves is one
+// find-first-bit on the column's "not up" bits.  Only the stored-row index `bs` of the current cell is tracked at iterations
+// >= 32 (matches and diagonal moves are counted, columns = n + m - diagonals); below (window possibly clamped at row 1, st
+// ramps) row and window position are tracked as well: there the path may reach row 0, after which only left moves remain.
 constexpr uint32_t ENT_EMPTY = 0xF0000000u, ENT_ESC = 0xFFFFFFFFu;
 constexpr int BACKLOG_DRAIN = 20;
 struct AlnJobF {
@@ -2442,7 +1955,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     }
     int jc = 0;
     // the window's 64 rows (x in [skip, skip + 64)) and the reservoir of the rows below it (x from 64 + skip on: `ev` of them valid);
-    // planes kept COMPLEMENTED (see aln_fast).  At the end of the 32 slots from s0 the reservoir takes x in [64 + s0, 96 + s0) --
+    // planes kept COMPLEMENTED: Eq = (~A ^ cl) & (~B ^ ch) saves two inversions per column.  At the end of the 32 slots from s0 the reservoir takes x in [64 + s0, 96 + s0) --
     // half a word of the aligned stream, the same for every lane (the first time a lane with skip = 1 drops the row its window
     // has already) -- so that the rows a column can need (x <= slot + 32) are always there.
     unsigned long long EA = 0ull, EB = 0ull;
@@ -2594,8 +2107,8 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     }
     const int m = col;
     ovf = ovf || m > mcap;                                        // (the job's op bytes / the read's output slot hold mcap columns)
-    // ---- walk back from (n, m): all lanes in lockstep over the ITERATIONS (see aln_fast for the walk itself); an entry without a
-    // column is skipped by its lane, a lane joins at its own last column
+    // ---- walk back from (n, m): all lanes in lockstep over the ITERATIONS; an entry without a column is skipped by its lane, a
+    // lane joins at its own last column
     bad = bad || shmax > 31;
     why |= (shmax > 31 ? 8u : 0u) | (shmax > 14 ? 16u : 0u) | ((act && m > 0 && (n - t > 63 || n - t < 0)) ? 32u : 0u);
     bool fail = act && m > 0 && (n - t > 63 || n - t < 0 || bad), needfull = false;
@@ -2718,7 +2231,7 @@ DEV void load_job_f(const FastBuffers& FB, uint32_t job, uint32_t rng, bool act,
     J.popd8 = reinterpret_cast<unsigned long long*>(FB.job_popd + G.popd_off + (size_t)rel * G.ncap);
     mcap = (int)G.ncap;
 }
-// what k_job did for a window that outgrew its rows (insertion-heavy read): the host reruns the batch with larger slots
+// a window that outgrew its rows (insertion-heavy read): the host reruns the batch with larger slots
 DEV void job_overflow(const FastBuffers& FB, const SimBuffers& O, uint32_t r) {
     O.status[r] |= 1u; O.out_len[r] = 0; O.rec_len[r] = 0; O.identity[r] = 0.0;
     FB.state[r].stage = 2;
@@ -2732,8 +2245,11 @@ DEV void store_result_f(const FastBuffers& FB, uint32_t r, const AlnResF& R) {
 // path left them (counters[10] of them in redo_list) with all 64 rows, lines in the full-width pool: a fixed grid whose waves loop over
 // the list.  Rounds with few jobs are bound by the latency of one lane's pass: all their jobs go straight to the 64-row version
 // (LIST false; counters[3] allocates pool lines per wave).
+// (register budget: the 14-row pass needs ~131 vector registers -- 3 waves per SIMD; forced into 128 it spills, and a spill inside
+// the pop's divergent region cost correct results once: never again below its natural size)
+constexpr int ALNF_WAVES = 3;
 template <int MODE, int ROWS, bool LIST>
-__global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
+__global__ __launch_bounds__(64, ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
     const int lane = threadIdx.x;
     if (!LIST) {
         const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
@@ -3137,7 +2653,7 @@ __global__ __launch_bounds__(256) void k_interleave_copy(int P_, PtrPack streams
     const uint64_t len = o[i + 1] - o[i];
     uint8_t* d = dst + dst_off[gi];
     // 16 bytes per lane and step (neither side is aligned: records have any length), the last bytes one at a time
-    struct __attribute__((packed, aligned(1))) U16 { uint4 v; };
+    struct __attribute__((packed, aligned(1))) U16 { uint32_t x, y, z, w; };
     const uint64_t body = len & ~15ull;
     for (uint64_t t = 16ull * lane; t < body; t += 1024) *reinterpret_cast<U16*>(d + t) = *reinterpret_cast<const U16*>(s + t);
     if (body + lane < len) d[body + lane] = s[body + lane];
@@ -3290,11 +2806,6 @@ hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_
     hipLaunchKernelGGL(k_qjobs, dim3((count + 63) / 64), dim3(64), 0, s, fb, k, count);
     return hipGetLastError();
 }
-hipError_t launch_job(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, hipStream_t s) {
-    if (!n_jobs) return hipSuccess;
-    hipLaunchKernelGGL(k_job, dim3((n_jobs + 63) / 64), dim3(64), 0, s, p, fb, o, n_jobs);
-    return hipGetLastError();
-}
 // start of a round: this round's per-range job counts and the alignment passes' two counters (rows of the full-width pool, jobs
 // handed to the second pass), in one launch
 __global__ void k_round_reset(uint32_t* __restrict__ job_cnt, uint32_t n_words, uint32_t* __restrict__ counters) {
@@ -3310,28 +2821,6 @@ hipError_t launch_round_reset(const FastBuffers& fb, hipStream_t s) {
 hipError_t launch_collect_unfinished(const FastBuffers& fb, uint64_t n_reads, hipStream_t s) {
     if (!n_reads) return hipSuccess;
     hipLaunchKernelGGL(k_collect_unfinished, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, fb, n_reads);
-    return hipGetLastError();
-}
-hipError_t launch_aln(const SimParams& p, const FastBuffers& fb, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s) {
-    if (!n_jobs) return hipSuccess;
-    const uint32_t waves = (n_jobs + 63) / 64;
-    if (full_only) {
-        if (mode) hipLaunchKernelGGL((k_aln<1, 64, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
-        else hipLaunchKernelGGL((k_aln<0, 64, false>), dim3(waves), dim3(64), 0, s, p, fb, n_jobs);
-        return hipGetLastError();
-    }
-    // pass 2's grid: an eighth of the jobs per sweep (its waves loop over what the list holds), within the pool
-    const uint32_t g2 = std::max<uint32_t>(1u, std::min<uint32_t>((waves + 7) / 8, std::max<uint32_t>(1u, fb.full_rows / 64)));
-    // pass 1 asks for lds_pad bytes of LDS it never touches: a cap on its waves per CU (16 KB: 10 instead of 20).  A wave reads its
-    // 270 KB of predecessor codes back ~1 000 columns after writing them; with fewer waves in flight more of them are still in the
-    // memory-side cache (measured: 8 - 10 waves per CU 4 % faster than 20, 4 per CU 13 % slower).
-    if (mode) {
-        hipLaunchKernelGGL((k_aln<1, 16, false>), dim3(waves), dim3(64), lds_pad, s, p, fb, n_jobs);
-        hipLaunchKernelGGL((k_aln<1, 64, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
-    } else {
-        hipLaunchKernelGGL((k_aln<0, 16, false>), dim3(waves), dim3(64), lds_pad, s, p, fb, n_jobs);
-        hipLaunchKernelGGL((k_aln<0, 64, true>), dim3(g2), dim3(64), 0, s, p, fb, n_jobs);
-    }
     return hipGetLastError();
 }
 hipError_t launch_alnf(const SimParams& p, const FastBuffers& fb, const SimBuffers& o, uint32_t n_jobs, bool full_only, int mode, unsigned lds_pad, hipStream_t s) {
