@@ -100,7 +100,9 @@ def cpu_baseline(n_reads, mean_len, seconds_budget=20.0):
 
 def e2e_leg(n_molecules):
     """`tksm sequence` on files, wall time of the whole process (start, device, reference packing, models, MDF parse, PCIe,
-    FASTQ written to a file): a fixed file of n_molecules bulk molecules (blocks of 1 M distinct molecules) on a 4 x 8 Mb genome."""
+    FASTQ written to a file): a fixed file of n_molecules bulk molecules (blocks of 1 M distinct molecules) on a 4 x 8 Mb genome.
+    Three destinations, so that the bound is visible: the temporary directory (the headline: page cache of the box's file system),
+    /dev/shm (tmpfs) and /dev/null (no file system at all: process start + device + parse + PCIe ceiling)."""
     import shutil
     import subprocess
     import tempfile
@@ -131,16 +133,32 @@ def e2e_leg(n_molecules):
         n = block * reps
         env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
         cores = host_cores()
-        cmd = [exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", os.path.join(d, "out.fastq"),
-               "-t", str(max(1, cores // 2)), "--verbosity", "ERROR"]
-        t0 = time.time()
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
-        dt = time.time() - t0
-        if r.returncode:
-            return {"reads_per_s": None, "error": r.stderr[-300:]}
-        return {"reads_per_s": n / dt, "molecules": n, "wall_s": dt, "mdf_bytes": os.path.getsize(os.path.join(d, "mols.mdf")),
-                "fastq_bytes": os.path.getsize(os.path.join(d, "out.fastq")), "files_on": base,
-                "command": "tksm sequence -i mols.mdf -r ref.fa -o out.fastq -t %d (Badread + q-scores, nanopore2020)" % max(1, cores // 2)}
+        def one(out_path):
+            cmd = [exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", out_path,
+                   "-t", str(max(1, cores // 2)), "--verbosity", "ERROR"]
+            t0 = time.time()
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+            dt = time.time() - t0
+            return (None, r.stderr[-300:]) if r.returncode else (dt, None)
+        dt, err = one(os.path.join(d, "out.fastq"))
+        if dt is None:
+            return {"reads_per_s": None, "error": err}
+        res = {"reads_per_s": n / dt, "molecules": n, "wall_s": dt, "mdf_bytes": os.path.getsize(os.path.join(d, "mols.mdf")),
+               "fastq_bytes": os.path.getsize(os.path.join(d, "out.fastq")), "files_on": base,
+               "command": "tksm sequence -i mols.mdf -r ref.fa -o out.fastq -t %d (Badread + q-scores, nanopore2020)" % max(1, cores // 2)}
+        os.remove(os.path.join(d, "out.fastq"))
+        # the same run with the records going nowhere (a character device: the ordered-writer path) and to tmpfs
+        os.symlink("/dev/null", os.path.join(d, "null.fastq"))
+        dt0, _ = one(os.path.join(d, "null.fastq"))
+        res["to_dev_null"] = {"reads_per_s": n / dt0 if dt0 else None, "wall_s": dt0}
+        if base != "/dev/shm" and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40e9:
+            shm = tempfile.mkdtemp(prefix="tksm_e2e_", dir="/dev/shm")
+            try:
+                dt1, _ = one(os.path.join(shm, "out.fastq"))
+                res["to_dev_shm"] = {"reads_per_s": n / dt1 if dt1 else None, "wall_s": dt1}
+            finally:
+                shutil.rmtree(shm, ignore_errors=True)
+        return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

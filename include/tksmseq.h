@@ -53,6 +53,12 @@ int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out);
 int tksmseq_host_alloc(uint64_t bytes, void** out);
 void tksmseq_host_free(void* p);
 int tksmseq_synchronize(tksmseq_ctx* ctx);
+/* Device memory of the caller's own (on ctx's device) and copies out of it on ctx's stream: what a writer needs to keep a batch's
+ * records (tksmseq_result_copy_device into such a buffer) while the context that made them runs its next batch.  async != 0:
+ * returns once the copy is queued (tksmseq_synchronize before the bytes are read). */
+int tksmseq_device_alloc(tksmseq_ctx* ctx, uint64_t bytes, void** out);
+void tksmseq_device_free(tksmseq_ctx* ctx, void* p);
+int tksmseq_copy_to_host(tksmseq_ctx* ctx, void* dst_host, const void* src_device, uint64_t bytes, int async);
 
 /* ---- reference genome (S0) -------------------------------------------------------------------
  * get_reference_seqs / generate_fasta, py/sequence.py:168-194: name = header up to the first

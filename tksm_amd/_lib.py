@@ -61,7 +61,7 @@ SYMBOLS = [
     "tksmseq_prefetch_model", "tksmseq_prefetch_identity", "tksmseq_result_download", "tksmseq_result_download_range", "tksmseq_result_copy_device", "tksmseq_stats_download", "tksmseq_interleave_records", "tksmseq_sequence_main",
     "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
     "tksmseq_set_host_threads", "tksmseq_model_available",
-    "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_pcr_template_counts", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
+    "tksmseq_device_alloc", "tksmseq_device_free", "tksmseq_copy_to_host", "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_pcr_template_counts", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
     "tksmseq_molecules_from_mdf_text", "tksmseq_pcr_main", "tksmseq_truncate_main",
 ]
 

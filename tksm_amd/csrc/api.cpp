@@ -85,6 +85,22 @@ int tksmseq_host_alloc(uint64_t bytes, void** out) {
 
 void tksmseq_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+int tksmseq_device_alloc(tksmseq_ctx* ctx, uint64_t bytes, void** out) {
+    if (!ctx || !out) return TKSMSEQ_EINVAL;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return TKSMSEQ_OK;
+}
+void tksmseq_device_free(tksmseq_ctx* ctx, void* p) { if (ctx && p) { (void)hipSetDevice(ctx->device); (void)hipFree(p); } }
+int tksmseq_copy_to_host(tksmseq_ctx* ctx, void* dst_host, const void* src_device, uint64_t bytes, int async) {
+    if (!ctx || ((!dst_host || !src_device) && bytes)) return TKSMSEQ_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (!async) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TKSMSEQ_OK;
+}
+
 void tksmseq_destroy(tksmseq_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

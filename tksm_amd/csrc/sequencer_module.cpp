@@ -10,9 +10,9 @@
 // Streaming: the reader cuts the MDF text into batches of whole molecules and numbers their reads; two parser threads per
 // device group (contexts of their own) turn the text into device batches ahead of time; --in-flight worker threads (one
 // context each, sharing the packed reference and the model tables) run and download a batch each, so that parsing, the
-// device work of consecutive batches, the copies and the writes overlap.  Regular output files are written by the workers
-// themselves at their final offsets (pwrite, MDF order); pipes and devices by one writer that puts the record streams back
-// into MDF order.
+// device work of consecutive batches, the copies and the writes overlap.  Regular output files are written at their final
+// offsets (pwrite, MDF order) by a writer thread per worker, from a device-side copy of the batch's records, while the worker's
+// context runs its next batch; pipes and devices by one writer that puts the record streams back into MDF order.
 // Exit codes: 0 ok; 1 for `sys.exit("msg")`-style validation and runtime errors; 2 for argparse
 // usage errors (missing -i, neither -o nor --perfect) -- what the embedded interpreter returns.
 #include "sequencer_module.h"
@@ -170,6 +170,22 @@ struct Worker {                                           // one batch in flight
     // regular uncompressed files: the records pass through two page-locked pieces (one being written while the next arrives)
     uint64_t piece = 64ull << 20;                       // (TKSMSEQ_PIECE_BYTES: small pieces for the tests)
     uint8_t* ring[2] = {nullptr, nullptr};
+    // ... behind the worker's back: the batch's records are copied into one of two device buffers of the writer's (a device copy
+    // takes a millisecond), and the worker's context runs the next batch while a thread of its own streams the buffer out
+    struct Job { int stage = 0, k = 0; uint64_t bytes = 0, off = 0; };
+    tksmseq_ctx* wctx = nullptr;                        // the writer thread's context (its stream carries the copies)
+    void* stage[2] = {nullptr, nullptr}; uint64_t stage_cap[2] = {0, 0};
+    bool stage_busy[2] = {false, false};                // guarded by m
+    std::deque<Job> jobs; bool jobs_closed = false;     // guarded by m
+    int cur_stage = 0;
+    bool stage_reserve(int q, uint64_t bytes) {
+        if (bytes <= stage_cap[q]) return true;
+        tksmseq_device_free(wctx, stage[q]); stage[q] = nullptr; stage_cap[q] = 0;
+        const uint64_t want = bytes + bytes / 8 + 4096;
+        if (tksmseq_device_alloc(wctx, want, &stage[q])) return false;
+        stage_cap[q] = want;
+        return true;
+    }
     bool ring_ready() {
         for (int q = 0; q < 2; q++)
             if (!ring[q]) { void* p = nullptr; if (tksmseq_host_alloc(piece, &p)) return false; ring[q] = (uint8_t*)p; }
@@ -535,24 +551,30 @@ public:
                     Writer& wr = k == 0 ? wb : wp;
                     if (positional && !wr.gz) {
                         // a regular uncompressed file: the batch's place in it is known as soon as every earlier batch has announced
-                        // its size; the records go there in pieces, straight from the device (pwrite into the page cache takes
-                        // ~4 GB/s per thread; the copy of the next piece runs meanwhile)
+                        // its size (writes into ONE file are serialised by the file system: 11 - 13.5 GB/s on the test box whatever
+                        // the number of threads, tools/fs_write_probe.py -- the bound of the end-to-end rate)
                         uint64_t off = 0;
                         if (!take_place(k, c.seq, r.records_bytes, n, off)) return false;
-                        if (!W.ring_ready()) { set_error("out of page-locked host memory"); return false; }
-                        const uint64_t np = (r.records_bytes + W.piece - 1) / W.piece;
-                        auto piece_bytes = [&](uint64_t q) { return std::min<uint64_t>(W.piece, r.records_bytes - q * W.piece); };
-                        if (np && tksmseq_result_download_range(W.ctx, W.ring[0], 0, piece_bytes(0), 1)) { set_error(tksmseq_last_error(W.ctx)); return false; }
-                        for (uint64_t q = 0; q < np; q++) {
-                            const auto t_copy = now();
-                            if (tksmseq_synchronize(W.ctx)) { set_error(tksmseq_last_error(W.ctx)); return false; }
-                            if (q + 1 < np && tksmseq_result_download_range(W.ctx, W.ring[(q + 1) & 1], (q + 1) * W.piece, piece_bytes(q + 1), 1)) { set_error(tksmseq_last_error(W.ctx)); return false; }
-                            add_clk(2, t_copy);
-                            const auto t_write = now();
-                            const bool wok = wr.write_at(W.ring[q & 1], piece_bytes(q), off + q * W.piece);
-                            add_clk(3, t_write);
-                            if (!wok) { (void)tksmseq_synchronize(W.ctx); set_error("write failed"); return false; }
+                        // (blocks allocated ahead of the writes: the writes into one file are serialised by the file system, and
+                        // the allocation would happen inside them -- 12 -> 13.5 GB/s on the test box, tools/fs_write_probe.py)
+                        if (r.records_bytes) (void)posix_fallocate(wr.fd, (off_t)off, (off_t)r.records_bytes);
+                        // the records move into a staging buffer of the writer thread's (device to device), which streams them
+                        // out while this context runs its next batch
+                        const auto t_copy = now();
+                        int q;
+                        {
+                            std::unique_lock<std::mutex> l(W.m);
+                            q = W.cur_stage;
+                            W.cv.wait(l, [&] { return !W.stage_busy[q] || failed.load(); });
+                            if (failed) return false;
+                            W.stage_busy[q] = true;
+                            W.cur_stage ^= 1;
                         }
+                        if (!W.stage_reserve(q, r.records_bytes)) { set_error("out of device memory for the output staging buffers"); return false; }
+                        if (r.records_bytes && (tksmseq_result_copy_device(W.ctx, W.stage[q], nullptr) || tksmseq_synchronize(W.ctx))) { set_error(tksmseq_last_error(W.ctx)); return false; }
+                        add_clk(2, t_copy);
+                        { std::lock_guard<std::mutex> l(W.m); Worker::Job j; j.stage = q; j.k = k; j.bytes = r.records_bytes; j.off = off; W.jobs.push_back(j); }
+                        W.cv.notify_all();
                         fin.bytes[k] = r.records_bytes;
                         return true;
                     }
@@ -637,7 +659,43 @@ public:
                 next++;
             }
         };
-        std::vector<std::thread> threads, parsers;
+        // positional outputs: a writer thread per worker takes the staged batches in order, copies them to the host in pieces
+        // (two page-locked pieces: the copy of one under the write of the other) and writes them at their place
+        auto write_behind = [&](int wi) {
+            Worker& W = *workers[wi];
+            for (;;) {
+                Worker::Job j;
+                {
+                    std::unique_lock<std::mutex> l(W.m);
+                    W.cv.wait(l, [&] { return !W.jobs.empty() || W.jobs_closed; });
+                    if (W.jobs.empty()) return;
+                    j = W.jobs.front(); W.jobs.pop_front();
+                }
+                Writer& wr = j.k == 0 ? wb : wp;
+                bool ok = !failed && W.ring_ready();
+                if (!ok && !failed) set_error("out of page-locked host memory");
+                const uint64_t np = (j.bytes + W.piece - 1) / W.piece;
+                auto piece_bytes = [&](uint64_t q) { return std::min<uint64_t>(W.piece, j.bytes - q * W.piece); };
+                const uint8_t* src = (const uint8_t*)W.stage[j.stage];
+                if (ok && np && tksmseq_copy_to_host(W.wctx, W.ring[0], src, piece_bytes(0), 1)) { set_error(tksmseq_last_error(W.wctx)); ok = false; }
+                for (uint64_t q = 0; q < np && ok; q++) {
+                    if (tksmseq_synchronize(W.wctx)) { set_error(tksmseq_last_error(W.wctx)); ok = false; break; }
+                    if (q + 1 < np && tksmseq_copy_to_host(W.wctx, W.ring[(q + 1) & 1], src + (q + 1) * W.piece, piece_bytes(q + 1), 1)) { set_error(tksmseq_last_error(W.wctx)); ok = false; break; }
+                    const auto t_write = now();
+                    const bool wok = wr.write_at(W.ring[q & 1], piece_bytes(q), j.off + q * W.piece);
+                    add_clk(3, t_write);
+                    if (!wok) { (void)tksmseq_synchronize(W.wctx); set_error("write failed"); ok = false; }
+                }
+                { std::lock_guard<std::mutex> l(W.m); W.stage_busy[j.stage] = false; }
+                W.cv.notify_all();
+            }
+        };
+        std::vector<std::thread> threads, parsers, writers;
+        if (positional)
+            for (int w = 0; w < n_workers; w++) {
+                if (tksmseq_clone(workers[(size_t)w]->ctx, &workers[(size_t)w]->wctx)) { set_error(std::string("writer context: ") + tksmseq_last_error(workers[(size_t)w]->ctx)); break; }
+                writers.emplace_back(write_behind, w);
+            }
         for (int w = 0; w < n_workers; w++) threads.emplace_back(work, w);
         for (int pi = 0; pi < n_groups * parsers_per_group; pi++) parsers.emplace_back(parse_ahead, pi);
         std::thread writer;
@@ -708,6 +766,8 @@ public:
         for (auto& t : parsers) t.join();
         for (auto& q2 : pq) q2->close();                                                           // (the workers take what is still queued)
         for (auto& t : threads) t.join();
+        for (auto& W : workers) { { std::lock_guard<std::mutex> l(W->m); W->jobs_closed = true; } W->cv.notify_all(); }
+        for (auto& t : writers) t.join();
         for (int g = 0; g < n_groups; g++) if (templates[(size_t)g]) tksmseq_batch_free(pctx[(size_t)g * parsers_per_group], templates[(size_t)g]);
         done_cv.notify_all();
         if (writer.joinable()) writer.join();
@@ -718,7 +778,10 @@ public:
             fprintf(stderr, "[sequence] %d batches, %d in flight, %.2f s streaming: parse %.2f, run %.2f, copy %.2f, wait for writer %.2f "
                             "(summed over workers); write %.2f; read + count %.2f\n", (int)seq, n_workers,
                     std::chrono::duration<double>(now() - t_start).count(), clk[0], clk[1], clk[2], clk[4], clk[3], clk[5]);
-        for (auto& W : workers) { tksmseq_host_free(W->host[0]); tksmseq_host_free(W->host[1]); tksmseq_host_free(W->ring[0]); tksmseq_host_free(W->ring[1]); }
+        for (auto& W : workers) {
+            tksmseq_host_free(W->host[0]); tksmseq_host_free(W->host[1]); tksmseq_host_free(W->ring[0]); tksmseq_host_free(W->ring[1]);
+            if (W->wctx) { tksmseq_device_free(W->wctx, W->stage[0]); tksmseq_device_free(W->wctx, W->stage[1]); tksmseq_destroy(W->wctx); W->wctx = nullptr; }
+        }
         const auto t_close = now();
         fclose(in);
         if ((!wb.close() || !wp.close()) && !status) { status = 1; fprintf(stderr, "Error: write failed\n"); }
