@@ -172,7 +172,7 @@ struct Worker {                                           // one batch in flight
     uint8_t* ring[2] = {nullptr, nullptr};
     // ... behind the worker's back: the batch's records are copied into one of two device buffers of the writer's (a device copy
     // takes a millisecond), and the worker's context runs the next batch while a thread of its own streams the buffer out
-    struct Job { int stage = 0, k = 0; uint64_t bytes = 0, off = 0; };
+    struct Job { int stage = 0, k = 0; uint64_t bytes = 0, off = 0, seq = 0; };
     tksmseq_ctx* wctx = nullptr;                        // the writer thread's context (its stream carries the copies)
     void* stage[2] = {nullptr, nullptr}; uint64_t stage_cap[2] = {0, 0};
     bool stage_busy[2] = {false, false};                // guarded by m
@@ -462,6 +462,12 @@ public:
         uint64_t n_batches = 0; bool reader_done = false;                                          // guarded by done_m
         // every open output is a regular file: positional writes from the workers, no writer thread
         const bool positional = (a.badread.empty() || wb.positional) && (a.perfect.empty() || wp.positional);
+        // uncompressed outputs (files, pipes, devices) are written BEHIND the workers: a batch's records move into a staging buffer on
+        // the device, and a writer thread per worker streams them out -- at their place in a regular file, in batch order into
+        // anything else -- while the worker's context runs its next batch.  (.gz outputs keep whole-batch host buffers: the members
+        // are compressed side by side.)
+        const bool behind = (a.badread.empty() || !wb.gz) && (a.perfect.empty() || !wp.gz);
+        uint64_t written_upto[2] = {0, 0};                                                          // non-seekable outputs: batches written; guarded by done_m
         uint64_t next_place[2] = {0, 0}, place[2] = {0, 0};                                        // per output; guarded by done_m
         // stage clocks (TKSMSEQ_VERBOSE): seconds spent parsing, running, copying, writing, reading
         const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr || log.level <= Logger::DEBUG;
@@ -549,15 +555,15 @@ public:
                     if (verbose2) fprintf(stderr, "[sequence] batch %llu worker %d: run %.3f s (%llu reads) at %.3f s\n", (unsigned long long)c.seq, wi,
                                           std::chrono::duration<double>(now() - t_run).count(), (unsigned long long)n, std::chrono::duration<double>(now() - t_start).count());
                     Writer& wr = k == 0 ? wb : wp;
-                    if (positional && !wr.gz) {
-                        // a regular uncompressed file: the batch's place in it is known as soon as every earlier batch has announced
+                    if (behind || (positional && !wr.gz)) {
+                        // an uncompressed output (or the plain regular file next to a .gz one); a regular file: the batch's place in it is known as soon as every earlier batch has announced
                         // its size (writes into ONE file are serialised by the file system: 11 - 13.5 GB/s on the test box whatever
                         // the number of threads, tools/fs_write_probe.py -- the bound of the end-to-end rate)
                         uint64_t off = 0;
                         if (!take_place(k, c.seq, r.records_bytes, n, off)) return false;
                         // (blocks allocated ahead of the writes: the writes into one file are serialised by the file system, and
                         // the allocation would happen inside them -- 12 -> 13.5 GB/s on the test box, tools/fs_write_probe.py)
-                        if (r.records_bytes) (void)posix_fallocate(wr.fd, (off_t)off, (off_t)r.records_bytes);
+                        if (r.records_bytes && wr.positional) (void)posix_fallocate(wr.fd, (off_t)off, (off_t)r.records_bytes);
                         // the records move into a staging buffer of the writer thread's (device to device), which streams them
                         // out while this context runs its next batch
                         const auto t_copy = now();
@@ -573,7 +579,7 @@ public:
                         if (!W.stage_reserve(q, r.records_bytes)) { set_error("out of device memory for the output staging buffers"); return false; }
                         if (r.records_bytes && (tksmseq_result_copy_device(W.ctx, W.stage[q], nullptr) || tksmseq_synchronize(W.ctx))) { set_error(tksmseq_last_error(W.ctx)); return false; }
                         add_clk(2, t_copy);
-                        { std::lock_guard<std::mutex> l(W.m); Worker::Job j; j.stage = q; j.k = k; j.bytes = r.records_bytes; j.off = off; W.jobs.push_back(j); }
+                        { std::lock_guard<std::mutex> l(W.m); Worker::Job j; j.stage = q; j.k = k; j.bytes = r.records_bytes; j.off = off; j.seq = c.seq; W.jobs.push_back(j); }
                         W.cv.notify_all();
                         fin.bytes[k] = r.records_bytes;
                         return true;
@@ -624,13 +630,21 @@ public:
                 if (ok && n) {
                     if (!a.badread.empty()) ok = emit(0, wb.fastq, TKSMSEQ_MODE_BADREAD, 0);
                     if (ok && !a.perfect.empty()) ok = a.badread.empty() ? emit(1, wp.fastq, TKSMSEQ_MODE_PERFECT, 0) : emit(1, wp.fastq, TKSMSEQ_MODE_BADREAD, 1);
-                } else if (ok && positional) {                      // an empty batch still takes its (empty) place
+                } else if (ok && (positional || behind)) {          // an empty batch still takes its (empty) place
                     uint64_t off = 0;
-                    if (!a.badread.empty()) ok = take_place(0, c.seq, 0, 0, off);
-                    if (ok && !a.perfect.empty()) ok = take_place(1, c.seq, 0, 0, off);
+                    for (int k2 = 0; k2 < 2 && ok; k2++) {
+                        if ((k2 == 0 ? a.badread : a.perfect).empty()) continue;
+                        ok = take_place(k2, c.seq, 0, 0, off);
+                        if (ok && behind && !(k2 == 0 ? wb : wp).positional) {     // ... and its turn in a non-seekable output
+                            std::unique_lock<std::mutex> l(done_m);
+                            done_cv.wait(l, [&] { return written_upto[k2] == c.seq || failed.load(); });
+                            written_upto[k2]++;
+                            done_cv.notify_all();
+                        }
+                    }
                 }
                 tksmseq_batch_free(W.ctx, b);
-                if (!ok || positional) continue;                    // (regular files: written inside emit)
+                if (!ok || positional || behind) continue;          // (written inside emit / behind the worker)
                 { std::lock_guard<std::mutex> l(W.m); W.host_busy = true; }
                 { std::lock_guard<std::mutex> l(done_m); done[c.seq] = fin; }
                 done_cv.notify_all();
@@ -678,20 +692,26 @@ public:
                 auto piece_bytes = [&](uint64_t q) { return std::min<uint64_t>(W.piece, j.bytes - q * W.piece); };
                 const uint8_t* src = (const uint8_t*)W.stage[j.stage];
                 if (ok && np && tksmseq_copy_to_host(W.wctx, W.ring[0], src, piece_bytes(0), 1)) { set_error(tksmseq_last_error(W.wctx)); ok = false; }
+                if (ok && !wr.positional) {                         // a pipe / device: the batches before this one have been written
+                    std::unique_lock<std::mutex> l(done_m);
+                    done_cv.wait(l, [&] { return written_upto[j.k] == j.seq || failed.load(); });
+                    ok = !failed;
+                }
                 for (uint64_t q = 0; q < np && ok; q++) {
                     if (tksmseq_synchronize(W.wctx)) { set_error(tksmseq_last_error(W.wctx)); ok = false; break; }
                     if (q + 1 < np && tksmseq_copy_to_host(W.wctx, W.ring[(q + 1) & 1], src + (q + 1) * W.piece, piece_bytes(q + 1), 1)) { set_error(tksmseq_last_error(W.wctx)); ok = false; break; }
                     const auto t_write = now();
-                    const bool wok = wr.write_at(W.ring[q & 1], piece_bytes(q), j.off + q * W.piece);
+                    const bool wok = wr.positional ? wr.write_at(W.ring[q & 1], piece_bytes(q), j.off + q * W.piece) : wr.write(W.ring[q & 1], piece_bytes(q));
                     add_clk(3, t_write);
                     if (!wok) { (void)tksmseq_synchronize(W.wctx); set_error("write failed"); ok = false; }
                 }
+                if (!wr.positional) { { std::lock_guard<std::mutex> l(done_m); if (ok) written_upto[j.k]++; } done_cv.notify_all(); }
                 { std::lock_guard<std::mutex> l(W.m); W.stage_busy[j.stage] = false; }
                 W.cv.notify_all();
             }
         };
         std::vector<std::thread> threads, parsers, writers;
-        if (positional)
+        if (behind || positional)
             for (int w = 0; w < n_workers; w++) {
                 if (tksmseq_clone(workers[(size_t)w]->ctx, &workers[(size_t)w]->wctx)) { set_error(std::string("writer context: ") + tksmseq_last_error(workers[(size_t)w]->ctx)); break; }
                 writers.emplace_back(write_behind, w);
@@ -699,7 +719,7 @@ public:
         for (int w = 0; w < n_workers; w++) threads.emplace_back(work, w);
         for (int pi = 0; pi < n_groups * parsers_per_group; pi++) parsers.emplace_back(parse_ahead, pi);
         std::thread writer;
-        if (!positional) writer = std::thread(write_all);
+        if (!positional && !behind) writer = std::thread(write_all);
 
         // reader: batches of whole molecules, numbered; the first read index of a batch is known before it is parsed
         std::vector<char> buf;
@@ -771,7 +791,7 @@ public:
         for (int g = 0; g < n_groups; g++) if (templates[(size_t)g]) tksmseq_batch_free(pctx[(size_t)g * parsers_per_group], templates[(size_t)g]);
         done_cv.notify_all();
         if (writer.joinable()) writer.join();
-        if (positional && !failed) { wb.wrote = place[0] != 0; wp.wrote = place[1] != 0; }
+        if ((positional || behind) && !failed) { wb.wrote = wb.wrote || place[0] != 0; wp.wrote = wp.wrote || place[1] != 0; }
         int status = failed ? 1 : 0;
         if (status) fprintf(stderr, "Error: %s\n", first_error.c_str());
         if (verbose)
