@@ -1,7 +1,8 @@
 """Per-kernel HBM bytes per step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; both report KiB), corrected with
 the factors calibrated on this repo's access patterns (tools/calib/fetch_calib.hip -> profiles/r02_fetch_calibration.json):
 FETCH_SIZE tallies 128-byte requests at 64 bytes, so wide coalesced reads are under-reported by 2 (MI355X_MICROARCH.md),
-per-lane 64-byte runs (k_job's slot codes; k_aln's record and code lines since r02_c) by 1 / 0.606 (whole 64-byte lines moved by 4
+per-lane 64-byte runs (k_alnf's code lines and slot codes -- every lane streams rows of its own; k_job's slot codes and k_aln's
+record and code lines in round 2) by 1 / 0.606 (whole 64-byte lines moved by 4
 lanes x 16 bytes, k_aln up to r02_b: 1 / 0.542); single 16-byte gathers (k_loop's table reads) are counted as one 64-byte sector
 each (factor 1); WRITE_SIZE is exact."""
 import csv, glob, collections, json, re, sys
@@ -9,7 +10,7 @@ import csv, glob, collections, json, re, sys
 d, nsteps = sys.argv[1], int(sys.argv[2])
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1703936
 tag = sys.argv[4] if len(sys.argv) > 4 else ""
-FETCH_FACTOR = {"k_aln": 1 / 0.606, "k_job": 1 / 0.606, "k_loop": 1.0, "k_qjobs": 1.0, "k_err": 2.0, "k_init": 2.0, "k_emit": 2.0, "k_perfect": 2.0,
+FETCH_FACTOR = {"k_alnf": 1 / 0.606, "k_aln": 1 / 0.606, "k_job": 1 / 0.606, "k_loop": 1.0, "k_qjobs": 1.0, "k_err": 2.0, "k_init": 2.0, "k_emit": 2.0, "k_perfect": 2.0,
                 "k_pack": 2.0, "k_simulate": 1.0}
 
 
