@@ -15,6 +15,27 @@
  *
  * There is no CPU fallback: every compute entry point runs HIP kernels on gfx950 and fails with
  * TKSMSEQ_EDEVICE when no device is usable.
+ *
+ * Environment.  Results never depend on any of these: they choose between kernel variants that produce the same bytes (the GPU tests
+ * use them to reach every variant) or print diagnostics.  Read when a context is created unless noted.
+ *   TKSM_MODELS            colon list of model directories searched after the built-in one (src/sequence.cpp:38-52, py/sequence.py:17-31)
+ *   TKSMSEQ_BUILTIN_MODELS the built-in model directory (default: models/ next to the library)
+ *   TKSMSEQ_VERBOSE=1|2    per-run statistics on stderr (rounds, slow-path reads, full-width redo jobs, alignment fall-backs by reason);
+ *                          2: per-batch stage times as well (also read by the CLI)
+ *   TKSMSEQ_FORCE_SLOW=1   every read through the exact wave-wide kernel (k_simulate) instead of the fast pipeline
+ *   TKSMSEQ_SMALL_ALN=N    rounds with at most N alignment jobs store all 64 band rows in one launch (default 131072; 0: always the
+ *                          14-row pass + redo list)
+ *   TKSMSEQ_SMALL_ROUND=N  (round 1's launch grouping; kept for the tests) rounds below N reads are launched merged (default 16384)
+ *   TKSMSEQ_WAVE_LOOP=N    rounds with at most N reads left run the error loop one wave per read (k_loopw; default 16384, 0: never)
+ *   TKSMSEQ_ALN_LDS_PAD=B  bytes of LDS the 14-row alignment pass asks for without using them: caps its waves per CU (default 0)
+ *   TKSMSEQ_HBM_STATE_LEN=L fragments longer than L are edited in HBM by the last visit instead of being staged in LDS (default 2304)
+ *   TKSMSEQ_DEFER_LEN=L    reads longer than L wait with their q-score alignment until the regular rounds are over (default 0: all)
+ *   TKSMSEQ_BUCKETS=N      length buckets of the last visit's launches (default 16)
+ *   TKSMSEQ_TAIL_CUT=N     diagnostic: once fewer than N reads are left, they finish in the wave-wide kernel (default 0: off)
+ *   TKSMSEQ_FULL_POOL_MB=M memory for the unbanded alignment fallback of the wave-wide kernel (default 1024)
+ *   TKSMSEQ_PIECE_BYTES=B  (CLI) size of the page-locked pieces a batch's records pass through (default 64 MB; the tests use 4 KB)
+ *   TKSMSEQ_ABLATE=N       only in the diagnostic build (`make ablate`, -DTKSM_ABLATE): early-return points for timing experiments
+ *   GPU_MAX_HW_QUEUES      (HIP runtime) the CLI and bench.py set 16 when unset: a hardware queue per context in flight -- INTEGRATION.md
  */
 #ifndef TKSMSEQ_H
 #define TKSMSEQ_H

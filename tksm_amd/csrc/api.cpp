@@ -1002,7 +1002,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
                     (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);
             fprintf(stderr, "[tksmseq] fused alignment failures: %u, reasons or-ed 0x%x, last 0x%x (n %u, m %u)\n", cc[12], cc[13], cc[14], cc[15] & 0xffffu, cc[15] >> 16);
-            fprintf(stderr, "[tksmseq]   per reason: npend %u upos %u ev %u sh>31 %u sh>14 %u end cell %u walk %u | q-score jobs %u, list pass %u\n", cc[16], cc[17], cc[18], cc[19], cc[20], cc[21], cc[22], cc[24], cc[25]);
+            fprintf(stderr, "[tksmseq]   per reason: queue / reservoir overflow %u - - shift>31 %u shift>14 %u end cell %u walk %u | q-score jobs %u, list pass %u\n", cc[16], cc[19], cc[20], cc[21], cc[22], cc[24], cc[25]);
         }
         for (int k2 = 0; k2 < tksmseq_ctx::N_SIDE; k2++)
             if (ctx->side_used[k2]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_done[k2], 0));

@@ -1944,14 +1944,14 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     const int wb = base >> 6, bsh = base & 63;
     auto fpw = [&](int w) { return J.fp[min(max(w, 0), J.wlast)]; };
     auto aligned = [&](const ulonglong2& a, const ulonglong2& b) { ulonglong2 v; v.x = funnel128(a.x, b.x, bsh); v.y = funnel128(a.y, b.y, bsh); return v; };
-    ulonglong2 Wn, Rl, Rn;                                        // word jc + 1 (jc = s0 >> 6); raw word behind it; next raw word (in flight)
+    ulonglong2 Wn;                                                // word jc + 1 (jc = s0 >> 6), fetched when the slots reach it (once per 64
+                                                                  // iterations: its latency is the other waves' to hide, its registers are not held)
     unsigned long long A, B;
     {
         const ulonglong2 r0 = fpw(wb), r1 = fpw(wb + 1), r2 = fpw(wb + 2);
         const ulonglong2 W0 = aligned(r0, r1);
         Wn = aligned(r1, r2);
         A = ~funnel128(W0.x, Wn.x, skip); B = ~funnel128(W0.y, Wn.y, skip);
-        Rl = r2; Rn = fpw(wb + 3);
     }
     int jc = 0;
     // the window's 64 rows (x in [skip, skip + 64)) and the reservoir of the rows below it (x from 64 + skip on: `ev` of them valid);
@@ -1967,7 +1967,6 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     unsigned long long U = 0ull;
     int npend = 0, upos = 0, pcol = -1 - skip, col = 0, col32 = 0, shmax = 0;
     bool bad = false;
-    uint32_t why = 0u;
     // ---- slot codes: 16 slots (32 bytes) at a time, the next 16 in flight
     struct __attribute__((packed, aligned(4))) U4b { uint32_t x, y, z, w; };
     uint32_t cw[8], cwn[8];
@@ -2005,7 +2004,6 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
             const uint32_t m5 = (1u << len) - 1u;
             const uint32_t lo5 = code & m5, hi5 = (code >> 5) & m5;
             bad |= npend > 26 || upos > 57;
-            why |= (npend > 26 ? 1u : 0u) | (upos > 57 ? 2u : 0u);
             qlo |= lo5 << npend; qhi |= hi5 << npend;
             U |= (unsigned long long)(m5 << 1) << upos;
             upos += len + inc; npend += len;
@@ -2086,8 +2084,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
         if (!drain) {
             if (s0 & 16) {
                 // the reservoir takes the 32 rows x in [64 + s0 - 16, 96 + s0 - 16): a half of the next aligned word
-                bad |= ev > 32 && s0 + HS - skip < n;
-                why |= (ev > 32 && s0 + HS - skip < n) ? 4u : 0u;              // (a lane past its last slot takes nothing from the reservoir any more)
+                bad |= ev > 32 && s0 + HS - skip < n;              // (a lane past its last slot takes nothing from the reservoir any more)
                 const bool upper = ((s0 - 16) & 32) != 0;
                 const bool first = s0 == 16;
                 const uint32_t drop = first ? (uint32_t)skip : 0u;
@@ -2096,8 +2093,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 ev += 32 - (int)drop;
                 if (upper) {                                      // the plane words follow the slot position
                     jc++;
-                    Wn = aligned(Rl, Rn);
-                    Rl = Rn; Rn = fpw(wb + jc + 3);
+                    Wn = aligned(fpw(wb + jc + 1), fpw(wb + jc + 2));
                 }
             }
 #pragma unroll
@@ -2109,8 +2105,8 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     ovf = ovf || m > mcap;                                        // (the job's op bytes / the read's output slot hold mcap columns)
     // ---- walk back from (n, m): all lanes in lockstep over the ITERATIONS; an entry without a column is skipped by its lane, a
     // lane joins at its own last column
+    const uint32_t why = (bad ? 1u : 0u) | (shmax > 31 ? 8u : 0u) | (shmax > 14 ? 16u : 0u) | ((act && m > 0 && (n - t > 63 || n - t < 0)) ? 32u : 0u);
     bad = bad || shmax > 31;
-    why |= (shmax > 31 ? 8u : 0u) | (shmax > 14 ? 16u : 0u) | ((act && m > 0 && (n - t > 63 || n - t < 0)) ? 32u : 0u);
     bool fail = act && m > 0 && (n - t > 63 || n - t < 0 || bad), needfull = false;
     bool live = act && !fail && m > 0 && !ovf;
     uint32_t mt = 0, dg = 0;
@@ -2247,9 +2243,9 @@ DEV void store_result_f(const FastBuffers& FB, uint32_t r, const AlnResF& R) {
 // (LIST false; counters[3] allocates pool lines per wave).
 // (register budget: the 14-row pass needs ~131 vector registers -- 3 waves per SIMD; forced into 128 it spills, and a spill inside
 // the pop's divergent region cost correct results once: never again below its natural size)
-constexpr int ALNF_WAVES = 3;
+constexpr int ALNF_WAVES = 4;
 template <int MODE, int ROWS, bool LIST>
-__global__ __launch_bounds__(64, ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
+__global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
     const int lane = threadIdx.x;
     if (!LIST) {
         const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
