@@ -1173,7 +1173,7 @@ DEV void join_out(const uint8_t* frag, const uint16_t* nb, int n, uint8_t* out_s
 // slot codes stay in HBM (read and written only by the draws that change something).
 // A read that stops at a re-estimation point gets an alignment job here (id, meta record: k_alnf decodes and aligns its window
 // it; pending = 1); one whose loop has ended waits in stage 3 for its q-score job and its last visit (k_qjobs, k_err).
-constexpr int LOOP_B = 4;
+constexpr int LOOP_N = 16, LOOP_K = 4;      // draws per pass of k_loop; changing draws applied per pass
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
                                               uint32_t begin, uint32_t count, int Wl, int from_jobs, uint32_t c0, uint32_t c1) {
     uint32_t* lf = reinterpret_cast<uint32_t*>(lds_raw);      // [Wl][64]: word w of lane l at w * 64 + l (conflict-free)
@@ -1248,106 +1248,135 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     if (P.ablate == 33) st = IDLE;                              // timing experiment: prologue only
     int nbatch = 0;
 #endif
+    // ---- passes of LOOP_N draws.  Phase 1, all LOOP_N draws: generator, k-mer, the k-mer's own threshold t0 (one round of gathers
+    // for all of them) -> which draws change something (~19 %).  Phase 2, the first LOOP_K of those only: the generator once more
+    // (its other words), then segment thresholds + the slot codes under the k-mer, then the alternative -- the rounds of dependent
+    // gathers that go to the read's own rows and the big tables are paid once per pass, not once per four draws.  Phase 3 applies
+    // them in draw order; the no-op draws in between only advance the draw counter (the stop rules move with applied changes
+    // alone).  Draws behind the LOOP_K-th changing one, a re-estimation point or the end of the loop are dropped and drawn again.
+    uint32_t* ldi = lf + (size_t)Wl * 64;                     // [LOOP_N][64] draw positions of the pass
+    uint16_t* lki = reinterpret_cast<uint16_t*>(ldi + LOOP_N * 64);   // [LOOP_N][64] their k-mer indices
     while (__ballot(st == RUN) != 0ull) {
-#ifdef TKSM_ABLATE
-        if (P.ablate >= 34 && P.ablate <= 36 && ++nbatch > (P.ablate == 34 ? 10 : P.ablate == 35 ? 20 : 40)) break;   // ... a fixed number of batches
-#endif
         if (st != RUN) continue;
-        // ---- four draws: positions and k-mers (first base in the high bits of the table index)
-        int di[LOOP_B], kidx[LOOP_B];
-        uint32_t dw[LOOP_B], dz[LOOP_B], dv[LOOP_B];
+        const uint32_t navail = (uint32_t)max(0ll, min((long long)LOOP_N, loop_limit - (long long)n));     // draws of this pass below the loop limit
+        uint32_t mask = 0u;                                    // draws of the pass that change something
+        {
+            uint32_t dwv[LOOP_N], t0v[LOOP_N];
 #pragma unroll
-        for (int b = 0; b < LOOP_B; b++) {
-            const Ph4 d = philox(P.seed, g, ST_DRAW, n + (uint32_t)b);
-            di[b] = (int)__umulhi(d.x, kmer_range); dw[b] = d.y; dz[b] = d.z; dv[b] = d.w;
-        }
-#pragma unroll
-        for (int b = 0; b < LOOP_B; b++) {
-            const int w = di[b] >> 4, o = di[b] & 15;
-#ifdef TKSM_ABLATE
-            if (P.ablate == 31 || P.ablate == 32) {             // timing experiment: every k-mer from the words in LDS (wrong results)
-                const int w2 = min(w, Wl - 2);
-                kidx[b] = (int)((uint32_t)(mk64(lf[w2 * 64 + lane], lf[(w2 + 1) * 64 + lane]) >> (64 - 2 * o - 2 * k)) & kmask);
-                continue;
+            for (int b = 0; b < LOOP_N; b++) {
+                const Ph4 d = philox(P.seed, g, ST_DRAW, n + (uint32_t)b);
+                const int di1 = (int)__umulhi(d.x, kmer_range);
+                dwv[b] = d.y;
+                const int w = di1 >> 4, o = di1 & 15;
+                const uint32_t hi = w < Wl ? lf[w * 64 + lane] : f2[w], lo = w + 1 < Wl ? lf[(w + 1) * 64 + lane] : f2[w + 1];
+                const uint32_t kx = (uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask;
+                ldi[b * 64 + lane] = (uint32_t)di1; lki[b * 64 + lane] = (uint16_t)kx;
+                t0v[b] = EM.pseg[kx].x;
             }
-#endif
-            const uint32_t hi = w < Wl ? lf[w * 64 + lane] : f2[w], lo = w + 1 < Wl ? lf[(w + 1) * 64 + lane] : f2[w + 1];
-            kidx[b] = (int)((uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask);
-        }
-        // ---- first-level thresholds {t0, t8, t16, t24}: the k-mer itself (t0, ~81 % of the draws) ends here.
-        // Every load below is unconditional and straight-line, so that the four draws' requests are in flight together
-        // (a load inside a divergent region is waited for at the region's end); lanes that do not need one read a common
-        // dummy address (one cache line for the whole wave).
-        int cls[LOOP_B];                                      // 0 no-op, 1 alternative a (thresholds needed), 2 random change, 3 alternative 0
-        uint4 seg[LOOP_B];
-        int nab[LOOP_B];
 #pragma unroll
-        for (int b = 0; b < LOOP_B; b++) { seg[b] = EM.pseg[kidx[b]]; nab[b] = EM.max_alts; }
-#ifdef TKSM_ABLATE
-        if (P.ablate == 30 || P.ablate == 32) {                 // timing experiment: no first-level gather (wrong results)
-#pragma unroll
-            for (int b = 0; b < LOOP_B; b++) seg[b] = make_uint4(3478923509u + (uint32_t)(kidx[b] & 1023), 3800000000u, 4000000000u, 4200000000u);
+            for (int b = 0; b < LOOP_N; b++) {
+                const bool chg = EM.type == 0 || !EM.alt0_noop || !(dwv[b] < t0v[b]);
+                mask |= (chg && (uint32_t)b < navail) ? 1u << b : 0u;
+            }
         }
-#endif
+        // ---- the first LOOP_K changing draws (relative index LOOP_N: none)
+        int di[LOOP_K], kidx[LOOP_K];
+        uint32_t bj[LOOP_K], dw[LOOP_K], dz[LOOP_K], dv[LOOP_K];
+        bool rest;                                             // more changing draws than LOOP_K: the pass ends behind the last chosen one
+        {
+            uint32_t mm = mask;
+#pragma unroll
+            for (int j = 0; j < LOOP_K; j++) {
+                bj[j] = mm ? (uint32_t)__builtin_ctz(mm) : (uint32_t)LOOP_N;
+                mm &= mm - 1u;
+                const uint32_t bb = min(bj[j], (uint32_t)LOOP_N - 1u);
+                const Ph4 d = philox(P.seed, g, ST_DRAW, n + bb);
+                dw[j] = d.y; dz[j] = d.z; dv[j] = d.w;
+                di[j] = (int)ldi[bb * 64 + lane]; kidx[j] = (int)lki[bb * 64 + lane];
+            }
+            rest = mm != 0u;
+        }
+        // ---- first-level thresholds {t0, t8, t16, t24} again (the lines are in the cache), segment thresholds, slot codes.
+        // Every load below is unconditional and straight-line (a load inside a divergent region is waited for at the region's end);
+        // lanes that do not need one read a common dummy address (one cache line for the whole wave).
+        int cls[LOOP_K];                                      // 0 no-op, 1 alternative a (thresholds needed), 2 random change, 3 alternative 0
+        uint4 seg[LOOP_K];
+        int nab[LOOP_K];
+#pragma unroll
+        for (int j = 0; j < LOOP_K; j++) { seg[j] = EM.pseg[kidx[j]]; nab[j] = EM.max_alts; }
         if (!EM.uniform_nalts) {
 #pragma unroll
-            for (int b = 0; b < LOOP_B; b++) nab[b] = (int)EM.nalts[kidx[b]];
+            for (int j = 0; j < LOOP_K; j++) nab[j] = (int)EM.nalts[kidx[j]];
         }
-        int sbase[LOOP_B];
-        uint4 th0[LOOP_B], th1[LOOP_B];
+        int sbase[LOOP_K];
+        uint4 th0[LOOP_K], th1[LOOP_K];
         struct __attribute__((packed, aligned(4))) W5 { uint32_t v[5]; };
-        W5 nbw[LOOP_B];                                       // the slot codes under the k-mer: 10 u16 from the even position below i
+        W5 nbw[LOOP_K];                                       // the slot codes under the k-mer: 10 u16 from the even position below i
 #pragma unroll
-        for (int b = 0; b < LOOP_B; b++) {
-            cls[b] = EM.type == 0 ? 2 : (dw[b] < seg[b].x ? (EM.alt0_noop ? 0 : 3) : 1);
-            sbase[b] = 8 * ((dw[b] < seg[b].y ? 0 : 1) + (dw[b] < seg[b].z ? 0 : 1) + (dw[b] < seg[b].w ? 0 : 1));
-            const uint4* c4 = reinterpret_cast<const uint4*>(EM.cdf32 + (cls[b] == 1 ? (size_t)kidx[b] * 32 + sbase[b] : (size_t)0));
-            th0[b] = c4[0]; th1[b] = c4[1];
-            const uint16_t* gp = cls[b] != 0 ? gnb + (di[b] & ~1) : FB.st_nb;
-            nbw[b] = *reinterpret_cast<const W5*>(gp);
+        for (int j = 0; j < LOOP_K; j++) {
+            const bool have = bj[j] < (uint32_t)LOOP_N;
+            cls[j] = !have ? 0 : EM.type == 0 ? 2 : (dw[j] < seg[j].x ? (EM.alt0_noop ? 0 : 3) : 1);
+            sbase[j] = 8 * ((dw[j] < seg[j].y ? 0 : 1) + (dw[j] < seg[j].z ? 0 : 1) + (dw[j] < seg[j].w ? 0 : 1));
+            const uint4* c4 = reinterpret_cast<const uint4*>(EM.cdf32 + (cls[j] == 1 ? (size_t)kidx[j] * 32 + sbase[j] : (size_t)0));
+            th0[j] = c4[0]; th1[j] = c4[1];
+            const uint16_t* gp = cls[j] != 0 ? gnb + (di[j] & ~1) : FB.st_nb;
+            nbw[j] = *reinterpret_cast<const W5*>(gp);
         }
         // ---- the alternatives
-        uint4 alt[LOOP_B];
+        uint4 alt[LOOP_K];
 #pragma unroll
-        for (int b = 0; b < LOOP_B; b++) {
+        for (int j = 0; j < LOOP_K; j++) {
             size_t at = 0;
-            if (cls[b] == 1 || cls[b] == 3) {
-                const int na = nab[b];
-                int a = 0;
-                if (cls[b] == 1) {
-                    const uint32_t w = dw[b];
-                    a = sbase[b];
-                    a += !(w < th0[b].x) ? 1 : 0; a += !(w < th0[b].y) ? 1 : 0; a += !(w < th0[b].z) ? 1 : 0; a += !(w < th0[b].w) ? 1 : 0;
-                    a += !(w < th1[b].x) ? 1 : 0; a += !(w < th1[b].y) ? 1 : 0; a += !(w < th1[b].z) ? 1 : 0; a += !(w < th1[b].w) ? 1 : 0;
-                    a = min(a, na);
+            if (cls[j] == 1 || cls[j] == 3) {
+                const int na = nab[j];
+                int a2 = 0;
+                if (cls[j] == 1) {
+                    const uint32_t w = dw[j];
+                    a2 = sbase[j];
+                    a2 += !(w < th0[j].x) ? 1 : 0; a2 += !(w < th0[j].y) ? 1 : 0; a2 += !(w < th0[j].z) ? 1 : 0; a2 += !(w < th0[j].w) ? 1 : 0;
+                    a2 += !(w < th1[j].x) ? 1 : 0; a2 += !(w < th1[j].y) ? 1 : 0; a2 += !(w < th1[j].z) ? 1 : 0; a2 += !(w < th1[j].w) ? 1 : 0;
+                    a2 = min(a2, na);
                 }
-                if (a == na) cls[b] = 2;                      // residual mass: add_one_random_change
-                else if (a == 0 && EM.alt0_noop) cls[b] = 0;
-                else at = (size_t)kidx[b] * EM.max_alts + a;
+                if (a2 == na) cls[j] = 2;                     // residual mass: add_one_random_change
+                else if (a2 == 0 && EM.alt0_noop) cls[j] = 0;
+                else at = (size_t)kidx[j] * EM.max_alts + a2;
             }
-            alt[b] = EM.alts_enc[at];
+            alt[j] = EM.alts_enc[at];
         }
-        // ---- apply in order
-        uint32_t wrote = 0u;                                  // draws of this batch that wrote slots
+        // ---- apply in draw order.  `n` is the draw whose iteration comes next; n0 the pass's first draw; the pass holds the draws
+        // n0 .. n0 + end - 1
+        const uint32_t n0 = n;
+        const uint32_t end = rest ? bj[LOOP_K - 1] + 1u : navail;
+        uint32_t wrote = 0u;                                  // chosen draws of this pass that wrote slots
+        // the top of an iteration (:353-367); false: the loop has ended.  The estimate only moves when a change is applied, so one
+        // look covers a run of draws that change nothing and the changing draw behind them
+        auto top_of_iteration = [&](double& est) -> bool {
+            est = 1.0 - div_inrange(errors, frag_len, rcp_len);
+            if ((double)change_count > 0.9 * frag_len || est <= target) { st = DONE; st_draws = (int)n; return false; }
+            if ((long long)n + 1 > loop_limit) { st = DONE; st_draws = (int)loop_limit; return false; }
+            return true;
+        };
 #pragma unroll
-        for (int b = 0; b < LOOP_B; b++) {
+        for (int j = 0; j <= LOOP_K; j++) {
             if (st != RUN) break;
             double est = est_keep;
-            if (resume_j == 0) {
-                // stop rules at the top of an iteration (:353-367)
-                est = 1.0 - div_inrange(errors, frag_len, rcp_len);
-                if ((double)change_count > 0.9 * frag_len || est <= target) { st = DONE; st_draws = (int)n; break; }
-                if ((long long)n + 1 > loop_limit) { st = DONE; st_draws = (int)loop_limit; break; }
+            if (j == LOOP_K || bj[j] >= (uint32_t)LOOP_N) {
+                // behind the last chosen draw: the rest of the pass changes nothing
+                if (n - n0 < end) { if (!top_of_iteration(est)) break; n = n0 + end; }
+                if (!rest && navail < (uint32_t)LOOP_N) (void)top_of_iteration(est);      // the next iteration is the one the loop limit ends
+                break;
             }
-            if (cls[b] != 0) {
-                uint4 A = alt[b];
-                if (cls[b] == 2) {
+            if (resume_j == 0 && !top_of_iteration(est)) break;
+            n = n0 + bj[j];                                   // (the draws in front of this one change nothing)
+            if (cls[j] != 0) {
+                uint4 A = alt[j];
+                if (cls[j] == 2) {
                     // add_one_random_change (:199-213): one slot of the k-mer changes -- substitution by the r3-th next base,
                     // insertion of base4 before / after, deletion; the other slots keep their base (encoding 0: never applied)
-                    const uint32_t type = __umulhi(dz[b], 3u), pos = __umulhi(dv[b], (uint32_t)k);
-                    const uint32_t base4 = dv[b] & 3u, side = (dv[b] >> 2) & 1u;
-                    const uint32_t r3 = (((dz[b] & 0xffffu) * 3u) >> 16) + 1u;
-                    const uint32_t kc = ((uint32_t)kidx[b] >> (2 * (k - 1 - (int)pos))) & 3u;
+                    const uint32_t type = __umulhi(dz[j], 3u), pos = __umulhi(dv[j], (uint32_t)k);
+                    const uint32_t base4 = dv[j] & 3u, side = (dv[j] >> 2) & 1u;
+                    const uint32_t r3 = (((dz[j] & 0xffffu) * 3u) >> 16) + 1u;
+                    const uint32_t kc = ((uint32_t)kidx[j] >> (2 * (k - 1 - (int)pos))) & 3u;
                     const uint32_t v = type == 0 ? 0x8000u | (1u << 12) | planar1((kc + r3) & 3u)
                                      : type == 1 ? 0x8000u | (2u << 12) | (side ? planar2(kc, base4) : planar2(base4, kc))
                                                  : 0x8000u;
@@ -1359,24 +1388,24 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                               (((A.z >> 15) & 1u) << 4) | ((A.z >> 31) << 5) | (((A.w >> 15) & 1u) << 6) | ((A.w >> 31) << 7);
                 dm &= ((1u << k) - 1u) & ~((1u << resume_j) - 1u);
                 if (dm) {
-                    // slot codes read before an overlapping earlier draw of this batch wrote: read them again (rare)
+                    // slot codes read before an overlapping earlier draw of this pass wrote: read them again (rare)
                     bool stale = false;
 #pragma unroll
-                    for (int b2 = 0; b2 < LOOP_B; b2++) if (b2 < b) stale |= ((wrote >> b2) & 1u) && abs(di[b] - di[b2]) < k;
-                    if (stale) nbw[b] = *reinterpret_cast<const W5*>(gnb + (di[b] & ~1));
+                    for (int j2 = 0; j2 < LOOP_K; j2++) if (j2 < j) stale |= ((wrote >> j2) & 1u) && abs(di[j] - di[j2]) < k;
+                    if (stale) nbw[j] = *reinterpret_cast<const W5*>(gnb + (di[j] & ~1));
                     // in slot order (:378-403): applied if the position is still pristine
                     const double f15 = est * sqrt_inrange(est);
-                    const int odd = di[b] & 1;
+                    const int odd = di[j] & 1;
                     int stop_at = -1;
                     while (dm) {
                         const int jj = __builtin_ctz(dm);
                         dm &= dm - 1u;
                         const int ent = jj + odd, wi = ent >> 1;
-                        const uint32_t cw2 = wi == 0 ? nbw[b].v[0] : wi == 1 ? nbw[b].v[1] : wi == 2 ? nbw[b].v[2] : wi == 3 ? nbw[b].v[3] : nbw[b].v[4];
+                        const uint32_t cw2 = wi == 0 ? nbw[j].v[0] : wi == 1 ? nbw[j].v[1] : wi == 2 ? nbw[j].v[2] : wi == 3 ? nbw[j].v[3] : nbw[j].v[4];
                         if (((cw2 >> (16 * (ent & 1))) & 0x8000u) == 0u) {              // still pristine (bit 15: changed)
                             const uint32_t e = draw_slot(A, jj);
-                            gnb[di[b] + jj] = (uint16_t)(e | 0x8000u);
-                            wrote |= 1u << b;
+                            gnb[di[j] + jj] = (uint16_t)(e | 0x8000u);
+                            wrote |= 1u << j;
                             change_count++;
                             const int len_j = (int)((e >> 12) & 7u);
                             errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
@@ -2788,7 +2817,7 @@ hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuf
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
     const int Wl = loop_lds_words(lcap);
-    hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
+    hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256 + (size_t)LOOP_N * 64 * 6, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
     return hipGetLastError();
 }
 hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
