@@ -197,6 +197,10 @@ int loop_lds_words(int lcap);
 // the same visit with one wave per read (rounds with few reads left; the read's slot codes are staged in LDS: lcap <= 32768)
 hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                         uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
+// the same visits, and every later visit of the read, on one wave (k_loopw<true>: the alignments by band_align on the wave)
+hipError_t launch_tail(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
+                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
+size_t tail_lds_bytes(int lcap);
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,

@@ -54,19 +54,27 @@ DEV uint8_t comp(uint8_t c) {
     return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
 }
 
-DEV int scan_min_incl(int x, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x = min(x, y); }
-    return x;
-}
-DEV int scan_max_incl(int x, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x = max(x, y); }
-    return x;
-}
-DEV int scan_add_incl(int x, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+// Wave-wide inclusive scans by data-parallel-primitive moves (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then the last lane
+// of row 0 / 2 to row 1 / 3 and lane 31 to the upper half): 6 steps of ~2 instructions, no LDS crossbar (ds_bpermute: ~70 cycles
+// of latency a step, 6 steps a scan -- the column step of band_align is a chain of two scans).  A lane without a source keeps
+// `old` = the operation's identity.
+template <int CTRL, int ROW_MASK> DEV int dpp_mov(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false); }
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;    // lane l takes lane l + 1 / lane l - 1 (the first / last lane keeps `old`)
+#define TKSM_DPP_SCAN(OP, IDENT, x)                         \
+    x = OP(x, dpp_mov<0x111, 0xf>(IDENT, x));               \
+    x = OP(x, dpp_mov<0x112, 0xf>(IDENT, x));               \
+    x = OP(x, dpp_mov<0x114, 0xf>(IDENT, x));               \
+    x = OP(x, dpp_mov<0x118, 0xf>(IDENT, x));               \
+    x = OP(x, dpp_mov<0x142, 0xa>(IDENT, x));               \
+    x = OP(x, dpp_mov<0x143, 0xc>(IDENT, x));
+DEV int scan_min_incl(int x, int) { TKSM_DPP_SCAN(min, 0x7fffffff, x) return x; }
+DEV int scan_max_incl(int x, int) { TKSM_DPP_SCAN(max, (int)0x80000000, x) return x; }
+DEV int add_i32(int a, int b) { return a + b; }
+DEV int scan_add_incl(int x, int) { TKSM_DPP_SCAN(add_i32, 0, x) return x; }
+DEV uint32_t scan_umax_incl(uint32_t x) {
+#define TKSM_UMAX_STEP(C, R) x = max(x, (uint32_t)dpp_mov<C, R>(0, (int)x));
+    TKSM_UMAX_STEP(0x111, 0xf) TKSM_UMAX_STEP(0x112, 0xf) TKSM_UMAX_STEP(0x114, 0xf) TKSM_UMAX_STEP(0x118, 0xf) TKSM_UMAX_STEP(0x142, 0xa) TKSM_UMAX_STEP(0x143, 0xc)
+#undef TKSM_UMAX_STEP
     return x;
 }
 // exclusive prefix sum over the wave of a small value (0..7) from three ballots: no cross-lane shuffles
@@ -356,43 +364,71 @@ struct AlnOut { int dist; uint32_t stat; };
 template <int MODE, bool TRACE, class OT>
 DEV AlnOut band_align(const uint8_t* F, int n, const uint8_t* N, const OT* owner, int m, int lane,
                       unsigned long long* trace) {
+    // One column per step; the step is a chain (previous column -> vertical propagation = a min-scan -> predecessor -> the
+    // statistics of the preferred path = a segmented copy), so its length is its latency: the column's symbol, window and fragment
+    // bytes are loaded one / two columns ahead, the previous column's cells come by a one-lane shift of the wave when the window
+    // moved by 0 or 1 rows (all but the columns behind a deleted slot), the scans are data-parallel-primitive moves, and the
+    // segmented copy is ONE unsigned max-scan of {source lane, value} packed into a word.  stat (matches << 16 | columns) is only
+    // produced without TRACE (the callers with a trace count along their walk), for windows of <= 1023 rows (the re-estimation
+    // windows have <= 1000): the value then fits the 26 bits the packing leaves it.
+    // Unreachable cells carry BIG (is_inf: >= 2^27); BIG + a few thousand is still unreachable and never equals a finite value, so
+    // the sums below need no guards, and every selection is a bitwise one (no branches inside the chain).
     int tp = 1;
     int H = 1 + lane;                         // column 0: H[i][0] = i
     uint32_t st = (uint32_t)(1 + lane);
+    auto top_at = [&](int j) { return max(1, (int)owner[j - 1] + 1 - 31); };
+    auto frag_at = [&](int t) { const int b = (int)F[max(min(t + lane, n) - 1, 0)]; return t + lane <= n ? b : 257; };
+    int t1 = m >= 1 ? top_at(1) : 1, nc1 = m >= 1 ? (int)N[0] : 0;
+    int fc1 = frag_at(t1);
+    int t2 = m >= 2 ? top_at(2) : 1, nc2 = m >= 2 ? (int)N[1] : 0;
     for (int j = 1; j <= m; j++) {
-        const int g = (int)owner[j - 1] + 1;
-        const int t = max(1, g - 31);
-        const int sh = t - tp;
-        const int nc = N[j - 1];
-        const int i = t + lane;
-        const bool valid = i <= n;
-        const int fc = valid ? (int)F[i - 1] : 257;
-        const int match = fc == nc;
+        const int t = __builtin_amdgcn_readfirstlane(t1);
+        const int nc = nc1, fc = fc1;
+        t1 = t2; nc1 = nc2;
+        fc1 = frag_at(t1);
+        { const int j2 = min(j + 2, m); t2 = top_at(j2); nc2 = (int)N[j2 - 1]; }
+        const int sh = t - tp;                                  // (wave-uniform)
+        const bool valid = t + lane <= n;
+        const int match = fc == nc ? 1 : 0;
         // previous column at rows i-1 (diag) and i (left)
-        const int ld = lane + sh - 1, ll = lane + sh;
-        const int hbot = __shfl(H, 63, 64); const uint32_t sbot = __shfl(st, 63, 64);
-        int hd = __shfl(H, ld & 63, 64); uint32_t sd = __shfl(st, ld & 63, 64);
-        int hl = __shfl(H, ll & 63, 64); uint32_t sl = __shfl(st, ll & 63, 64);
-        if (ld > 63) { hd = is_inf(hbot) ? BIG : hbot + (ld - 63); sd = sbot + (uint32_t)(ld - 63); }
-        else if (ld < 0) { if (tp == 1) { hd = j - 1; sd = (uint32_t)(j - 1); } else hd = BIG; }
-        if (ll > 63) { hl = is_inf(hbot) ? BIG : hbot + (ll - 63); sl = sbot + (uint32_t)(ll - 63); }
-        const int vd = !is_inf(hd) ? hd + 1 - match : BIG;
-        const int vl = !is_inf(hl) ? hl + 1 : BIG;
+        int hd, hl; uint32_t sd, sl;
+        if (sh == 1) {
+            // diag = the same lane; left = the lane above, for lane 63 the virtual cell below the previous window
+            hd = H; sd = st;
+            hl = dpp_mov<DPP_WAVE_SHL1, 0xf>(H + 1, H);
+            sl = (uint32_t)dpp_mov<DPP_WAVE_SHL1, 0xf>((int)(st + 1u), (int)st);
+        } else if (sh == 0) {
+            // left = the same lane; diag = the lane below, for lane 0 the boundary row 0 (H[0][j-1] = j-1) while the window is at row 1
+            hl = H; sl = st;
+            hd = dpp_mov<DPP_WAVE_SHR1, 0xf>(tp == 1 ? j - 1 : BIG, H);
+            sd = (uint32_t)dpp_mov<DPP_WAVE_SHR1, 0xf>(j - 1, (int)st);
+        } else {
+            const int ld = lane + sh - 1, ll = lane + sh;
+            const int hbot = __builtin_amdgcn_readlane(H, 63); const uint32_t sbot = (uint32_t)__builtin_amdgcn_readlane((int)st, 63);
+            hd = __shfl(H, ld & 63, 64); sd = __shfl(st, ld & 63, 64);
+            hl = __shfl(H, ll & 63, 64); sl = __shfl(st, ll & 63, 64);
+            if (ld > 63) { hd = hbot + (ld - 63); sd = sbot + (uint32_t)(ld - 63); }
+            if (ll > 63) { hl = hbot + (ll - 63); sl = sbot + (uint32_t)(ll - 63); }
+        }
+        const int vd = hd + 1 - match, vl = hl + 1;
         const int vu0 = (lane == 0 && t == 1) ? j + 1 : BIG;      // boundary row 0 above lane 0
         const int tmin = valid ? min(min(vd, vl), vu0) : BIG;
         const int x = scan_min_incl(tmin - lane, lane) + lane;
-        const int h = (valid && !is_inf(x)) ? x : BIG;
-        int hup = __shfl_up(h, 1, 64);
-        if (lane == 0) hup = BIG;
-        const bool ok = !is_inf(h);
-        const bool upok = ok && (lane == 0 ? vu0 == h : (!is_inf(hup) && hup + 1 == h));
-        const bool leftok = ok && vl == h;
-        const int take = MODE == 0 ? (upok ? 0 : (leftok ? 1 : 2)) : (leftok ? 1 : (upok ? 0 : 2));
-        const bool base = take != 0 || lane == 0;
-        const uint32_t sb = take == 0 ? (uint32_t)(j + 1) : (take == 1 ? sl + 1u : sd + ((uint32_t)match << 16) + 1u);
-        const int srcl = scan_max_incl(base ? lane : -1, lane);
-        const uint32_t ss = __shfl(sb, srcl & 63, 64);
-        st = base ? sb : ss + (uint32_t)(lane - srcl);
+        const bool ok = valid & !is_inf(x);
+        const int h = ok ? x : BIG;
+        // the cell above: lane 0 has the boundary row 0 (value j) while the window is at row 1
+        const int hup = dpp_mov<DPP_WAVE_SHR1, 0xf>(t == 1 ? j : BIG, h);
+        const bool upok = ok & (hup + 1 == h);
+        const bool leftok = ok & (vl == h);
+        if (!TRACE) {
+            const bool up_taken = MODE == 0 ? upok : (upok & !leftok), left_taken = MODE == 0 ? (leftok & !upok) : leftok;
+            const bool base = !up_taken | (lane == 0);
+            const uint32_t sb = up_taken ? (uint32_t)(j + 1) : (left_taken ? sl + 1u : sd + ((uint32_t)match << 16) + 1u);
+            // a run of up moves copies the statistics of the cell below the run, + 1 column per row: the nearest base lane at or
+            // below each lane and its value, by one max-scan of lane << 26 | value
+            const uint32_t km = scan_umax_incl(base ? ((uint32_t)lane << 26) | (sb & 0x3ffffffu) : 0u);
+            st = base ? sb : (km & 0x3ffffffu) + (uint32_t)(lane - (int)(km >> 26));
+        }
         H = h; tp = t;
         if (TRACE) {
             const unsigned long long um = __ballot(upok), lm = __ballot(leftok);
@@ -402,7 +438,7 @@ DEV AlnOut band_align(const uint8_t* F, int n, const uint8_t* N, const OT* owner
     AlnOut o;
     const int bf = n - tp;
     if (bf < 0 || bf > 63) { o.dist = BIG; o.stat = 0; return o; }
-    o.dist = __shfl(H, bf, 64); o.stat = __shfl(st, bf, 64);
+    o.dist = __builtin_amdgcn_readlane(H, bf); o.stat = TRACE ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)st, bf);
     return o;
 }
 
@@ -1473,9 +1509,37 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
 // the draws that change something (~12 of 64) are then applied in draw order by the whole wave, on the read's slot codes staged
 // in LDS (every applied slot is also written through to HBM).  What follows a stop (re-estimation point, end of the loop) is
 // dropped and drawn again on the next visit, exactly as in k_loop: same draws, same order, same state records.
+// TAIL (k_tail, the last rounds of a batch): the wave does not hand its read back at a re-estimation point -- it aligns the window
+// itself (band_align, one lane per band row: ~0.1 us per column against the ~0.45 us of a lone lane-per-job wave) and goes on
+// with the read's next visit, until the read's loop has ended: the stragglers of a batch (reads with a low target identity need
+// two to three times the visits of the average read) finish in ONE launch instead of one host round trip + three latency-bound
+// launches per visit.  Same draws, same windows, same preference: band_align is the alignment of the byte-exact kernel.  A window
+// with more columns than the wave's LDS holds (TAIL_WCAP) takes the regular route (job, k_alnf) for that visit.
+constexpr int TAIL_WCAP = 2048, TAIL_FCAP = 1024;
+DEV int join_window_planar(const uint16_t* nbl, int p0, int n, uint8_t* N, uint16_t* owner, int ncap, int lane) {
+    int base = 0;
+    for (int q = 0; q < n; q += 64) {
+        const int p = q + lane;
+        uint32_t code = 0; int len = 0;
+        if (p < n) { code = nbl[p0 + p]; len = (int)((code >> 12) & 7u); }
+        int total;
+        const int off = base + prefix_small(len, total);
+        if (off + len <= ncap)
+            for (int x2 = 0; x2 < len; x2++) {
+                N[off + x2] = (uint8_t)(((code >> x2) & 1u) | (((code >> (5 + x2)) & 1u) << 1));     // 2-bit code, as st_frag has the fragment (band_align compares for equality only)
+                owner[off + x2] = (uint16_t)p;
+            }
+        base += total;
+    }
+    return base;
+}
+template <bool TAIL>
 __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
-                                               uint32_t begin, uint32_t count, int from_jobs, uint32_t c0, uint32_t c1) {
+                                               uint32_t begin, uint32_t count, int from_jobs, uint32_t c0, uint32_t c1, int lcap) {
     uint16_t* nbl = reinterpret_cast<uint16_t*>(lds_raw);     // [lcap] slot codes of the read
+    uint8_t* Fw = lds_raw + (((size_t)lcap * 2 + 16 + 15) & ~(size_t)15);   // TAIL: [TAIL_FCAP] fragment bytes of the window | N [TAIL_WCAP] | owner [TAIL_WCAP] u16
+    uint8_t* Nw = Fw + TAIL_FCAP;
+    uint16_t* ownw = reinterpret_cast<uint16_t*>(Nw + TAIL_WCAP);
     const int lane = threadIdx.x;
     const uint32_t widx = blockIdx.x;
     if (widx >= count) return;
@@ -1532,6 +1596,10 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     int cc25 = change_count % 25;
     enum { RUN = 0, NEED_ALN = 1, DONE = 2 };
     int st = RUN;
+    int st_aligns = S.st_aligns;
+    const uint8_t* gfrag = frag_row(FB, r);
+    if (TAIL && L <= 1000) { for (int t = lane; t < L; t += 64) Fw[t] = gfrag[t]; }     // (a longer fragment: the window of each alignment)
+  for (;;) {
     while (st == RUN) {
         double est_cur = est_keep;
         if (resume_j == 0) {
@@ -1629,9 +1697,40 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
         if (dead) { st = DONE; st_draws = (int)loop_limit; break; }
         n += 64u;
     }
+    if (!TAIL || st != NEED_ALN) break;
+    // ---- TAIL: the re-estimation alignment (py/tksm_badread.py:405-432) on this wave, then the next visit
+    {
+        int p0 = 0, nrows = L;
+        if (L > 1000) {
+            p0 = (int)__umulhi(philox(P.seed, g, ST_ALNPOS, aln_no).x, (uint32_t)(L - 1000 + 1));
+            nrows = 1000;
+            wave_sync();
+            for (int t = lane; t < nrows; t += 64) Fw[t] = gfrag[p0 + t];
+        }
+        wave_sync();
+        const int m = join_window_planar(nbl, p0, nrows, Nw, ownw, TAIL_WCAP, lane);
+        wave_sync();
+        if (m > TAIL_WCAP) break;                              // (the regular route for this visit: st stays NEED_ALN)
+        const AlnOut a = band_align<0, false>(Fw, nrows, Nw, ownw, m, lane, nullptr);
+        st_aligns++;
+        if (is_inf(a.dist)) {                                  // outside the band representation: the byte-exact kernel takes the read
+            go_slow(FB, r, lane, 0);
+            return;
+        }
+        const int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
+        const double ident = cols ? (double)mt / (double)cols : 0.0;
+        if (L <= 1000) errors = (1.0 - ident) * frag_len;
+        else {
+            const double estimated = (1.0 - ident) * frag_len;
+            const double weight = 1000.0 / frag_len;
+            errors = estimated * weight + errors * (1.0 - weight);
+        }
+        aln_no++;
+        st = RUN;
+    }
+  }
     // ---- as at the end of k_loop: a read at a re-estimation point gets an alignment job, one whose loop has ended waits (stage 3)
     if (lane == 0) {
-        int st_aligns = S.st_aligns;
         uint32_t job = 0;
         if (st == NEED_ALN) {
             job = FB.base_cur[rc] + atomicAdd(&FB.job_cnt[rc * 32u], 1u);
@@ -2823,7 +2922,14 @@ hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuf
 hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                         uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(k_loopw, dim3(count), dim3(64), (size_t)lcap * 2 + 16, s, em, p, fb, order, begin, count, from_jobs, c0, c1);
+    hipLaunchKernelGGL(k_loopw<false>, dim3(count), dim3(64), (size_t)lcap * 2 + 16, s, em, p, fb, order, begin, count, from_jobs, c0, c1, lcap);
+    return hipGetLastError();
+}
+size_t tail_lds_bytes(int lcap) { return (((size_t)lcap * 2 + 16 + 15) & ~(size_t)15) + TAIL_FCAP + TAIL_WCAP * 3; }
+hipError_t launch_tail(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
+                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_loopw<true>, dim3(count), dim3(64), tail_lds_bytes(lcap), s, em, p, fb, order, begin, count, from_jobs, c0, c1, lcap);
     return hipGetLastError();
 }
 hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s) {
