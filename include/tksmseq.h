@@ -27,6 +27,8 @@
  *                          14-row pass + redo list)
  *   TKSMSEQ_SMALL_ROUND=N  (round 1's launch grouping; kept for the tests) rounds below N reads are launched merged (default 16384)
  *   TKSMSEQ_WAVE_LOOP=N    rounds with at most N reads left run the error loop one wave per read (k_loopw; default 16384, 0: never)
+ *   TKSMSEQ_TAIL_WAVE=N    once at most N reads are left (and each can have a wave of its own at once) they finish in ONE launch that runs
+ *                          every remaining visit of a read on one wave, alignments included (k_loopw<true>; default 4096, 0: never)
  *   TKSMSEQ_ALN_LDS_PAD=B  bytes of LDS the 14-row alignment pass asks for without using them: caps its waves per CU (default 0)
  *   TKSMSEQ_HBM_STATE_LEN=L fragments longer than L are edited in HBM by the last visit instead of being staged in LDS (default 2304)
  *   TKSMSEQ_DEFER_LEN=L    reads longer than L wait with their q-score alignment until the regular rounds are over (default 0: all)
@@ -34,7 +36,8 @@
  *   TKSMSEQ_TAIL_CUT=N     diagnostic: once fewer than N reads are left, they finish in the wave-wide kernel (default 0: off)
  *   TKSMSEQ_FULL_POOL_MB=M memory for the unbanded alignment fallback of the wave-wide kernel (default 1024)
  *   TKSMSEQ_PIECE_BYTES=B  (CLI) size of the page-locked pieces a batch's records pass through (default 64 MB; the tests use 4 KB)
- *   TKSMSEQ_ABLATE=N       only in the diagnostic build (`make ablate`, -DTKSM_ABLATE): early-return points for timing experiments
+ *   TKSMSEQ_ABLATE=N       only in the diagnostic build (`make ablate`, -DTKSM_ABLATE): timing experiments on the last visit's q-score loop
+ *                          (40 - 45, tools/ablate_err.sh) and k_loop's prologue (33)
  *   GPU_MAX_HW_QUEUES      (HIP runtime) the CLI and bench.py set 16 when unset: a hardware queue per context in flight -- INTEGRATION.md
  */
 #ifndef TKSMSEQ_H

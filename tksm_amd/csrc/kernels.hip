@@ -1516,12 +1516,19 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
 // launches per visit.  Same draws, same windows, same preference: band_align is the alignment of the byte-exact kernel.  A window
 // with more columns than the wave's LDS holds (TAIL_WCAP) takes the regular route (job, k_alnf) for that visit.
 constexpr int TAIL_WCAP = 2048, TAIL_FCAP = 1024;
-DEV int join_window_planar(const uint16_t* nbl, int p0, int n, uint8_t* N, uint16_t* owner, int ncap, int lane) {
+__host__ __device__ inline size_t tail_bitmap_bytes(int lcap) { return ((size_t)((lcap + 63) / 64) * 8 + 16 + 15) & ~(size_t)15; }
+DEV int join_window_planar(const uint16_t* gnb, int p0, int n, uint8_t* N, uint16_t* owner, int ncap, int lane) {
+    // the window's slot codes come from the read's row in HBM, all groups of 64 requested before the first is used (n <= 1024)
+    uint32_t codes[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) codes[q] = 64 * q + lane < n ? (uint32_t)gnb[p0 + 64 * q + lane] : 0u;
     int base = 0;
-    for (int q = 0; q < n; q += 64) {
-        const int p = q + lane;
-        uint32_t code = 0; int len = 0;
-        if (p < n) { code = nbl[p0 + p]; len = (int)((code >> 12) & 7u); }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        if (64 * q >= n) break;
+        const int p = 64 * q + lane;
+        const uint32_t code = codes[q];
+        const int len = (int)((code >> 12) & 7u);              // (0 past the window)
         int total;
         const int off = base + prefix_small(len, total);
         if (off + len <= ncap)
@@ -1537,7 +1544,10 @@ template <bool TAIL>
 __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
                                                uint32_t begin, uint32_t count, int from_jobs, uint32_t c0, uint32_t c1, int lcap) {
     uint16_t* nbl = reinterpret_cast<uint16_t*>(lds_raw);     // [lcap] slot codes of the read
-    uint8_t* Fw = lds_raw + (((size_t)lcap * 2 + 16 + 15) & ~(size_t)15);   // TAIL: [TAIL_FCAP] fragment bytes of the window | N [TAIL_WCAP] | owner [TAIL_WCAP] u16
+    // TAIL: a bit per slot ("changed") instead of the codes -- the wave's LDS does not grow with the fragment, so the stragglers of
+    // a batch of long molecules all get a wave at once -- | [TAIL_FCAP] fragment bytes of the window | N [TAIL_WCAP] | owner [TAIL_WCAP] u16
+    uint32_t* bml = reinterpret_cast<uint32_t*>(lds_raw);
+    uint8_t* Fw = lds_raw + tail_bitmap_bytes(lcap);
     uint8_t* Nw = Fw + TAIL_FCAP;
     uint16_t* ownw = reinterpret_cast<uint16_t*>(Nw + TAIL_WCAP);
     const int lane = threadIdx.x;
@@ -1560,7 +1570,23 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     const int L = S.raw_len + 2 * k;
     const uint32_t* f2 = frag2_row(FB, r);
     uint16_t* gnb = nb_row(FB, r);
-    for (int t = 2 * lane; t < L; t += 128) *reinterpret_cast<uint32_t*>(nbl + t) = *reinterpret_cast<const uint32_t*>(gnb + t);   // (rows are padded to 8 slots)
+    if (!TAIL) {
+        for (int t = 2 * lane; t < L; t += 128) *reinterpret_cast<uint32_t*>(nbl + t) = *reinterpret_cast<const uint32_t*>(gnb + t);   // (rows are padded to 8 slots)
+    } else {
+        // 32 slots per lane and step (rows are padded to 64 slots, zero past the fragment): bit 15 of each code
+        for (int t = 32 * lane; t < L; t += 2048) {
+            const uint4* c4 = reinterpret_cast<const uint4*>(gnb + t);
+            uint32_t word = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = c4[q];
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) word |= (((w4[e] >> 15) & 1u) | ((w4[e] >> 31) << 1)) << (8 * q + 2 * e);
+            }
+            bml[t >> 5] = word;
+        }
+    }
     wave_sync();
     const uint64_t g = P.first_read + (uint64_t)r * P.stride;
     const double frag_len = (double)L, target = S.target;
@@ -1671,9 +1697,13 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
             while (dms) {
                 const int jj = __builtin_ctz(dms);
                 dms &= dms - 1u;
-                if ((nbl[ai + jj] & 0x8000u) == 0) {
+                const int ps = ai + jj;
+                if (TAIL ? ((bml[ps >> 5] >> (ps & 31)) & 1u) == 0u : (nbl[ps] & 0x8000u) == 0) {
                     const uint32_t e = draw_slot(As, jj);
-                    if (lane == 0) { nbl[ai + jj] = (uint16_t)(e | 0x8000u); gnb[ai + jj] = (uint16_t)(e | 0x8000u); }
+                    if (lane == 0) {
+                        if (TAIL) bml[ps >> 5] |= 1u << (ps & 31); else nbl[ps] = (uint16_t)(e | 0x8000u);
+                        gnb[ps] = (uint16_t)(e | 0x8000u);
+                    }
                     change_count++;
                     const int len_j = (int)((e >> 12) & 7u);
                     errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
@@ -1708,7 +1738,7 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
             for (int t = lane; t < nrows; t += 64) Fw[t] = gfrag[p0 + t];
         }
         wave_sync();
-        const int m = join_window_planar(nbl, p0, nrows, Nw, ownw, TAIL_WCAP, lane);
+        const int m = join_window_planar(gnb, p0, nrows, Nw, ownw, TAIL_WCAP, lane);
         wave_sync();
         if (m > TAIL_WCAP) break;                              // (the regular route for this visit: st stays NEED_ALN)
         const AlnOut a = band_align<0, false>(Fw, nrows, Nw, ownw, m, lane, nullptr);
@@ -2925,7 +2955,7 @@ hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBu
     hipLaunchKernelGGL(k_loopw<false>, dim3(count), dim3(64), (size_t)lcap * 2 + 16, s, em, p, fb, order, begin, count, from_jobs, c0, c1, lcap);
     return hipGetLastError();
 }
-size_t tail_lds_bytes(int lcap) { return (((size_t)lcap * 2 + 16 + 15) & ~(size_t)15) + TAIL_FCAP + TAIL_WCAP * 3; }
+size_t tail_lds_bytes(int lcap) { return tail_bitmap_bytes(lcap) + TAIL_FCAP + TAIL_WCAP * 3; }
 hipError_t launch_tail(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
