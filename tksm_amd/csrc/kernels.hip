@@ -1304,10 +1304,20 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                 const int di1 = (int)__umulhi(d.x, kmer_range);
                 dwv[b] = d.y;
                 const int w = di1 >> 4, o = di1 & 15;
+#ifdef TKSM_ABLATE
+                // timing experiments (results are wrong): 35 / 36: every k-mer from the words in LDS; 34 / 36: no first-level threshold gather
+                const bool abl_lds = P.ablate == 35 || P.ablate == 36, abl_t0 = P.ablate == 34 || P.ablate == 36;
+                const uint32_t hi = (abl_lds || w < Wl) ? lf[min(w, Wl - 1) * 64 + lane] : f2[w], lo = (abl_lds || w + 1 < Wl) ? lf[min(w + 1, Wl - 1) * 64 + lane] : f2[w + 1];
+#else
                 const uint32_t hi = w < Wl ? lf[w * 64 + lane] : f2[w], lo = w + 1 < Wl ? lf[(w + 1) * 64 + lane] : f2[w + 1];
+#endif
                 const uint32_t kx = (uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask;
                 ldi[b * 64 + lane] = (uint32_t)di1; lki[b * 64 + lane] = (uint16_t)kx;
+#ifdef TKSM_ABLATE
+                t0v[b] = abl_t0 ? 0xCF000000u : EM.pseg[kx].x;
+#else
                 t0v[b] = EM.pseg[kx].x;
+#endif
             }
 #pragma unroll
             for (int b = 0; b < LOOP_N; b++) {
@@ -2941,7 +2951,10 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
 // (L2).  Measured with three batches in flight (bench.py): 80 words / 6 draws at a time (20 KB, 228 VGPRs: 2 waves per SIMD)
 // 8.11 M reads/s; 48 / 4: 8.29 M; 32 / 4 (164 VGPRs: 3 waves per SIMD): 8.42 M; no LDS at all: 8.25 M; 2 draws at a time: 6.8 M
 constexpr int LOOP_WL_MAX = 32;
-int loop_lds_words(int lcap) { return std::min(LOOP_WL_MAX, (((lcap + 15) / 16 + 1) + 3) & ~3); }
+int loop_lds_words(int lcap) {
+    static const int wl_max = [] { const char* e = getenv("TKSMSEQ_LOOP_WL"); return e ? std::max(4, atoi(e) & ~3) : LOOP_WL_MAX; }();
+    return std::min(wl_max, (((lcap + 15) / 16 + 1) + 3) & ~3);
+}
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
