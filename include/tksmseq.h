@@ -29,6 +29,7 @@
  *   TKSMSEQ_WAVE_LOOP=N    rounds with at most N reads left run the error loop one wave per read (k_loopw; default 16384, 0: never)
  *   TKSMSEQ_TAIL_WAVE=N    once at most N reads are left (and each can have a wave of its own at once) they finish in ONE launch that runs
  *                          every remaining visit of a read on one wave, alignments included (k_loopw<true>; default 4096, 0: never)
+ *   TKSMSEQ_LOOP_WL=W      words (16 bases each) of a read's packed fragment that k_loop keeps in LDS per lane (default 64, multiple of 4)
  *   TKSMSEQ_ALN_LDS_PAD=B  bytes of LDS the 14-row alignment pass asks for without using them: caps its waves per CU (default 0)
  *   TKSMSEQ_HBM_STATE_LEN=L fragments longer than L are edited in HBM by the last visit instead of being staged in LDS (default 2304)
  *   TKSMSEQ_DEFER_LEN=L    reads longer than L wait with their q-score alignment until the regular rounds are over (default 0: all)

@@ -2950,7 +2950,9 @@ hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelV
 // fragment words per lane kept in LDS: at most LOOP_WL_MAX words (512 bases, 8 KB per wave); the words beyond come from HBM
 // (L2).  Measured with three batches in flight (bench.py): 80 words / 6 draws at a time (20 KB, 228 VGPRs: 2 waves per SIMD)
 // 8.11 M reads/s; 48 / 4: 8.29 M; 32 / 4 (164 VGPRs: 3 waves per SIMD): 8.42 M; no LDS at all: 8.25 M; 2 draws at a time: 6.8 M
-constexpr int LOOP_WL_MAX = 32;
+// round 3 (16-draw passes): what the first phase pays for is its gather instructions, and the k-mers past the part in LDS are 22 % of
+// the kernel (tools/ablate_loop.sh); 64 words (1024 bases, 22 KB per wave, 7 waves per CU): 31.2 -> 29.3 ms per 1.31 M reads, 96: 32.0
+constexpr int LOOP_WL_MAX = 64;
 int loop_lds_words(int lcap) {
     static const int wl_max = [] { const char* e = getenv("TKSMSEQ_LOOP_WL"); return e ? std::max(4, atoi(e) & ~3) : LOOP_WL_MAX; }();
     return std::min(wl_max, (((lcap + 15) / 16 + 1) + 3) & ~3);
