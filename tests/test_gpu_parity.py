@@ -128,7 +128,7 @@ def _make_molecules(rs, ref, n, mean_len, literal=True):
     return mols
 
 
-@pytest.mark.parametrize("path", ["fast", "fast-hbm", "fast-small", "slow"])
+@pytest.mark.parametrize("path", ["fast", "fast-hbm", "fast-small", "fast-tail", "fast-tail-narrow", "slow"])
 @pytest.mark.parametrize("mean_len,n,compute_q", [(300, 96, True), (1000, 64, True), (1000, 32, False), (2600, 24, True), (9000, 6, True)])
 def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n, compute_q, path):
     """whole records of the stochastic path, GPU vs oracle, same (seed, read index).  mean_len 2600 exercises
@@ -136,8 +136,15 @@ def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n
     run: k_loop (one lane per read) in every round, k_aln with 16 stored rows and its 64-row follow-up pass, k_err per length
     bucket (reads touching N / IUPAC bytes still take the wave-wide kernel); "fast-hbm" = the same with k_err's long-read variant for
     every length; "fast-small" = the latency-bound variants small rounds switch to (k_loopw: one wave per read; every alignment with
-    all 64 rows stored; one k_err launch); "slow" = wave-wide kernel for all."""
+    all 64 rows stored; one k_err launch); "fast-tail" = the default knobs, with which a batch this small is handed to the straggler
+    kernel after its first round (k_loopw<true>: every later visit of a read on one wave, alignments by band_align on the wave);
+    "fast-tail-narrow" = the same with room for 700 columns on the wave, so that wider windows take the regular route (job, k_alnf)
+    for that visit and the straggler kernel picks the read up again in the next round; "slow" = wave-wide kernel for all."""
     monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
+    if not path.startswith("fast-tail"):
+        monkeypatch.setenv("TKSMSEQ_TAIL_WAVE", "0")
+    if path == "fast-tail-narrow":
+        monkeypatch.setenv("TKSMSEQ_TAIL_WCAP", "700")
     if path in ("fast", "fast-hbm"):
         monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_TAIL_CUT", "0")
         monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0")
@@ -258,7 +265,7 @@ def test_full_size_properties_and_shard_invariance():
     # wave-wide kernel do not change a byte
     with pytest.MonkeyPatch.context() as mp:
         mp.setenv("TKSMSEQ_SMALL_ALN", str(1 << 30)); mp.setenv("TKSMSEQ_SMALL_ROUND", str(1 << 30)); mp.setenv("TKSMSEQ_TAIL_CUT", "0")
-        mp.setenv("TKSMSEQ_WAVE_LOOP", "0")
+        mp.setenv("TKSMSEQ_WAVE_LOOP", "0"); mp.setenv("TKSMSEQ_TAIL_WAVE", "0")
         s3 = Sequencer(0)
     setup(s3)
     b3 = s3.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
@@ -537,7 +544,7 @@ def test_tail_noise_bit_exact_vs_oracle(oracle_models, po, monkeypatch, path):
     same batch rebuilds the batch's lengths and order; symbols outside ACGT in `bases` take the wave-wide kernel."""
     monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "1" if path == "slow" else "0")
     if path == "fast":
-        monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0")
+        monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0"); monkeypatch.setenv("TKSMSEQ_TAIL_WAVE", "0")
     import json
     s, ref, rs = _random_genome_seqr()
     s.set_identity(84.0, 99.0, 5.5)
@@ -683,7 +690,7 @@ def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_mode
     and --perfect): `pcr` = substitution-heavy molecules as 20 PCR cycles leave them (BASELINE config 5: ~5 substitutions per kb,
     both strands, interval ends), `scrna` = barcode + UMI + polyA literal segments (config 3).  Run as the large rounds of a large
     batch are (k_loop in every round; 16 stored rows per alignment: 5 % of the polyA-tailed jobs go on to the 64-row pass)."""
-    monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0")
+    monkeypatch.setenv("TKSMSEQ_SMALL_ALN", "0"); monkeypatch.setenv("TKSMSEQ_SMALL_ROUND", "0"); monkeypatch.setenv("TKSMSEQ_WAVE_LOOP", "0"); monkeypatch.setenv("TKSMSEQ_TAIL_WAVE", "0")
     from tksm_amd import synthetic
     rs = np.random.RandomState(17)
     lens = [200_000, 150_000]

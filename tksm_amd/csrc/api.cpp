@@ -45,6 +45,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_SMALL_ALN")) c->small_aln = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_WAVE_LOOP")) c->wave_loop = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_TAIL_WAVE")) c->tail_wave = (uint32_t)atoi(tc);
+    if (const char* tc = getenv("TKSMSEQ_TAIL_WCAP")) c->tail_wcap = atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_ALN_LDS_PAD")) c->aln_lds_pad = (unsigned)std::min(60000, std::max(0, atoi(tc)));
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
@@ -932,7 +933,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 // later: the reads of the previous round's jobs), then this round's jobs packed for k_aln, one lane each
                 if (rounds == 0) HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, (uint32_t)n, lcap, 0, 0, 0, s));
                 else if (hprefix[FB.n_ranges] <= std::min<uint64_t>(ctx->tail_wave, tail_slots) && tk::tail_lds_bytes(lcap) <= 65536)    // the stragglers: every remaining visit in this launch
-                    HIPCHK(ctx, tk::launch_tail(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
+                    HIPCHK(ctx, tk::launch_tail(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, ctx->tail_wcap, s));
                 else if (hprefix[FB.n_ranges] <= ctx->wave_loop && lcap <= 32768)        // few reads left: a wave each (latency)
                     HIPCHK(ctx, tk::launch_loopw(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));
                 else HIPCHK(ctx, tk::launch_loop(EM, P, FB, b->d_order.as<uint32_t>(), 0, hprefix[FB.n_ranges], lcap, 1, 0, FB.n_ranges, s));

@@ -125,6 +125,7 @@ struct tksmseq_ctx : ContigLookup {
     uint8_t* h_geo = nullptr; size_t h_geo_bytes = 0;
     bool force_slow = false;
     uint32_t tail_cut = 0;   // > 0: hand the last reads of a batch to the wave-wide kernel (diagnostic)
+    int tail_wcap = 2048;                 // columns of a re-estimation window the straggler kernel aligns itself (its LDS holds 2048; smaller: tests)
     uint32_t tail_wave = 4096;            // rounds with at most this many reads left: one launch that runs every remaining visit of a read on a wave of its own (k_loopw<true>); 0: never
     uint32_t wave_loop = 16384;           // rounds with at most this many reads left run the error loop one wave per read (k_loopw)
     unsigned aln_lds_pad = 0;             // LDS the first alignment pass asks for without using it: caps its waves per CU (kernels.hip launch_aln)

@@ -199,7 +199,7 @@ hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBu
                         uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
 // the same visits, and every later visit of the read, on one wave (k_loopw<true>: the alignments by band_align on the wave)
 hipError_t launch_tail(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
-                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
+                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, int wcap, hipStream_t s);
 size_t tail_lds_bytes(int lcap);
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);

@@ -1552,7 +1552,7 @@ DEV int join_window_planar(const uint16_t* gnb, int p0, int n, uint8_t* N, uint1
 }
 template <bool TAIL>
 __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
-                                               uint32_t begin, uint32_t count, int from_jobs, uint32_t c0, uint32_t c1, int lcap) {
+                                               uint32_t begin, uint32_t count, int from_jobs, uint32_t c0, uint32_t c1, int lcap, int wcap) {
     uint16_t* nbl = reinterpret_cast<uint16_t*>(lds_raw);     // [lcap] slot codes of the read
     // TAIL: a bit per slot ("changed") instead of the codes -- the wave's LDS does not grow with the fragment, so the stragglers of
     // a batch of long molecules all get a wave at once -- | [TAIL_FCAP] fragment bytes of the window | N [TAIL_WCAP] | owner [TAIL_WCAP] u16
@@ -1748,9 +1748,9 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
             for (int t = lane; t < nrows; t += 64) Fw[t] = gfrag[p0 + t];
         }
         wave_sync();
-        const int m = join_window_planar(gnb, p0, nrows, Nw, ownw, TAIL_WCAP, lane);
+        const int m = join_window_planar(gnb, p0, nrows, Nw, ownw, wcap, lane);
         wave_sync();
-        if (m > TAIL_WCAP) break;                              // (the regular route for this visit: st stays NEED_ALN)
+        if (m > wcap) break;                              // (the regular route for this visit: st stays NEED_ALN)
         const AlnOut a = band_align<0, false>(Fw, nrows, Nw, ownw, m, lane, nullptr);
         st_aligns++;
         if (is_inf(a.dist)) {                                  // outside the band representation: the byte-exact kernel takes the read
@@ -2967,14 +2967,14 @@ hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuf
 hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                         uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(k_loopw<false>, dim3(count), dim3(64), (size_t)lcap * 2 + 16, s, em, p, fb, order, begin, count, from_jobs, c0, c1, lcap);
+    hipLaunchKernelGGL(k_loopw<false>, dim3(count), dim3(64), (size_t)lcap * 2 + 16, s, em, p, fb, order, begin, count, from_jobs, c0, c1, lcap, 0);
     return hipGetLastError();
 }
 size_t tail_lds_bytes(int lcap) { return tail_bitmap_bytes(lcap) + TAIL_FCAP + TAIL_WCAP * 3; }
 hipError_t launch_tail(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
-                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
+                       uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, int wcap, hipStream_t s) {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(k_loopw<true>, dim3(count), dim3(64), tail_lds_bytes(lcap), s, em, p, fb, order, begin, count, from_jobs, c0, c1, lcap);
+    hipLaunchKernelGGL(k_loopw<true>, dim3(count), dim3(64), tail_lds_bytes(lcap), s, em, p, fb, order, begin, count, from_jobs, c0, c1, lcap, std::min(std::max(wcap, 1), TAIL_WCAP));
     return hipGetLastError();
 }
 hipError_t launch_qjobs(const FastBuffers& fb, int k, uint32_t count, hipStream_t s) {
