@@ -1635,140 +1635,140 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     int st_aligns = S.st_aligns;
     const uint8_t* gfrag = frag_row(FB, r);
     if (TAIL && L <= 1000) { for (int t = lane; t < L; t += 64) Fw[t] = gfrag[t]; }     // (a longer fragment: the window of each alignment)
-  for (;;) {
-    while (st == RUN) {
-        double est_cur = est_keep;
-        if (resume_j == 0) {
-            // stop rules at the top of an iteration (:353-367)
-            est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
-            if ((double)change_count > 0.9 * frag_len || est_cur <= target) { st = DONE; st_draws = (int)n; break; }
-        }
-        // ---- 64 draws: lane l takes draw n + l
-        const uint32_t nl = n + (uint32_t)lane;
-        const bool live = (long long)nl + 1 <= loop_limit;
-        const Ph4 d = philox(P.seed, g, ST_DRAW, nl);
-        const int di = (int)__umulhi(d.x, kmer_range);
-        const int w = di >> 4, o = di & 15;
-        const int kidx = (int)((uint32_t)(mk64(f2[w], f2[w + 1]) >> (64 - 2 * o - 2 * k)) & kmask);
-        const uint4 seg = EM.pseg[kidx];
-        const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
-        int cls = EM.type == 0 ? 2 : (d.y < seg.x ? (EM.alt0_noop ? 0 : 3) : 1);     // 0 no-op, 1 alternative a, 2 random change, 3 alternative 0
-        const int sbase = 8 * ((d.y < seg.y ? 0 : 1) + (d.y < seg.z ? 0 : 1) + (d.y < seg.w ? 0 : 1));
-        const uint4* c4 = reinterpret_cast<const uint4*>(EM.cdf32 + (cls == 1 ? (size_t)kidx * 32 + sbase : (size_t)0));
-        const uint4 th0 = c4[0], th1 = c4[1];
-        size_t at = 0;
-        if (cls == 1 || cls == 3) {
-            int a = 0;
-            if (cls == 1) {
-                const uint32_t wv = d.y;
-                a = sbase;
-                a += !(wv < th0.x) ? 1 : 0; a += !(wv < th0.y) ? 1 : 0; a += !(wv < th0.z) ? 1 : 0; a += !(wv < th0.w) ? 1 : 0;
-                a += !(wv < th1.x) ? 1 : 0; a += !(wv < th1.y) ? 1 : 0; a += !(wv < th1.z) ? 1 : 0; a += !(wv < th1.w) ? 1 : 0;
-                a = min(a, na);
+    for (;;) {                                               // (TAIL: one turn per visit of the read; else a single turn)
+        while (st == RUN) {
+            double est_cur = est_keep;
+            if (resume_j == 0) {
+                // stop rules at the top of an iteration (:353-367)
+                est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
+                if ((double)change_count > 0.9 * frag_len || est_cur <= target) { st = DONE; st_draws = (int)n; break; }
             }
-            if (a == na) cls = 2;                             // residual mass: add_one_random_change
-            else if (a == 0 && EM.alt0_noop) cls = 0;
-            else at = (size_t)kidx * EM.max_alts + a;
-        }
-        uint4 A = EM.alts_enc[at];
-        if (cls == 2) {
-            // add_one_random_change (:199-213), as in k_loop
-            const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
-            const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
-            const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
-            const uint32_t kc = ((uint32_t)kidx >> (2 * (k - 1 - (int)pos))) & 3u;
-            const uint32_t v = type == 0 ? 0x8000u | (1u << 12) | planar1((kc + r3) & 3u)
-                             : type == 1 ? 0x8000u | (2u << 12) | (side ? planar2(kc, base4) : planar2(base4, kc))
-                                         : 0x8000u;
-            const uint32_t wv = v << (16 * (pos & 1u)), which = pos >> 1;
-            A = make_uint4(which == 0 ? wv : 0u, which == 1 ? wv : 0u, which == 2 ? wv : 0u, which == 3 ? wv : 0u);
-        }
-        // the slots that differ from the original base (bit 15 of their encodings)
-        uint32_t dm = ((A.x >> 15) & 1u) | ((A.x >> 31) << 1) | (((A.y >> 15) & 1u) << 2) | ((A.y >> 31) << 3) |
-                      (((A.z >> 15) & 1u) << 4) | ((A.z >> 31) << 5) | (((A.w >> 15) & 1u) << 6) | ((A.w >> 31) << 7);
-        dm &= (1u << k) - 1u;
-        if (!live || cls == 0) dm = 0u;
-        unsigned long long mask = __ballot(dm != 0u);
-        const unsigned long long dead = __ballot(!live);
-        // ---- the draws that may change something, in draw order
-        while (mask) {
-            const int src = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const int ai = __builtin_amdgcn_readlane(di, src);
-            uint4 As;
-            As.x = (uint32_t)__builtin_amdgcn_readlane((int)A.x, src); As.y = (uint32_t)__builtin_amdgcn_readlane((int)A.y, src);
-            As.z = (uint32_t)__builtin_amdgcn_readlane((int)A.z, src); As.w = (uint32_t)__builtin_amdgcn_readlane((int)A.w, src);
-            uint32_t dms = (uint32_t)__builtin_amdgcn_readlane((int)dm, src);
-            double est = est_cur;
-            if (resume_j > 0) { dms &= ~((1u << resume_j) - 1u); est = est_keep; }      // (the first draw of the visit: lane 0)
-            // in slot order (:378-403): applied if the position is still pristine
-            const double f15 = est * sqrt_inrange(est);
-            int stop_at = -1;
-            while (dms) {
-                const int jj = __builtin_ctz(dms);
-                dms &= dms - 1u;
-                const int ps = ai + jj;
-                if (TAIL ? ((bml[ps >> 5] >> (ps & 31)) & 1u) == 0u : (nbl[ps] & 0x8000u) == 0) {
-                    const uint32_t e = draw_slot(As, jj);
-                    if (lane == 0) {
-                        if (TAIL) bml[ps >> 5] |= 1u << (ps & 31); else nbl[ps] = (uint16_t)(e | 0x8000u);
-                        gnb[ps] = (uint16_t)(e | 0x8000u);
-                    }
-                    change_count++;
-                    const int len_j = (int)((e >> 12) & 7u);
-                    errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
-                    if (++cc25 == 25) { cc25 = 0; stop_at = jj; break; }                  // ALIGNMENT_INTERVAL
+            // ---- 64 draws: lane l takes draw n + l
+            const uint32_t nl = n + (uint32_t)lane;
+            const bool live = (long long)nl + 1 <= loop_limit;
+            const Ph4 d = philox(P.seed, g, ST_DRAW, nl);
+            const int di = (int)__umulhi(d.x, kmer_range);
+            const int w = di >> 4, o = di & 15;
+            const int kidx = (int)((uint32_t)(mk64(f2[w], f2[w + 1]) >> (64 - 2 * o - 2 * k)) & kmask);
+            const uint4 seg = EM.pseg[kidx];
+            const int na = EM.uniform_nalts ? EM.max_alts : (int)EM.nalts[kidx];
+            int cls = EM.type == 0 ? 2 : (d.y < seg.x ? (EM.alt0_noop ? 0 : 3) : 1);     // 0 no-op, 1 alternative a, 2 random change, 3 alternative 0
+            const int sbase = 8 * ((d.y < seg.y ? 0 : 1) + (d.y < seg.z ? 0 : 1) + (d.y < seg.w ? 0 : 1));
+            const uint4* c4 = reinterpret_cast<const uint4*>(EM.cdf32 + (cls == 1 ? (size_t)kidx * 32 + sbase : (size_t)0));
+            const uint4 th0 = c4[0], th1 = c4[1];
+            size_t at = 0;
+            if (cls == 1 || cls == 3) {
+                int a = 0;
+                if (cls == 1) {
+                    const uint32_t wv = d.y;
+                    a = sbase;
+                    a += !(wv < th0.x) ? 1 : 0; a += !(wv < th0.y) ? 1 : 0; a += !(wv < th0.z) ? 1 : 0; a += !(wv < th0.w) ? 1 : 0;
+                    a += !(wv < th1.x) ? 1 : 0; a += !(wv < th1.y) ? 1 : 0; a += !(wv < th1.z) ? 1 : 0; a += !(wv < th1.w) ? 1 : 0;
+                    a = min(a, na);
                 }
+                if (a == na) cls = 2;                             // residual mass: add_one_random_change
+                else if (a == 0 && EM.alt0_noop) cls = 0;
+                else at = (size_t)kidx * EM.max_alts + a;
             }
-            wave_sync();
-            if (stop_at >= 0) {
-                st = NEED_ALN;
-                if (stop_at + 1 < k) { resume_j = stop_at + 1; est_keep = est; n += (uint32_t)src; }   // the rest of this draw follows the alignment
-                else { resume_j = 0; n += (uint32_t)src + 1u; }
-                break;
+            uint4 A = EM.alts_enc[at];
+            if (cls == 2) {
+                // add_one_random_change (:199-213), as in k_loop
+                const uint32_t type = __umulhi(d.z, 3u), pos = __umulhi(d.w, (uint32_t)k);
+                const uint32_t base4 = d.w & 3u, side = (d.w >> 2) & 1u;
+                const uint32_t r3 = (((d.z & 0xffffu) * 3u) >> 16) + 1u;
+                const uint32_t kc = ((uint32_t)kidx >> (2 * (k - 1 - (int)pos))) & 3u;
+                const uint32_t v = type == 0 ? 0x8000u | (1u << 12) | planar1((kc + r3) & 3u)
+                                 : type == 1 ? 0x8000u | (2u << 12) | (side ? planar2(kc, base4) : planar2(base4, kc))
+                                             : 0x8000u;
+                const uint32_t wv = v << (16 * (pos & 1u)), which = pos >> 1;
+                A = make_uint4(which == 0 ? wv : 0u, which == 1 ? wv : 0u, which == 2 ? wv : 0u, which == 3 ? wv : 0u);
             }
+            // the slots that differ from the original base (bit 15 of their encodings)
+            uint32_t dm = ((A.x >> 15) & 1u) | ((A.x >> 31) << 1) | (((A.y >> 15) & 1u) << 2) | ((A.y >> 31) << 3) |
+                          (((A.z >> 15) & 1u) << 4) | ((A.z >> 31) << 5) | (((A.w >> 15) & 1u) << 6) | ((A.w >> 31) << 7);
+            dm &= (1u << k) - 1u;
+            if (!live || cls == 0) dm = 0u;
+            unsigned long long mask = __ballot(dm != 0u);
+            const unsigned long long dead = __ballot(!live);
+            // ---- the draws that may change something, in draw order
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const int ai = __builtin_amdgcn_readlane(di, src);
+                uint4 As;
+                As.x = (uint32_t)__builtin_amdgcn_readlane((int)A.x, src); As.y = (uint32_t)__builtin_amdgcn_readlane((int)A.y, src);
+                As.z = (uint32_t)__builtin_amdgcn_readlane((int)A.z, src); As.w = (uint32_t)__builtin_amdgcn_readlane((int)A.w, src);
+                uint32_t dms = (uint32_t)__builtin_amdgcn_readlane((int)dm, src);
+                double est = est_cur;
+                if (resume_j > 0) { dms &= ~((1u << resume_j) - 1u); est = est_keep; }      // (the first draw of the visit: lane 0)
+                // in slot order (:378-403): applied if the position is still pristine
+                const double f15 = est * sqrt_inrange(est);
+                int stop_at = -1;
+                while (dms) {
+                    const int jj = __builtin_ctz(dms);
+                    dms &= dms - 1u;
+                    const int ps = ai + jj;
+                    if (TAIL ? ((bml[ps >> 5] >> (ps & 31)) & 1u) == 0u : (nbl[ps] & 0x8000u) == 0) {
+                        const uint32_t e = draw_slot(As, jj);
+                        if (lane == 0) {
+                            if (TAIL) bml[ps >> 5] |= 1u << (ps & 31); else nbl[ps] = (uint16_t)(e | 0x8000u);
+                            gnb[ps] = (uint16_t)(e | 0x8000u);
+                        }
+                        change_count++;
+                        const int len_j = (int)((e >> 12) & 7u);
+                        errors += (double)(len_j < 2 ? 1 : len_j - 1) * f15;
+                        if (++cc25 == 25) { cc25 = 0; stop_at = jj; break; }                  // ALIGNMENT_INTERVAL
+                    }
+                }
+                wave_sync();
+                if (stop_at >= 0) {
+                    st = NEED_ALN;
+                    if (stop_at + 1 < k) { resume_j = stop_at + 1; est_keep = est; n += (uint32_t)src; }   // the rest of this draw follows the alignment
+                    else { resume_j = 0; n += (uint32_t)src + 1u; }
+                    break;
+                }
+                resume_j = 0;
+                // the rules at the top of the next iteration
+                est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
+                if ((double)change_count > 0.9 * frag_len || est_cur <= target) { st = DONE; st_draws = (int)n + src + 1; break; }
+            }
+            if (st != RUN) break;
             resume_j = 0;
-            // the rules at the top of the next iteration
-            est_cur = 1.0 - div_inrange(errors, frag_len, rcp_len);
-            if ((double)change_count > 0.9 * frag_len || est_cur <= target) { st = DONE; st_draws = (int)n + src + 1; break; }
+            if (dead) { st = DONE; st_draws = (int)loop_limit; break; }
+            n += 64u;
         }
-        if (st != RUN) break;
-        resume_j = 0;
-        if (dead) { st = DONE; st_draws = (int)loop_limit; break; }
-        n += 64u;
-    }
-    if (!TAIL || st != NEED_ALN) break;
-    // ---- TAIL: the re-estimation alignment (py/tksm_badread.py:405-432) on this wave, then the next visit
-    {
-        int p0 = 0, nrows = L;
-        if (L > 1000) {
-            p0 = (int)__umulhi(philox(P.seed, g, ST_ALNPOS, aln_no).x, (uint32_t)(L - 1000 + 1));
-            nrows = 1000;
+        if (!TAIL || st != NEED_ALN) break;
+        // ---- TAIL: the re-estimation alignment (py/tksm_badread.py:405-432) on this wave, then the next visit
+        {
+            int p0 = 0, nrows = L;
+            if (L > 1000) {
+                p0 = (int)__umulhi(philox(P.seed, g, ST_ALNPOS, aln_no).x, (uint32_t)(L - 1000 + 1));
+                nrows = 1000;
+                wave_sync();
+                for (int t = lane; t < nrows; t += 64) Fw[t] = gfrag[p0 + t];
+            }
             wave_sync();
-            for (int t = lane; t < nrows; t += 64) Fw[t] = gfrag[p0 + t];
+            const int m = join_window_planar(gnb, p0, nrows, Nw, ownw, wcap, lane);
+            wave_sync();
+            if (m > wcap) break;                              // (the regular route for this visit: st stays NEED_ALN)
+            const AlnOut a = band_align<0, false>(Fw, nrows, Nw, ownw, m, lane, nullptr);
+            st_aligns++;
+            if (is_inf(a.dist)) {                                  // outside the band representation: the byte-exact kernel takes the read
+                go_slow(FB, r, lane, 0);
+                return;
+            }
+            const int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
+            const double ident = cols ? (double)mt / (double)cols : 0.0;
+            if (L <= 1000) errors = (1.0 - ident) * frag_len;
+            else {
+                const double estimated = (1.0 - ident) * frag_len;
+                const double weight = 1000.0 / frag_len;
+                errors = estimated * weight + errors * (1.0 - weight);
+            }
+            aln_no++;
+            st = RUN;
         }
-        wave_sync();
-        const int m = join_window_planar(gnb, p0, nrows, Nw, ownw, wcap, lane);
-        wave_sync();
-        if (m > wcap) break;                              // (the regular route for this visit: st stays NEED_ALN)
-        const AlnOut a = band_align<0, false>(Fw, nrows, Nw, ownw, m, lane, nullptr);
-        st_aligns++;
-        if (is_inf(a.dist)) {                                  // outside the band representation: the byte-exact kernel takes the read
-            go_slow(FB, r, lane, 0);
-            return;
-        }
-        const int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
-        const double ident = cols ? (double)mt / (double)cols : 0.0;
-        if (L <= 1000) errors = (1.0 - ident) * frag_len;
-        else {
-            const double estimated = (1.0 - ident) * frag_len;
-            const double weight = 1000.0 / frag_len;
-            errors = estimated * weight + errors * (1.0 - weight);
-        }
-        aln_no++;
-        st = RUN;
     }
-  }
     // ---- as at the end of k_loop: a read at a re-estimation point gets an alignment job, one whose loop has ended waits (stage 3)
     if (lane == 0) {
         uint32_t job = 0;
