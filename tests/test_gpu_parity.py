@@ -177,6 +177,38 @@ def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n
     s.close()
 
 
+def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_models, po, monkeypatch, capfd):
+    """a batch with a long tail of predicted visits (length x (1 - target identity) > 4 x the batch's median): those reads get their
+    straggler waves at round 0, on a stream of their own, and the regular rounds pass them by (api.cpp: predicted stragglers);
+    records and per-read statistics equal the oracle's whatever stream ran the read"""
+    monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "0"); monkeypatch.setenv("TKSMSEQ_EARLY_TAIL", "8"); monkeypatch.setenv("TKSMSEQ_VERBOSE", "1")
+    s, ref, rs = _random_genome_seqr()
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    mols = _make_molecules(rs, ref, 150, 300) + _make_molecules(rs, ref, 6, 5000)
+    mols = [(f"m{i}", ivs) for i, (_, ivs) in enumerate(mols)]
+    text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
+    batch = s.batch_from_mdf(text)
+    capfd.readouterr()
+    res = s.run(batch, target="badread", fastq=True, compute_qual=True, seed=SEED, first_read_index=77, stride=1, collect_stats=True)
+    err = capfd.readouterr().err
+    recs = res.records()
+    ist, dst = res.stats()
+    import re
+    got = re.search(r"predicted stragglers on their own stream: (\d+)", err)
+    assert got and 1 <= int(got.group(1)) <= 8, err[-600:]
+    ident = po.Identities(84.0, 5.5, 99.0)
+    em, qm = oracle_models["em"], oracle_models["qm"]
+    for i, (mid, ivs) in enumerate(mols):
+        raw = po.splice(ref, ivs)
+        want, st = po.badread_record(True, SEED, 77 + i, raw, ident, em, qm, True, mid)
+        assert (ist[i, 0], ist[i, 1], ist[i, 2]) == (st.n_draws, st.change_count, st.n_aligns), (i, ist[i, :8], st.n_draws, st.change_count, st.n_aligns)
+        assert dst[i, 0] == st.errors
+        assert recs[i] == want, (i, mid)
+    s.close()
+
+
 def test_cli_end_to_end_matches_goldens_and_oracle(tmp_path, po, oracle_models):
     """`tksm sequence` (the module boundary) on files: --perfect vs the reference CLI golden; -o vs the oracle with
     the CLI's seed; both outputs at once reproduce the reference's quirk (perfect file = badread sequence, quals K)."""

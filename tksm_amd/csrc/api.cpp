@@ -46,6 +46,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_WAVE_LOOP")) c->wave_loop = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_TAIL_WAVE")) c->tail_wave = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_TAIL_WCAP")) c->tail_wcap = atoi(tc);
+    if (const char* tc = getenv("TKSMSEQ_EARLY_TAIL")) c->early_tail = (uint32_t)std::min(4096, std::max(0, atoi(tc)));
     if (const char* tc = getenv("TKSMSEQ_ALN_LDS_PAD")) c->aln_lds_pad = (unsigned)std::min(60000, std::max(0, atoi(tc)));
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
@@ -110,6 +111,9 @@ void tksmseq_destroy(tksmseq_ctx* ctx) {
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->evpool) (void)hipEventDestroy(ev);
     for (auto& st : ctx->side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (ctx->early_stream) { (void)hipStreamSynchronize(ctx->early_stream); (void)hipStreamDestroy(ctx->early_stream); }
+    if (ctx->early_start) (void)hipEventDestroy(ctx->early_start);
+    if (ctx->early_done) (void)hipEventDestroy(ctx->early_done);
     for (auto& ev : ctx->side_done) if (ev) (void)hipEventDestroy(ev);
     if (ctx->side_start) (void)hipEventDestroy(ctx->side_start);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -775,6 +779,17 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         FB.redo_list = ctx->f_redo.as<uint32_t>();
         FB.trace_full = ctx->f_tracefull.p; FB.counters = reinterpret_cast<uint32_t*>(d_round + nrb);
         FB.slow_list = ctx->f_slow.as<uint32_t>();
+        // predicted stragglers (below): histogram of the reads' scores, their list, what they hand to the exact kernel
+        constexpr uint32_t EARLY_CAP = 4096;
+        const bool early_on = ctx->early_tail > 0 && ctx->tail_cut == 0 && ctx->tail_wave > 0 && tk::tail_lds_bytes(lcap) <= 65536 && n >= 16ull * ctx->early_tail;
+        FB.early_hist = nullptr; FB.early_list = nullptr; FB.early_slow = nullptr;
+        if (early_on) {
+            HIPCHK(ctx, ctx->f_early.ensure(65536 + (size_t)EARLY_CAP * 12 + 64));
+            FB.early_hist = ctx->f_early.as<uint32_t>();
+            FB.early_list = reinterpret_cast<uint2*>(ctx->f_early.as<uint8_t>() + 65536);
+            FB.early_slow = reinterpret_cast<uint32_t*>(ctx->f_early.as<uint8_t>() + 65536 + (size_t)EARLY_CAP * 8);
+            HIPCHK(ctx, hipMemsetAsync(ctx->f_early.p, 0, 65536, s));
+        }
         HIPCHK(ctx, ctx->f_defer.ensure(n * 8 + 64));
         HIPCHK(ctx, ctx->f_defercnt.ensure((size_t)FB.n_ranges * 128 + 64));
         FB.defer_list = ctx->f_defer.as<uint2>(); FB.defer_cnt = ctx->f_defercnt.as<uint32_t>(); FB.defer_len = ctx->defer_len;
@@ -883,9 +898,41 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             return TKSMSEQ_OK;
         };
         HIPCHK(ctx, hipMemcpyAsync(cnt, FB.counters, 64, hipMemcpyDeviceToHost, s));
+        std::vector<uint32_t> early_copies(early_on ? 64 * 256 : 0);
+        if (early_on) HIPCHK(ctx, hipMemcpyAsync(early_copies.data(), FB.early_hist, early_copies.size() * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
         mark("fragments spliced (k_init)");
         { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
+        // ---- predicted stragglers.  A read's visits are ~ 0.14 x length x (1 - target identity), known now.  In a batch whose
+        // distribution of that score has a long tail (skewed lengths), the reads at its end set the number of rounds and the length
+        // of the straggler launch: the top early_tail of them -- those that need > 4 x the median read's visits -- get their waves at
+        // once, on a stream of their own, and run underneath the regular rounds (which pass them by).
+        bool early_active = false, early_joined = false;
+        uint32_t n_early = 0;
+        if (early_on) {
+            uint32_t early_hist[256] = {};
+            for (size_t i = 0; i < early_copies.size(); i++) early_hist[i & 255] += early_copies[i];
+            uint64_t total = 0; for (uint32_t v : early_hist) total += v;
+            uint64_t acc = 0; int median_bin = 0;
+            for (int bb = 0; bb < 256; bb++) { acc += early_hist[bb]; if (2 * acc >= total) { median_bin = bb; break; } }
+            int min_bin = 256; uint64_t top = 0;
+            while (min_bin > median_bin + 16 && top + early_hist[min_bin - 1] <= ctx->early_tail) { min_bin--; top += early_hist[min_bin]; }   // 8 bins per factor of two: 16 bins = 4 x
+            if (top > 0) {
+                if (!ctx->early_stream) {
+                    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
+                    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->early_start, hipEventDisableTiming));
+                    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->early_done, hipEventDisableTiming));
+                }
+                n_early = (uint32_t)top;
+                HIPCHK(ctx, tk::launch_mark_early(FB, b->d_order.as<uint32_t>(), n, k, (uint32_t)min_bin, s));
+                HIPCHK(ctx, hipEventRecord(ctx->early_start, s));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->early_stream, ctx->early_start, 0));
+                HIPCHK(ctx, tk::launch_tail_early(EM, P, FB, n_early, lcap, ctx->tail_wcap, ctx->early_stream));
+                HIPCHK(ctx, hipEventRecord(ctx->early_done, ctx->early_stream));
+                early_active = true;
+            }
+        }
+        ctx->last_early = n_early;
         uint32_t rounds = 0, n_deferred = 0;
         bool revive = false, revived = false;
         // waves of the straggler kernel the device holds at once (its LDS per wave grows with the longest fragment of the batch): it
@@ -959,6 +1006,16 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             const bool stream_idle = !ctx->side_used[k_next] || hipEventQuery(ctx->side_done[k_next]) == hipSuccess;
             if ((pending >= 128 && (stream_idle || pending >= 2048)) || (pending && late && !late_flushed)) { const int rc2 = launch_side(cnt[2]); if (rc2) return rc2; }
             late_flushed = late_flushed || late;
+            if (cnt[0] == 0 && early_active && !early_joined) {
+                // the regular rounds are over: wait for the early reads' kernel, take over what it left for the exact kernel, and look
+                // at the counters again (deferred reads, slow list)
+                HIPCHK(ctx, hipEventSynchronize(ctx->early_done));
+                HIPCHK(ctx, tk::launch_merge_early_slow(FB, s));
+                HIPCHK(ctx, hipMemcpyAsync(cnt, FB.counters, 64, hipMemcpyDeviceToHost, s));
+                HIPCHK(ctx, hipStreamSynchronize(s));
+                cnt[0] = 0;
+                early_joined = true;
+            }
             if (cnt[0] == 0) {
                 if (cnt[1] == 0 || revived) break;
                 // every other read is done: job slots for the deferred reads (per-range counts), then their rounds
@@ -1006,8 +1063,8 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             uint32_t cc[32];
             HIPCHK(ctx, hipMemcpy(cc, FB.counters, 128, hipMemcpyDeviceToHost));
             fprintf(stderr, "[tksmseq] this thread so far: %u device allocations, %.3f s in hipMalloc\n", alloc_calls(), alloc_seconds());
-            fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves\n",
-                    (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9]);
+            fprintf(stderr, "[tksmseq] reads %llu rounds %u slow-path reads %u (band exit %u/%u, shift %u/%u), full-width redo: %u jobs in %u waves; predicted stragglers on their own stream: %u\n",
+                    (unsigned long long)n, rounds, cnt[2], cc[4], cc[7], cc[5], cc[6], cc[8], cc[9], n_early);
             fprintf(stderr, "[tksmseq] fused alignment failures: %u, reasons or-ed 0x%x, last 0x%x (n %u, m %u)\n", cc[12], cc[13], cc[14], cc[15] & 0xffffu, cc[15] >> 16);
             fprintf(stderr, "[tksmseq]   per reason: queue / reservoir overflow %u - - shift>31 %u shift>14 %u end cell %u walk %u | q-score jobs %u, list pass %u\n", cc[16], cc[19], cc[20], cc[21], cc[22], cc[24], cc[25]);
         }

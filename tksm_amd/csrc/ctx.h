@@ -92,6 +92,11 @@ struct tksmseq_ctx : ContigLookup {
     hipStream_t side[N_SIDE] = {};
     hipEvent_t side_start = nullptr, side_done[N_SIDE] = {};
     bool side_used[N_SIDE] = {};
+    // predicted stragglers: their straggler-kernel launch runs on a stream of its own from round 0 on (api.cpp)
+    hipStream_t early_stream = nullptr;
+    hipEvent_t early_start = nullptr, early_done = nullptr;
+    uint32_t early_tail = 2048;           // at most this many reads (and only from a batch with a long tail of predicted visits); 0: never
+    DevBuf f_early;
     bool own_stream = false;
     std::string err;
 
@@ -134,7 +139,7 @@ struct tksmseq_ctx : ContigLookup {
     int defer_len = 0;          // reads longer than this align for their q-scores after the regular rounds, all together
     int hbm_state_len = 2304;   // fragments longer than this are edited in HBM instead of being staged in LDS every round
     std::vector<hipEvent_t> evpool;
-    uint32_t last_rounds = 0, last_slow = 0;
+    uint32_t last_rounds = 0, last_slow = 0, last_early = 0;
     void* user_out = nullptr; uint64_t user_out_cap = 0;
     bool timing = false;
     int host_threads = 1;       // host threads for MDF parsing (tksmseq_set_host_threads)

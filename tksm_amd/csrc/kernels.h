@@ -119,7 +119,8 @@ struct ReadState {
     int16_t resume_src, resume_j;   // resume_j > 0: draw n_base was interrupted by a re-estimation after its slot resume_j - 1 (resume_src unused)
     uint8_t stage;                  // 0 error loop, 1 waiting for the q-score alignment, 2 done, 3 error loop done, q-score alignment deferred,
                                     // 4 error loop done in this round (k_loop), trims / q-score job / output still to do (k_err)
-    uint8_t pending, slow, pad;     // pending: 1 an alignment result waits to be applied, 2 k_loop asks k_err for an alignment job
+    uint8_t pending, slow, early;   // pending: 1 an alignment result waits to be applied, 2 k_loop asks k_err for an alignment job;
+                                    // early: the read's error loop runs on a wave of its own from round 0 on (predicted straggler: k_mark_early)
     int32_t st_draws, st_aligns;
     uint32_t job;
     int32_t raw_len;
@@ -168,6 +169,11 @@ struct FastBuffers {
     const uint32_t* base_cur; const uint32_t* base_prev;
     const RangeGeo* geo_cur; const RangeGeo* geo_prev;   // [n_ranges]
     uint32_t* slow_list;              // [n_reads]
+    // predicted stragglers (reads whose length x (1 - target identity) says they need several times the visits of the batch's median
+    // read): their error loops run from round 0 on, a wave each, on a side stream underneath the regular rounds
+    uint32_t* early_hist;             // [64][256] reads per score bin (k_init; 64 copies against contention), bin = 8 log2(1 + length x (1 - target))
+    uint2* early_list;                // {read, range}; counters[27] counts
+    uint32_t* early_slow;             // early reads that need the exact kernel; counters[26] counts (merged into slow_list after the side kernel)
     // reads longer than defer_len wait (stage 3) with their q-score alignment until the regular rounds are over
     uint2* defer_list;                // [n_reads] {read, range}; counters[1] counts
     uint32_t* defer_cnt;              // [n_ranges] per range, one counter per 128 B
@@ -201,6 +207,9 @@ hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBu
 hipError_t launch_tail(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                         uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, int wcap, hipStream_t s);
 size_t tail_lds_bytes(int lcap);
+hipError_t launch_mark_early(const FastBuffers& fb, const uint32_t* order, uint64_t n_reads, int k, uint32_t min_bin, hipStream_t s);
+hipError_t launch_tail_early(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, uint32_t max_count, int lcap, int wcap, hipStream_t s);
+hipError_t launch_merge_early_slow(const FastBuffers& fb, hipStream_t s);
 hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s);
 hipError_t launch_err(const BatchView& b, const ErrModelView& em, const QsModelView& qm, const SimParams& p, const SimBuffers& o,

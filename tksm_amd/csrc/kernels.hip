@@ -970,6 +970,12 @@ DEV int planes_words(const FastBuffers& FB, uint64_t r) { return (int)(FB.row64[
 DEV uint32_t* frag2_row(const FastBuffers& FB, uint64_t r) { return FB.st_frag2 + 4 * ((size_t)FB.row64[r] + r); }
 DEV int frag2_words(const FastBuffers& FB, uint64_t r) { return 4 * (int)(FB.row64[r + 1] - FB.row64[r]) + 4; }
 
+// a read's visits are ~ 0.14 x length x (1 - target identity): 8 bins per factor of two of that score (monotone; host and kernels
+// only compare bins)
+DEV uint32_t early_bin(int L, double target) {
+    const float sc = (float)L * (float)fmax(0.0, 1.0 - target);
+    return (uint32_t)min(255, max(0, (int)(8.0f * __log2f(1.0f + sc))));
+}
 // ---- k_init: splice (S1), flanks, target identity, 2-bit planes of the fragment, classification
 __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
                                                SimBuffers O, FastBuffers FB) {
@@ -1087,11 +1093,12 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
     if (lane == 0) {
         ReadState S;
         S.errors = 0.0; S.target = target; S.est = 0.0; S.change_count = 0; S.n_base = 0; S.aln_no = 0;
-        S.resume_src = -1; S.resume_j = 0; S.stage = 0; S.pending = 0; S.slow = slow ? 1 : 0; S.pad = 0;
+        S.resume_src = -1; S.resume_j = 0; S.stage = 0; S.pending = 0; S.slow = slow ? 1 : 0; S.early = 0;
         S.st_draws = 0; S.st_aligns = 0; S.job = 0; S.raw_len = raw_len; S.res_mt = 0; S.res_cols = 0; S.res_fail = 0; S.pad3 = 0;
         FB.state[r] = S;
         O.status[r] |= status;
         if (slow) { const uint32_t idx = atomicAdd(&FB.counters[2], 1u); FB.slow_list[idx] = (uint32_t)r; }
+        else if (FB.early_hist) atomicAdd(&FB.early_hist[(blockIdx.x & 63u) * 256u + early_bin(L, target)], 1u);    // (64 copies: a batch's reads fall into a dozen bins)
     }
 }
 
@@ -1230,7 +1237,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     ReadState* sp = FB.state + r;
     ReadState S{};
     if (act) S = *sp;
-    act = act && S.stage == 0 && !S.slow;
+    act = act && S.stage == 0 && !S.slow && !S.early;
     const int k = EM.k;
     const int L = S.raw_len + 2 * k;
     const uint32_t* f2 = frag2_row(FB, r);
@@ -1564,7 +1571,15 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     const uint32_t widx = blockIdx.x;
     if (widx >= count) return;
     uint32_t r, rc;                                           // the read and its range of the sorted order (wave-uniform)
-    if (!from_jobs) { r = order[begin + widx]; rc = (begin + widx) / FB.rs; }
+    // a straggler wave is a chain of dependent instructions that decides when the batch ends; beside the bulk kernels' waves (four per
+    // SIMD, each ready every cycle) it would get a fifth of the issue slots it can use: highest wave priority
+    if (TAIL) __builtin_amdgcn_s_setprio(3);
+    const bool early_mode = TAIL && from_jobs == 3;           // the predicted stragglers, from their list (side stream, from round 0 on)
+    if (early_mode) {
+        if (widx >= FB.counters[27]) return;
+        const uint2 e = FB.early_list[widx];
+        r = e.x; rc = e.y;
+    } else if (!from_jobs) { r = order[begin + widx]; rc = (begin + widx) / FB.rs; }
     else {
         const uint32_t target = FB.prefix[c0] + widx;
         uint32_t lo2 = c0, hi2 = c1 - 1;
@@ -1575,7 +1590,13 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r); rc = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc);
     ReadState* sp = FB.state + r;
     const ReadState S = *sp;
-    if (S.stage != 0 || S.slow) return;
+    if (S.stage != 0 || S.slow || (S.early && !early_mode)) return;
+    // an early read never has a job, and its kernel runs beside the rounds (which read the slow list's counter): what it hands to the
+    // exact kernel goes on a list of its own, merged after the side kernel has ended
+    auto to_exact_kernel = [&]() {
+        if (!early_mode) { go_slow(FB, r, lane, 0); return; }
+        if (lane == 0) { sp->slow = 1; FB.early_slow[atomicAdd(&FB.counters[26], 1u)] = r; }
+    };
     const int k = EM.k;
     const int L = S.raw_len + 2 * k;
     const uint32_t* f2 = frag2_row(FB, r);
@@ -1750,11 +1771,14 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
             wave_sync();
             const int m = join_window_planar(gnb, p0, nrows, Nw, ownw, wcap, lane);
             wave_sync();
-            if (m > wcap) break;                              // (the regular route for this visit: st stays NEED_ALN)
+            if (m > wcap) {
+                if (early_mode) { to_exact_kernel(); return; }    // (no job slots beside the rounds)
+                break;                                        // the regular route for this visit: st stays NEED_ALN
+            }
             const AlnOut a = band_align<0, false>(Fw, nrows, Nw, ownw, m, lane, nullptr);
             st_aligns++;
             if (is_inf(a.dist)) {                                  // outside the band representation: the byte-exact kernel takes the read
-                go_slow(FB, r, lane, 0);
+                to_exact_kernel();
                 return;
             }
             const int cols = (int)(a.stat & 0xffffu), mt = (int)(a.stat >> 16);
@@ -2101,7 +2125,6 @@ template <int MODE, int ROWS>
 DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls, int mcap) {
     static_assert(ROWS == 14 || ROWS == 64, "14 stored rows, or all of them");
     constexpr int NC = ROWS == 14 ? 16 : 4;                       // iterations per 64-byte line of codes
-    constexpr int LPC = 32 / NC;                                  // lines per chunk of 32 iterations
     constexpr int ST = ROWS == 14 ? 24 : 0;                       // first stored band row once the window moves
     constexpr int RAMP0 = 31 - ST;
     const bool act = J.act;
@@ -2971,6 +2994,36 @@ hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBu
     return hipGetLastError();
 }
 size_t tail_lds_bytes(int lcap) { return tail_bitmap_bytes(lcap) + TAIL_FCAP + TAIL_WCAP * 3; }
+// the reads of score bin >= min_bin, in sorted order, become early reads: flag (the regular kernels pass them by) and list entry
+__global__ void k_mark_early(FastBuffers FB, const uint32_t* __restrict__ order, uint64_t n_reads, int k, uint32_t min_bin) {
+    const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n_reads) return;
+    const uint32_t r = order[pos];
+    ReadState* sp = FB.state + r;
+    if (sp->stage != 0 || sp->slow) return;
+    if (early_bin(sp->raw_len + 2 * k, sp->target) < min_bin) return;
+    sp->early = 1;
+    FB.early_list[atomicAdd(&FB.counters[27], 1u)] = make_uint2(r, (uint32_t)(pos / FB.rs));
+}
+__global__ void k_merge_early_slow(FastBuffers FB) {
+    const uint32_t n = FB.counters[26];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) FB.slow_list[FB.counters[2] + i] = FB.early_slow[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { FB.counters[2] += n; FB.counters[4] += n; FB.counters[26] = 0u; }
+}
+hipError_t launch_mark_early(const FastBuffers& fb, const uint32_t* order, uint64_t n_reads, int k, uint32_t min_bin, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_early, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, fb, order, n_reads, k, min_bin);
+    return hipGetLastError();
+}
+hipError_t launch_tail_early(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, uint32_t max_count, int lcap, int wcap, hipStream_t s) {
+    if (!max_count) return hipSuccess;
+    hipLaunchKernelGGL(k_loopw<true>, dim3(max_count), dim3(64), tail_lds_bytes(lcap), s, em, p, fb, nullptr, 0u, max_count, 3, 0u, 0u, lcap, std::min(std::max(wcap, 1), TAIL_WCAP));
+    return hipGetLastError();
+}
+hipError_t launch_merge_early_slow(const FastBuffers& fb, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_early_slow, dim3(1), dim3(256), 0, s, fb);
+    return hipGetLastError();
+}
 hipError_t launch_tail(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, int wcap, hipStream_t s) {
     if (!count) return hipSuccess;
