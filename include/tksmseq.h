@@ -31,7 +31,7 @@
  *                          every remaining visit of a read on one wave, alignments included (k_loopw<true>; default 4096, 0: never)
  *   TKSMSEQ_LOOP_WL=W      words (16 bases each) of a read's packed fragment that k_loop keeps in LDS per lane (default 64, multiple of 4)
  *   TKSMSEQ_EARLY_TAIL=N   at most N reads whose length x (1 - target identity) exceeds 4 x the batch's median get their straggler waves at
- *                          round 0, on a stream of their own underneath the regular rounds (default 2048, at most 4096; 0: never)
+ *                          round 0, on a stream of their own underneath the regular rounds (default 1024, at most 4096; 0: never)
  *   TKSMSEQ_TAIL_WCAP=C    columns of a window the straggler kernel aligns on its wave (default and maximum 2048; a wider window takes the
  *                          regular route for that visit; the tests force that with a small value)
  *   TKSMSEQ_ALN_LDS_PAD=B  bytes of LDS the 14-row alignment pass asks for without using them: caps its waves per CU (default 0)

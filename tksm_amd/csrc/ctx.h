@@ -95,7 +95,7 @@ struct tksmseq_ctx : ContigLookup {
     // predicted stragglers: their straggler-kernel launch runs on a stream of its own from round 0 on (api.cpp)
     hipStream_t early_stream = nullptr;
     hipEvent_t early_start = nullptr, early_done = nullptr;
-    uint32_t early_tail = 2048;           // at most this many reads (and only from a batch with a long tail of predicted visits); 0: never
+    uint32_t early_tail = 1024;           // at most this many reads (and only from a batch with a long tail of predicted visits); 0: never
     DevBuf f_early;
     bool own_stream = false;
     std::string err;

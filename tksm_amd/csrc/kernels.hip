@@ -2435,6 +2435,7 @@ DEV void store_result_f(const FastBuffers& FB, uint32_t r, const AlnResF& R) {
 // (register budget: the 14-row pass needs ~131 vector registers -- 3 waves per SIMD; forced into 128 it spills, and a spill inside
 // the pop's divergent region cost correct results once: never again below its natural size)
 constexpr int ALNF_WAVES = 4;
+constexpr int LONG_QJOB = 3000;         // slots; q-score jobs above it skip the 14-row pass
 template <int MODE, int ROWS, bool LIST>
 __global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
     const int lane = threadIdx.x;
@@ -2469,8 +2470,13 @@ __global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) void k_alnf(SimPar
             trl = reinterpret_cast<uint4*>(FB.trace) + (G.trace_off + (size_t)(rel >> 6) * G.tstride * 64 + (rel & 63u)) * 4;
         }
         load_job_f(FB, job, rng, act || norow, J, r, mcap);
-        J.act = act;
+        // a q-score alignment covers the whole read: one over thousands of columns leaves the 14 stored rows somewhere with near
+        // certainty (1.9 % per 1000 columns), and its pass is as long as its window (0.45 us per iteration: the whole launch waits
+        // for the longest read) -- such a job goes straight to the list of the full-width pass
+        const bool straight_to_list = MODE == 1 && ROWS == 14 && act && J.n > LONG_QJOB;
+        J.act = act && !straight_to_list;
         AlnResF R = aln_fused<MODE, ROWS>(J, trl, tg, (int)FB.full_cl, ls, mcap);
+        if (straight_to_list) { R.fail = false; R.needfull = true; R.overflow = false; }
         if (norow) { R.fail = true; R.needfull = false; R.overflow = false; }
         if (act && R.overflow) { job_overflow(FB, O, r); return; }
         if (ROWS != 64) list_append(FB.redo_list, FB.counters + 10, act && R.needfull, job, lane);
