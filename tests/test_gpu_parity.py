@@ -177,7 +177,8 @@ def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n
     s.close()
 
 
-def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_models, po, monkeypatch, capfd):
+@pytest.mark.parametrize("compute_q", [True, False])
+def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_models, po, monkeypatch, capfd, compute_q):
     """a batch with a long tail of predicted visits (length x (1 - target identity) > 4 x the batch's median): those reads get their
     straggler waves at round 0, on a stream of their own, and the regular rounds pass them by (api.cpp: predicted stragglers);
     records and per-read statistics equal the oracle's whatever stream ran the read"""
@@ -191,7 +192,7 @@ def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_mod
     text = "".join(f"+{m}\t1\t\n" + "".join(f"{c}\t{a}\t{b}\t{st}\t{md}\n" for c, a, b, st, md in ivs) for m, ivs in mols)
     batch = s.batch_from_mdf(text)
     capfd.readouterr()
-    res = s.run(batch, target="badread", fastq=True, compute_qual=True, seed=SEED, first_read_index=77, stride=1, collect_stats=True)
+    res = s.run(batch, target="badread", fastq=True, compute_qual=compute_q, seed=SEED, first_read_index=77, stride=1, collect_stats=True)
     err = capfd.readouterr().err
     recs = res.records()
     ist, dst = res.stats()
@@ -202,7 +203,7 @@ def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_mod
     em, qm = oracle_models["em"], oracle_models["qm"]
     for i, (mid, ivs) in enumerate(mols):
         raw = po.splice(ref, ivs)
-        want, st = po.badread_record(True, SEED, 77 + i, raw, ident, em, qm, True, mid)
+        want, st = po.badread_record(True, SEED, 77 + i, raw, ident, em, qm, compute_q, mid)
         assert (ist[i, 0], ist[i, 1], ist[i, 2]) == (st.n_draws, st.change_count, st.n_aligns), (i, ist[i, :8], st.n_draws, st.change_count, st.n_aligns)
         assert dst[i, 0] == st.errors
         assert recs[i] == want, (i, mid)
