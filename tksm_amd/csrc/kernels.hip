@@ -3,7 +3,10 @@
 // Two implementations of the Badread path share the stage code below:
 //   * the fast pipeline: k_init, then rounds of k_loop (one LANE per read: error loop up to the next identity re-estimation;
 //     k_loopw, one wave per read, when few reads are left) and k_alnf (one lane per alignment job: the window decoded from the
-//     read's slot codes and aligned, bit-parallel), then the last visit k_err (one wave per read) -- ACGT reads;
+//     read's slot codes and aligned, bit-parallel); the last few thousand reads of a batch -- and, from round 0 on a stream of
+//     their own, the reads predicted to need several times the median read's visits -- finish in the straggler kernel
+//     (k_loopw<true>: every remaining visit of a read on one wave, alignments by band_align); then the last visit k_err (one wave
+//     per read) -- ACGT reads;
 //   * k_simulate: one wavefront owns one read from splice to finished sequence/qualities, alignment done across the
 //     wave -- byte-exact for any alphabet; the exact fallback and the --perfect path.
 // Reference behaviour restated per stage (file:line into vpc-ccg/tksm):
