@@ -2220,10 +2220,20 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 const uint32_t f = (sh == 0u && g) ? 1u : 0u;     // window did not move: top row only from the left
                 Pv = mk64(alignbit(~0u, hi32(Pv), sh), alignbit(hi32(Pv), lo32(Pv), sh) & ~f);
                 Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh) | f);
-                A = mk64(alignbit(lo32(EA), hi32(A), sh), alignbit(hi32(A), lo32(A), sh));
-                B = mk64(alignbit(lo32(EB), hi32(B), sh), alignbit(hi32(B), lo32(B), sh));
-                EA = mk64(hi32(EA) >> sh, alignbit(hi32(EA), lo32(EA), sh));
-                EB = mk64(hi32(EB) >> sh, alignbit(hi32(EB), lo32(EB), sh));
+                // {EA : A} and {EB : B} move down by sh rows, IN PLACE and from the low word up (the compiler, left to itself, computes the
+                // four new words of a plane into fresh registers and copies them back behind the branch: four v_mov_b64 per column)
+                {
+                    uint32_t a0 = lo32(A), a1 = hi32(A), a2 = lo32(EA), a3 = hi32(EA), b0 = lo32(B), b1 = hi32(B), b2 = lo32(EB), b3 = hi32(EB);
+                    asm("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a0) : "v"(a1), "v"(sh));
+                    asm("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a1) : "v"(a2), "v"(sh));
+                    asm("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a2) : "v"(a3), "v"(sh));
+                    asm("v_lshrrev_b32 %0, %1, %0" : "+v"(a3) : "v"(sh));
+                    asm("v_alignbit_b32 %0, %1, %0, %2" : "+v"(b0) : "v"(b1), "v"(sh));
+                    asm("v_alignbit_b32 %0, %1, %0, %2" : "+v"(b1) : "v"(b2), "v"(sh));
+                    asm("v_alignbit_b32 %0, %1, %0, %2" : "+v"(b2) : "v"(b3), "v"(sh));
+                    asm("v_lshrrev_b32 %0, %1, %0" : "+v"(b3) : "v"(sh));
+                    A = mk64(a1, a0); EA = mk64(a3, a2); B = mk64(b1, b0); EB = mk64(b3, b2);
+                }
                 ev -= (int)sh;
                 const unsigned long long clm = mk64(cl, cl), chm = mk64(ch, ch);
                 const unsigned long long Eq = bool3<BOOL3(TA & (TB ^ TC))>(A ^ clm, B, chm);
