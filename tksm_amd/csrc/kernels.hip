@@ -2188,6 +2188,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
         // are another lane's)
         uint4* const dl = trl + (size_t)(act ? ql : tg - 1) * ls;
         const int it0 = __builtin_amdgcn_readfirstlane(ql * NC);  // the pass's first iteration (scalar)
+        int mxn = 0, mxu = 0;                                     // the queues' fill before each push of the pass
 #pragma unroll
         for (int q = 0; q < HS; q++) {
             // ---- push slot s0 + q
@@ -2197,7 +2198,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
             const int len = on ? (int)((code >> 12) & 7u) : 0;    // (a pristine slot: length 1, its symbol the original base -- k_init)
             const uint32_t m5 = (1u << len) - 1u;
             const uint32_t lo5 = code & m5, hi5 = (code >> 5) & m5;
-            bad |= npend > 26 || upos > 57;
+            mxn = max(mxn, npend); mxu = max(mxu, upos);          // (capacity checked once per pass, below)
             qlo |= lo5 << npend; qhi |= hi5 << npend;
             U |= (unsigned long long)(m5 << 1) << upos;
             upos += len + inc; npend += len;
@@ -2249,13 +2250,16 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
                 const unsigned long long w1 = bool3<BOOL3(~(TA | TB))>(upv, Ph, 0ull);
                 const unsigned long long w0 = MODE ? bool3<BOOL3(TB | (~TA & TC))>(upv, Ph, D0) : bool3<BOOL3(~TA & (TB | TC))>(upv, Ph, D0);
-                const uint32_t sh4 = min(sh, 15u);
                 if constexpr (ROWS == 14) {
                     // stored rows st .. st + 13, st = clamp(iteration - RAMP0, 0, ST): a function of the iteration alone
-                    const uint32_t st = (uint32_t)(min(max(it0 + q, RAMP0), 31) - RAMP0);
+                    // (on the scalar unit: the compiler fuses min(max()) into a vector v_med3_i32 and reads it back)
+                    int st_s;
+                    asm("s_max_i32 %0, %1, %2\n\ts_min_i32 %0, %0, 31" : "=&s"(st_s) : "s"(it0 + q), "i"(RAMP0) : "scc");
+                    const uint32_t st = (uint32_t)(st_s - RAMP0);
                     const uint32_t c0 = alignbit(hi32(w0), lo32(w0), st), c1 = alignbit(hi32(w1), lo32(w1), st);
-                    const uint32_t c01 = (c0 & 0x3fffu) | (__builtin_amdgcn_ubfe(c1, 0u, 14u) << 14);
-                    ent0 = sh >= 15u ? ENT_ESC : (c01 | (sh4 << 28));
+                    const uint32_t c1s = c1 << 14;
+                    const uint32_t c01 = ((c0 & 0x3fffu) | (c1s & ~0x3fffu)) & 0x0fffffffu;      // (a bit-field insert and an and-or)
+                    ent0 = sh >= 15u ? ENT_ESC : (c01 | (sh << 28));
                 } else {
                     ent0 = lo32(w0); ent1 = hi32(w0); ent2 = lo32(w1); ent3 = hi32(w1);
                     shb = min(sh, 254u);
@@ -2283,6 +2287,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
             uint4* d = act ? trl + (size_t)(cl + (pi >> 2)) * ls + (pi & 3) : trl + (size_t)(tg - 1) * ls;
             *d = make_uint4(shw[0], shw[1], shw[2], shw[3]);
         }
+        bad |= mxn > 26 || mxu > 57;                              // a push would not have fitted the 32-bit symbol queues / the 64-bit slot stream
         ql += LPH;
         if (ql * NC == 32) { t32 = t; col32 = col; }              // window position / columns after iteration 31 (the walk's clamped start)
         if (!drain) {
