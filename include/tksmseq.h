@@ -40,8 +40,6 @@
  *   TKSMSEQ_BUCKETS=N      length buckets of the last visit's launches (default 16)
  *   TKSMSEQ_TAIL_CUT=N     diagnostic: once fewer than N reads are left, they finish in the wave-wide kernel (default 0: off)
  *   TKSMSEQ_FULL_POOL_MB=M memory for the unbanded alignment fallback of the wave-wide kernel (default 1024)
- *   TKSMSEQ_RAMP=0|1|2     (CLI) sizes of the first batches of a run: 0 all --batch-bytes; 1: 1/16, 1/8, 1/4, 1/2; 2 (default): one round of the
- *                          contexts at 1/8, one at 1/2 -- the first records reach the output 0.3 s earlier (the file is the bound of a run)
  *   TKSMSEQ_PIECE_BYTES=B  (CLI) size of the page-locked pieces a batch's records pass through (default 64 MB; the tests use 4 KB)
  *   TKSMSEQ_ABLATE=N       only in the diagnostic build (`make ablate`, -DTKSM_ABLATE): timing experiments on the last visit's q-score loop
  *                          (40 - 45, tools/ablate_err.sh) and k_loop's prologue (33)

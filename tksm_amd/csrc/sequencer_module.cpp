@@ -758,15 +758,9 @@ public:
         while ((!eof || have) && !failed) {
             // fill up to batch_bytes, then cut at the last molecule header so a batch holds whole molecules
             const auto t_read = now();
-            // the first batches are small (one round of the contexts at 1/8, one at 1/2 of --batch-bytes): the output file is the bound
-            // of the whole run (one file takes ~12 GB/s, the device 27), so what matters at the start is when the first records reach
-            // the writers -- 0.1 s after the device is ready instead of 0.4 s -- and that the batches behind them keep the writers fed
-            static const int ramp_mode = getenv("TKSMSEQ_RAMP") ? atoi(getenv("TKSMSEQ_RAMP")) : 2;
-            const int ramp = ramp_mode == 0 ? 0 : ramp_mode == 1 ? (seq < 4 ? 4 - (int)seq : 0) : seq < (uint64_t)n_workers ? 3 : seq < 2ull * (uint64_t)n_workers ? 1 : 0;
-            const size_t want = std::max<size_t>(std::min<size_t>(a.batch_bytes, 1u << 20), a.batch_bytes >> ramp);
-            buf.resize(have + want);
-            size_t got = eof ? 0 : fread(buf.data() + have, 1, want, in);
-            if (got < want) eof = true;
+            buf.resize(have + a.batch_bytes);
+            size_t got = eof ? 0 : fread(buf.data() + have, 1, a.batch_bytes, in);
+            if (got < a.batch_bytes) eof = true;
             have += got;
             size_t cut = have;
             if (!eof) {
