@@ -147,13 +147,17 @@ def e2e_leg(n_molecules):
                "fastq_bytes": os.path.getsize(os.path.join(d, "out.fastq")), "files_on": base,
                "command": "tksm sequence -i mols.mdf -r ref.fa -o out.fastq -t %d (Badread + q-scores, nanopore2020)" % max(1, cores // 2)}
         os.remove(os.path.join(d, "out.fastq"))
-        # the same run with the records going nowhere (a character device: the ordered-writer path) and to tmpfs
+        # the same run with the records going nowhere (a character device: the ordered-writer path) and to tmpfs.  A pause in front of
+        # each: a process that starts right after another one released its ~100 GiB of device memory (and while the page cache still
+        # writes the previous leg's 16 GB back) takes 1.5 - 2 x as long (tools/e2e_ab.sh)
         os.symlink("/dev/null", os.path.join(d, "null.fastq"))
+        time.sleep(8)
         dt0, _ = one(os.path.join(d, "null.fastq"))
         res["to_dev_null"] = {"reads_per_s": n / dt0 if dt0 else None, "wall_s": dt0}
         if base != "/dev/shm" and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40e9:
             shm = tempfile.mkdtemp(prefix="tksm_e2e_", dir="/dev/shm")
             try:
+                time.sleep(8)
                 dt1, _ = one(os.path.join(shm, "out.fastq"))
                 res["to_dev_shm"] = {"reads_per_s": n / dt1 if dt1 else None, "wall_s": dt1}
             finally:
