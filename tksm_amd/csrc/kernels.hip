@@ -2153,7 +2153,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     // half a word of the aligned stream, the same for every lane (the first time a lane with skip = 1 drops the row its window
     // has already) -- so that the rows a column can need (x <= slot + 32) are always there.
     unsigned long long EA = 0ull, EB = 0ull;
-    int ev = 0;
+    int app = 0;                                                  // rows appended to the reservoir so far; t - 1 of window + reservoir are used up: ev = app - (t - 1)
     unsigned long long Pv = ~0ull, Mv = 0ull;
     int t = 1, t32 = 1;
     // ---- queues
@@ -2214,7 +2214,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 const int tn = max(1, pcol - 30);
                 const uint32_t sh = (uint32_t)(tn - t);
                 t = tn;
-                shmax = max(shmax, (int)sh);
+                if constexpr (ROWS == 64) shmax = max(shmax, (int)sh);   // (14 stored rows: a shift >= 15 is an escape entry, and the job is redone here)
                 const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)qlo, 0u, 1u), ch = (uint32_t)__builtin_amdgcn_sbfe((int)qhi, 0u, 1u);
                 qlo >>= 1; qhi >>= 1; npend--; col++;
                 const bool g = t > 1;
@@ -2235,7 +2235,6 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                     asm("v_lshrrev_b32 %0, %1, %0" : "+v"(b3) : "v"(sh));
                     A = mk64(a1, a0); EA = mk64(a3, a2); B = mk64(b1, b0); EB = mk64(b3, b2);
                 }
-                ev -= (int)sh;
                 const unsigned long long clm = mk64(cl, cl), chm = mk64(ch, ch);
                 const unsigned long long Eq = bool3<BOOL3(TA & (TB ^ TC))>(A ^ clm, B, chm);
                 const unsigned long long Xv = Eq | Mv;
@@ -2293,13 +2292,14 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
         if (!drain) {
             if (s0 & 16) {
                 // the reservoir takes the 32 rows x in [64 + s0 - 16, 96 + s0 - 16): a half of the next aligned word
+                const int ev = app - (t - 1);
                 bad |= ev > 32 && s0 + HS - skip < n;              // (a lane past its last slot takes nothing from the reservoir any more)
                 const bool upper = ((s0 - 16) & 32) != 0;
                 const bool first = s0 == 16;
                 const uint32_t drop = first ? (uint32_t)skip : 0u;
                 const uint32_t na = ~(upper ? hi32(Wn.x) : lo32(Wn.x)) >> drop, nb2 = ~(upper ? hi32(Wn.y) : lo32(Wn.y)) >> drop;
                 EA |= (unsigned long long)na << (ev & 63); EB |= (unsigned long long)nb2 << (ev & 63);
-                ev += 32 - (int)drop;
+                app += 32 - (int)drop;
                 if (upper) {                                      // the plane words follow the slot position
                     jc++;
                     Wn = aligned(fpw(wb + jc + 1), fpw(wb + jc + 2));
