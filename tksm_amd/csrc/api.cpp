@@ -875,6 +875,15 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         uint32_t n_side = 0, side_launches = 0;
         bool late_flushed = false;
         for (bool& u : ctx->side_used) u = false;
+        // whatever way this function is left (an error return in the middle of the rounds included), no kernel of the side streams
+        // may still be running on the context's buffers when the caller reuses or frees them
+        struct SideGuard {
+            tksmseq_ctx* c;
+            ~SideGuard() {
+                for (int k2 = 0; k2 < tksmseq_ctx::N_SIDE; k2++) if (c->side_used[k2] && c->side[k2]) (void)hipStreamSynchronize(c->side[k2]);
+                if (c->early_stream) (void)hipStreamSynchronize(c->early_stream);
+            }
+        } side_guard{ctx};
         auto launch_side = [&](uint32_t upto) -> int {
             if (upto <= n_side || side_launches + 2 >= 1024) return TKSMSEQ_OK;
             const int k2 = (int)(side_launches % tksmseq_ctx::N_SIDE);
