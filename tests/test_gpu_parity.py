@@ -263,6 +263,46 @@ def test_cli_end_to_end_matches_goldens_and_oracle(tmp_path, po, oracle_models):
     assert r.returncode == 1 and "MDF line" in r.stderr
 
 
+def test_skewed_lengths_every_scheduling_variant_gives_the_same_bytes(capfd):
+    """40 000 reads with lognormal lengths (median 1 kb, to 16 kb): the default run -- predicted stragglers on their own stream from
+    round 0 (several hundred of them here), the straggler kernel for the last reads, long q-score jobs straight to the full-width
+    pass -- against the same batch with every read in the regular rounds only (no straggler kernel at all, lane-per-read loops and
+    the 14-row + list alignment passes in every round): not a byte may differ."""
+    from tksm_amd import synthetic
+    from tksm_amd.sequence import Sequencer
+    rs = np.random.RandomState(23)
+    lens = [4_000_000] * 4
+    contigs = [rs.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes() for n in lens]
+    m = synthetic.make_molecules(rs, lens, 40000, 1000, 200, lognormal_sigma=0.6)
+
+    def run(env):
+        with pytest.MonkeyPatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            mp.setenv("TKSMSEQ_VERBOSE", "1")                                # (read at run time; the other knobs when the context is created)
+            sq = Sequencer(0)
+            for c, seq in enumerate(contigs):
+                sq.add_contig(f"chr{c + 1}", seq)
+            sq.set_identity(84.0, 99.0, 5.5)
+            sq.load_error_model(ERR_MODEL)
+            sq.load_qscore_model(QS_MODEL)
+            b = sq.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+            capfd.readouterr()
+            rec, off = sq.run(b, seed=9).download()
+            err = capfd.readouterr().err
+            sq.close()
+        return rec, err
+    import re
+    rec_default, err_default = run({})
+    got = re.search(r"predicted stragglers on their own stream: (\d+)", err_default)
+    assert got and int(got.group(1)) >= 100, err_default[-500:]
+    rec_plain, err_plain = run({"TKSMSEQ_TAIL_WAVE": "0", "TKSMSEQ_EARLY_TAIL": "0", "TKSMSEQ_WAVE_LOOP": "0", "TKSMSEQ_SMALL_ALN": "0"})
+    assert re.search(r"predicted stragglers on their own stream: 0\b", err_plain)
+    assert rec_default == rec_plain
+    rec_late, _ = run({"TKSMSEQ_EARLY_TAIL": "0"})                       # the straggler kernel for the last reads only
+    assert rec_late == rec_default
+
+
 def test_full_size_properties_and_shard_invariance():
     """size-independent properties at a bench-like size (131072 reads of ~1 kb): record structure, determinism, and
     rank-count invariance -- two round-robin shards interleaved on the device equal the single-GPU stream."""
