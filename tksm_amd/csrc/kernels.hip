@@ -1292,7 +1292,6 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     int st = act ? RUN : IDLE;
 #ifdef TKSM_ABLATE
     if (P.ablate == 33) st = IDLE;                              // timing experiment: prologue only
-    int nbatch = 0;
 #endif
     // ---- passes of LOOP_N draws.  Phase 1, all LOOP_N draws: generator, k-mer, the k-mer's own threshold t0 (one round of gathers
     // for all of them) -> which draws change something (~19 %).  Phase 2, the first LOOP_K of those only: the generator once more
@@ -1576,7 +1575,9 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     uint32_t r, rc;                                           // the read and its range of the sorted order (wave-uniform)
     // a straggler wave is a chain of dependent instructions that decides when the batch ends; beside the bulk kernels' waves (four per
     // SIMD, each ready every cycle) it would get a fifth of the issue slots it can use: highest wave priority
+#ifndef TKSM_ABLATE                                           // (the diagnostic build runs them at the default priority: lognormal lengths, three contexts: 8.3 -> 8.0 M reads/s)
     if (TAIL) __builtin_amdgcn_s_setprio(3);
+#endif
     const bool early_mode = TAIL && from_jobs == 3;           // the predicted stragglers, from their list (side stream, from round 0 on)
     if (early_mode) {
         if (widx >= FB.counters[27]) return;
