@@ -982,6 +982,9 @@ DEV uint32_t early_bin(int L, double target) {
 // ---- k_init: splice (S1), flanks, target identity, 2-bit planes of the fragment, classification
 __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
                                                SimBuffers O, FastBuffers FB) {
+#ifndef TKSM_ABLATE
+    __builtin_amdgcn_s_setprio(2);                            // (a latency-bound kernel beside the alignment kernel's always-ready waves: see k_loopw)
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpw = blockDim.x >> 6;
     const uint64_t r = (uint64_t)blockIdx.x * wpw + wave;
     if (r >= B.n_reads) return;
@@ -1222,6 +1225,9 @@ DEV void join_out(const uint8_t* frag, const uint16_t* nb, int n, uint8_t* out_s
 constexpr int LOOP_N = 16, LOOP_K = 4;      // draws per pass of k_loop; changing draws applied per pass
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
                                               uint32_t begin, uint32_t count, int Wl, int from_jobs, uint32_t c0, uint32_t c1) {
+#ifndef TKSM_ABLATE
+    __builtin_amdgcn_s_setprio(2);                            // (a latency-bound kernel beside the alignment kernel's always-ready waves: see k_loopw)
+#endif
     uint32_t* lf = reinterpret_cast<uint32_t*>(lds_raw);      // [Wl][64]: word w of lane l at w * 64 + l (conflict-free)
     const int lane = threadIdx.x;
     const uint32_t widx = blockIdx.x * 64u + (uint32_t)lane;
@@ -1576,7 +1582,13 @@ __global__ __launch_bounds__(64) void k_loopw(ErrModelView EM, SimParams P, Fast
     // a straggler wave is a chain of dependent instructions that decides when the batch ends; beside the bulk kernels' waves (four per
     // SIMD, each ready every cycle) it would get a fifth of the issue slots it can use: highest wave priority
 #ifndef TKSM_ABLATE                                           // (the diagnostic build runs them at the default priority: lognormal lengths, three contexts: 8.3 -> 8.0 M reads/s)
+    // Wave priorities (s_setprio), measured with three contexts in flight on one box: the stragglers at 3 (skewed lengths 8.0 -> 8.3 M
+    // reads/s), the other latency-bound kernels -- k_loop, k_loopw, k_err, k_init, k_emit, the full-width alignment passes -- at 2
+    // beside the 14-row alignment pass at the default 0: 13.35 -> 13.7 M reads/s (3 instead of 2: no better)
     if (TAIL) __builtin_amdgcn_s_setprio(3);
+#ifndef TKSM_ABLATE
+    if (!TAIL) __builtin_amdgcn_s_setprio(2);
+#endif
 #endif
     const bool early_mode = TAIL && from_jobs == 3;           // the predicted stragglers, from their list (side stream, from round 0 on)
     if (early_mode) {
@@ -1833,6 +1845,9 @@ __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, Qs
     // one launch per length bucket: reads order[begin .. begin+count) share the LDS geometry (lds_lcap, lds_ncap),
     // so a batch with a few long molecules does not cost everyone its occupancy
     // wave-uniform values are pinned to scalar registers (readfirstlane): the vector file is the occupancy limit
+#ifndef TKSM_ABLATE
+    __builtin_amdgcn_s_setprio(2);                            // (a latency-bound kernel beside the alignment kernel's always-ready waves: see k_loopw)
+#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpw = blockDim.x >> 6;
     const uint32_t widx = blockIdx.x * (uint32_t)wpw + (uint32_t)wave;
     if (widx >= count) return;
@@ -2457,6 +2472,9 @@ constexpr int ALNF_WAVES = 4;
 constexpr int LONG_QJOB = 3000;         // slots; q-score jobs above it skip the 14-row pass
 template <int MODE, int ROWS, bool LIST>
 __global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
+#ifndef TKSM_ABLATE
+    if (ROWS == 64) __builtin_amdgcn_s_setprio(2);            // (the full-width passes are a few latency-bound waves)
+#endif
     const int lane = threadIdx.x;
     if (!LIST) {
         const uint32_t job0 = blockIdx.x * 64u, job = job0 + (uint32_t)lane;
@@ -2582,6 +2600,9 @@ __global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffe
                                                uint8_t* __restrict__ records) {
     __shared__ __attribute__((aligned(16))) uint8_t img_all[WAVES_PER_WG][EMIT_IMG + 32];
     __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
+#ifndef TKSM_ABLATE
+    __builtin_amdgcn_s_setprio(2);                            // (a latency-bound kernel beside the alignment kernel's always-ready waves: see k_loopw)
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t r = (uint64_t)blockIdx.x * WAVES_PER_WG + wave;
     if (r >= B.n_reads) return;
