@@ -1222,7 +1222,7 @@ DEV void join_out(const uint8_t* frag, const uint16_t* nb, int n, uint8_t* out_s
 // slot codes stay in HBM (read and written only by the draws that change something).
 // A read that stops at a re-estimation point gets an alignment job here (id, meta record: k_alnf decodes and aligns its window
 // it; pending = 1); one whose loop has ended waits in stage 3 for its q-score job and its last visit (k_qjobs, k_err).
-constexpr int LOOP_N = 16, LOOP_K = 4;      // draws per pass of k_loop; changing draws applied per pass
+constexpr int LOOP_N = 16, LOOP_K = 3;      // draws per pass of k_loop; changing draws applied per pass
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
                                               uint32_t begin, uint32_t count, int Wl, int from_jobs, uint32_t c0, uint32_t c1) {
 #ifndef TKSM_ABLATE
@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
         }
         // ---- the first LOOP_K changing draws (relative index LOOP_N: none)
         int di[LOOP_K], kidx[LOOP_K];
-        uint32_t bj[LOOP_K], dw[LOOP_K], dz[LOOP_K], dv[LOOP_K];
+        uint32_t bj[LOOP_K], dw[LOOP_K];
         bool rest;                                             // more changing draws than LOOP_K: the pass ends behind the last chosen one
         {
             uint32_t mm = mask;
@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                 mm &= mm - 1u;
                 const uint32_t bb = min(bj[j], (uint32_t)LOOP_N - 1u);
                 const Ph4 d = philox(P.seed, g, ST_DRAW, n + bb);
-                dw[j] = d.y; dz[j] = d.z; dv[j] = d.w;
+                dw[j] = d.y;
                 di[j] = (int)ldi[bb * 64 + lane]; kidx[j] = (int)lki[bb * 64 + lane];
             }
             rest = mm != 0u;
@@ -1434,9 +1434,13 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                 if (cls[j] == 2) {
                     // add_one_random_change (:199-213): one slot of the k-mer changes -- substitution by the r3-th next base,
                     // insertion of base4 before / after, deletion; the other slots keep their base (encoding 0: never applied)
-                    const uint32_t type = __umulhi(dz[j], 3u), pos = __umulhi(dv[j], (uint32_t)k);
-                    const uint32_t base4 = dv[j] & 3u, side = (dv[j] >> 2) & 1u;
-                    const uint32_t r3 = (((dz[j] & 0xffffu) * 3u) >> 16) + 1u;
+                    // (the draw's other two words: generated again here -- the residual mass is rare, and six registers held for it
+                    // across the gathers were what kept the kernel from a fourth wave per SIMD)
+                    const Ph4 d2 = philox(P.seed, g, ST_DRAW, n0 + bj[j]);
+                    const uint32_t dzj = d2.z, dvj = d2.w;
+                    const uint32_t type = __umulhi(dzj, 3u), pos = __umulhi(dvj, (uint32_t)k);
+                    const uint32_t base4 = dvj & 3u, side = (dvj >> 2) & 1u;
+                    const uint32_t r3 = (((dzj & 0xffffu) * 3u) >> 16) + 1u;
                     const uint32_t kc = ((uint32_t)kidx[j] >> (2 * (k - 1 - (int)pos))) & 3u;
                     const uint32_t v = type == 0 ? 0x8000u | (1u << 12) | planar1((kc + r3) & 3u)
                                      : type == 1 ? 0x8000u | (2u << 12) | (side ? planar2(kc, base4) : planar2(base4, kc))
