@@ -204,8 +204,9 @@ typedef struct {
     uint64_t bases_out;           /* emitted bases */
     float kernel_ms[8];           /* device time of this call by HIP events on its stream, 0 if timing is off: [0] lengths + scan,
                                      [1] the simulate stage as a whole, [2] record offsets, [3] k_emit / k_perfect, [4] everything;
-                                     Badread: summed launch durations of [5] k_loop, [6] k_aln, [7] k_job (the rest of [1]: k_init, the
-                                     final-stage k_err, host gaps between rounds) */
+                                     Badread: summed launch durations of [5] the error-loop kernels (k_loop, k_loopw, the straggler launch), [6] the
+                                     alignment kernel k_alnf (all passes), [7] the launches around k_qjobs (rounds 1 - 2: k_job); the rest of [1]:
+                                     k_init, the final-stage k_err, host gaps between rounds */
 } tksmseq_result;
 
 int tksmseq_run(tksmseq_ctx* ctx, const tksmseq_batch* batch, const tksmseq_run_params* params,
