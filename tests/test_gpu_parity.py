@@ -177,12 +177,16 @@ def test_badread_bit_exact_vs_oracle(oracle_models, po, monkeypatch, mean_len, n
     s.close()
 
 
-@pytest.mark.parametrize("compute_q", [True, False])
-def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_models, po, monkeypatch, capfd, compute_q):
+@pytest.mark.parametrize("compute_q,wcap", [(True, None), (False, None), (True, 700)])
+def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_models, po, monkeypatch, capfd, compute_q, wcap):
     """a batch with a long tail of predicted visits (length x (1 - target identity) > 4 x the batch's median): those reads get their
     straggler waves at round 0, on a stream of their own, and the regular rounds pass them by (api.cpp: predicted stragglers);
-    records and per-read statistics equal the oracle's whatever stream ran the read"""
+    records and per-read statistics equal the oracle's whatever stream ran the read.  wcap 700: the straggler waves have room for 700
+    columns only, so every early read hands itself to the exact kernel at its first re-estimation window (1000 slots) -- through the
+    early reads' own slow list, merged into the batch's when the host joins the side stream"""
     monkeypatch.setenv("TKSMSEQ_FORCE_SLOW", "0"); monkeypatch.setenv("TKSMSEQ_EARLY_TAIL", "8"); monkeypatch.setenv("TKSMSEQ_VERBOSE", "1")
+    if wcap:
+        monkeypatch.setenv("TKSMSEQ_TAIL_WCAP", str(wcap))
     s, ref, rs = _random_genome_seqr()
     s.set_identity(84.0, 99.0, 5.5)
     s.load_error_model(ERR_MODEL)
@@ -199,6 +203,9 @@ def test_predicted_stragglers_on_their_own_stream_bit_exact_vs_oracle(oracle_mod
     import re
     got = re.search(r"predicted stragglers on their own stream: (\d+)", err)
     assert got and 1 <= int(got.group(1)) <= 8, err[-600:]
+    slow = re.search(r"slow-path reads (\d+)", err)
+    if wcap:
+        assert slow and int(slow.group(1)) >= int(got.group(1)), err[-600:]     # the early reads went to the exact kernel
     ident = po.Identities(84.0, 5.5, 99.0)
     em, qm = oracle_models["em"], oracle_models["qm"]
     for i, (mid, ivs) in enumerate(mols):
