@@ -167,6 +167,27 @@ def e2e_leg(n_molecules):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: N child ranks under torch.distributed.run.  Counting devices does not
+    initialise the GPU in this process (torch.cuda.device_count reads the driver's list)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("TKSM_BENCH_SKIP_DEVICE_CHECK"):     # (the variable: for the CPU test of this launcher)
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,9 +210,19 @@ def main():
                          "offsets = all_gather of record lengths only, every rank learns its records' final file offsets (tksm_amd/ordering.py)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the short legs on the other workloads (scRNA-like, PCR-like, lognormal lengths)")
     ap.add_argument("--e2e-molecules", type=int, default=8_000_000)
+    ap.add_argument("--order-check-reads", type=int, default=32768,
+                    help="N > 1 (or the forced exchange): after the timed steps every rank runs its round-robin shard of ONE common set of "
+                         "N x this many molecules through the same exchange, and rank 0 compares the ordered stream with its own "
+                         "single-GPU run of the whole set (BASELINE config 4's FASTQ order check); 0 = skip")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as `python bench.py --gpus N`: this process becomes the launcher and never touches a GPU -- the N ranks are CHILD
+        # processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1); rank 0's JSON line reaches our stdout as it is
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with --gpus N (or leave WORLD_SIZE unset and bench.py starts them)")
     # stdout carries the one JSON line and nothing else: libraries that print while they initialise (RCCL) go to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -290,17 +321,21 @@ def main():
     # rank 0's interleave runs on the exchange stream itself (a context of its own on that stream): it follows the receives in
     # stream order, no host synchronisation in between
     xseq = first.seqr.clone(stream=xstream.cuda_stream) if exchange_on else None
-    xbuf = {"bytes": None, "offs": None, "out": None, "keep": None}
+    xbuf = {"bytes": None, "offs": None, "out": None, "keep": None, "n_out": 0}
 
-    def exchange(out_t, off_t, n_bytes):
+    def exchange(out_t, off_t, n_bytes, n_reads=None):
         """FASTQ ordering (N > 1, tksm_amd/ordering.py) on the exchange thread and stream, while the compute contexts run their next
         steps.  gather: the ranks' byte counts (all_gather), then exactly the record bytes and offsets of every rank to rank 0
-        (send / recv over RCCL), and the device interleave into global read order.  offsets: the ranks' record lengths only."""
+        (send / recv over RCCL), and the device interleave into global read order.  offsets: the ranks' record lengths only.
+        Returns when the exchange stream has drained: with RCCL a finished `wait()` orders the STREAM behind the transfer, not the
+        host, and the caller hands `out_t` / `off_t` back to a compute context (another stream) right after."""
+        n_reads = args.batch if n_reads is None else n_reads
         with torch.cuda.stream(xstream):
             if args.ordering == "offsets":
-                xbuf["keep"] = ordering.global_offsets(off_t[1:] - off_t[:-1], [args.batch] * world, rank, world)
+                xbuf["keep"] = ordering.global_offsets(off_t[1:n_reads + 1] - off_t[:n_reads], [n_reads] * world, rank, world)
+                xstream.synchronize()
                 return
-            sizes = ordering.exchange_sizes(n_bytes, args.batch, world, dev)
+            sizes = ordering.exchange_sizes(n_bytes, n_reads, world, dev)
             if rank == 0:
                 need_b, need_o = int(sizes[:, 0].sum()), int(sizes[:, 1].sum()) + world
                 if xbuf["bytes"] is None or xbuf["bytes"].numel() < need_b:
@@ -308,11 +343,12 @@ def main():
                     xbuf["out"] = torch.empty(int(need_b * 1.02) + 4096, dtype=torch.uint8, device=dev)
                 if xbuf["offs"] is None or xbuf["offs"].numel() < need_o:
                     xbuf["offs"] = torch.empty(need_o, dtype=torch.int64, device=dev)
-            got = ordering.gather_exact(out_t[:n_bytes], off_t, sizes, rank, world, xbuf["bytes"], xbuf["offs"])
+            got = ordering.gather_exact(out_t[:n_bytes], off_t[:n_reads + 1], sizes, rank, world, xbuf["bytes"], xbuf["offs"])
             if rank == 0:
                 fb, bstart, fo, ostart = got
-                xseq.interleave_records([fb.data_ptr() + int(bstart[p]) for p in range(world)], [fo.data_ptr() + 8 * int(ostart[p]) for p in range(world)],
-                                        [args.batch] * world, xbuf["out"].data_ptr(), xbuf["out"].numel())
+                xbuf["n_out"] = xseq.interleave_records([fb.data_ptr() + int(bstart[p]) for p in range(world)], [fo.data_ptr() + 8 * int(ostart[p]) for p in range(world)],
+                                                        [int(sizes[p, 1]) for p in range(world)], xbuf["out"].data_ptr(), xbuf["out"].numel())
+            xstream.synchronize()
 
     def run_steps(first, count):
         """steps first .. first+count-1: context t mod n_ctx runs step t on its own thread; with N > 1 the main thread
@@ -361,6 +397,52 @@ def main():
             raise errors[0]
         return results
 
+    def run_order_check():
+        """BASELINE config 4's FASTQ order check on the ranks of this run (untimed, after the timed steps): ONE common set of
+        world x nv molecules (every rank draws the same set), rank p runs reads p, p + world, ... of it and the SAME exchange as the timed
+        steps orders them on rank 0 -- which also runs the whole set alone (stride 1) and compares the two streams on the device,
+        byte for byte (gather), or every rank's offsets with the single-GPU record offsets (offsets)."""
+        nv = args.order_check_reads
+        c = ctxs[0]
+        rs = np.random.RandomState(4242)
+        g = synthetic.make_molecules(rs, [clen] * args.genome_contigs, nv * world, args.mean_len, args.mean_len * 0.2, kind=args.kind,
+                                     id_prefix="oc", lognormal_sigma=args.lognormal_sigma or None)
+        mine = synthetic.take(g, np.arange(rank, nv * world, world))
+        keep = c.batch
+        sb = c.seqr.batch_from_arrays(mine["reads"], mine["intervals"], mine["mods"], mine["literals"], mine["literal_pool"], mine["ids"], mine["id_pool"])
+        out_t, off_t = c.out_ts[0], c.off_ts[0]
+        c.seqr.set_output_buffer(out_t.data_ptr(), cap)
+        r = c.seqr.run(sb, target=target, fastq=True, compute_qual=compute_q, seed=42, first_read_index=rank, stride=world)
+        r.copy_to_device(None, off_t.data_ptr())
+        c.seqr.synchronize()
+        exchange(out_t, off_t, int(r.records_bytes), nv)
+        sb.free()
+        res = {"reads": nv * world, "ordering": args.ordering, "equal": None}
+        if args.ordering == "offsets":
+            my_off, total = xbuf["keep"]
+            my_off = my_off.clone()
+        if rank == 0 or args.ordering == "offsets":
+            wb = c.seqr.batch_from_arrays(g["reads"], g["intervals"], g["mods"], g["literals"], g["literal_pool"], g["ids"], g["id_pool"])
+            rw = c.seqr.run(wb, target=target, fastq=True, compute_qual=compute_q, seed=42, first_read_index=0, stride=1)
+            woff = torch.empty(nv * world + 1, dtype=torch.int64, device=dev)
+            rw.copy_to_device(None, woff.data_ptr())
+            c.seqr.synchronize()
+            if args.ordering == "gather":
+                n_out = int(xbuf["n_out"])
+                res["bytes"] = n_out
+                res["equal"] = bool(n_out == int(rw.records_bytes) and torch.equal(xbuf["out"][:n_out], out_t[:n_out]))
+            else:
+                ok = bool(total == int(rw.records_bytes) and torch.equal(my_off, woff[rank:nv * world:world]))
+                res["bytes"] = int(total)
+                res["equal"] = ok
+            wb.free()
+        c.batch = keep
+        if args.ordering == "offsets":
+            flag = torch.tensor([1 if res["equal"] else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            res["equal"] = bool(flag.item())
+        return res
+
     def fence():
         torch.cuda.synchronize()
         if exchange_on:
@@ -390,6 +472,9 @@ def main():
     fence()
     exclusive = {"k_loop": float(rx.kernel_ms[5]), "k_alnf": float(rx.kernel_ms[6]),
                  "simulate_stage_total": float(rx.kernel_ms[1]), "all_kernels": float(rx.kernel_ms[4])}
+    order_check = None
+    if exchange_on and args.order_check_reads > 0 and not args.perfect:
+        order_check = run_order_check()
     if exchange_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -505,6 +590,8 @@ def main():
         out["e2e_reads_per_s"] = e2e["reads_per_s"]
         out["e2e"] = e2e
     out["cpu_baseline"] = cpu_base
+    if order_check is not None:
+        out["order_check"] = order_check
     sys.stdout.flush()
     os.dup2(json_fd, 1)
     print(json.dumps(out), flush=True)
@@ -515,6 +602,8 @@ def main():
         c.seqr.close()
     if exchange_on:
         dist.destroy_process_group()
+    if order_check is not None and order_check["equal"] is False:
+        sys.exit("bench.py: FASTQ order check FAILED -- the ordered stream of the ranks differs from the single-GPU run")
 
 
 if __name__ == "__main__":

@@ -229,6 +229,17 @@ int tksmseq_model_available(const char* name, const char* kind);
 int tksmseq_prefetch_model(const char* name_or_path, const char* kind);
 int tksmseq_prefetch_identity(double mean, double max, double stdev);
 int tksmseq_set_timing(tksmseq_ctx* ctx, int enable);   /* hipEvent per stage, read via result.kernel_ms */
+/* Diagnostics of the last Badread tksmseq_run on this context (no reference counterpart: the lane-per-alignment kernels fall back
+ * to an exact wave-wide kernel for what their fixed-size queues / stored rows cannot hold, with the same results -- so a defect that
+ * only shows as fall-backs is invisible to parity tests; tests/test_gpu_parity.py watches these counts instead).  out[16]:
+ *  [0] rounds of the host loop            [1] reads finished by the exact wave-wide kernel (non-ACGT bytes, band exits, fall-backs)
+ *  [2] predicted stragglers (own stream)   [3] alignment jobs of the rounds whose first pass stores 14 rows
+ *  [4] of those, jobs redone at full width (path left the stored rows)       [5] fused-alignment fall-backs (job given up by k_alnf)
+ *  [6] the fall-backs' reasons, or-ed (bit 0 column-queue / reservoir overflow, 3 window shift > 31, 4 shift > 14 in the 14-row
+ *      pass, 5 end cell outside the band, 6 walk left the stored rows)        [7] fall-backs among q-score jobs
+ *  [8] fall-backs in the full-width list pass                                 [9] alignment jobs of all rounds
+ *  [10] reads whose alignment left the 64-row band (exact kernel)            [11..15] reserved (0) */
+int tksmseq_run_diagnostics(tksmseq_ctx* ctx, uint32_t* out);
 /* Copies the last result to host memory (records: records_bytes, offsets: n_reads + 1). */
 int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets);
 /* A slice [offset, offset + bytes) of the last result's record stream to host memory -- for callers that stream a large result

@@ -68,6 +68,74 @@ def test_cli_validation_matches_reference_messages():
     assert rc == 2 and "invalid choice" in err
 
 
+def test_cli_accepts_argparse_spellings(tmp_path):
+    """The reference's parser is argparse with its defaults (py/sequence.py:35-40, :124): `--opt=value`, any unambiguous prefix of a
+    long option, a value glued to a short option.  Each form reaches the same validation as the plain one; an ambiguous prefix and a
+    value given to a flag are usage errors (exit 2) with argparse's wording."""
+    for args in (("--input=x.mdf",), ("--inp", "x.mdf"), ("-ix.mdf",), ("--inpu=x.mdf",)):
+        rc, _, err = _cli(*args)
+        assert rc == 2 and "Must specify either --output or --perfect." in err, args
+    for args in (("-i", "x.mdf", "--badread=o.fq", "--badread-identity=abc"), ("-ix.mdf", "-oo.fq", "--badread-id", "abc"),
+                 ("-i", "x.mdf", "--perf=o.fq", "--badread-i=abc")):
+        rc, _, err = _cli(*args)
+        assert rc == 1 and "Error: could not parse --identity values" in err, args
+    rc, _, err = _cli("-i", "x.mdf", "--bad", "o.fq")
+    assert rc == 2 and "ambiguous option: --bad could match --badread, --badread-identity, --badread-error-model" in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fq", "--skip-qual-compute=1")
+    assert rc == 2 and "argument --skip-qual-compute: ignored explicit argument '1'" in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fq", "--output-format=bam")
+    assert rc == 2 and "invalid choice: 'bam'" in err
+    rc, _, err = _cli("-i", "x.mdf", "-o", "o.fq", "--nope=3")
+    assert rc == 2 and "unrecognized arguments: --nope=3" in err
+    rc, out, _ = _cli("--li")
+    assert rc == 0 and "badread_identity" in out.split()
+    # the C++ modules' parser is cxxopts (src/module.h:75-104): `--opt=value`, no abbreviations
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    p = subprocess.run([exe, "pcr", "--input=x.mdf", f"--output={tmp_path / 'o.mdf'}", "--cycles=3"], capture_output=True, text=True)
+    assert p.returncode == 1 and "molecule-count is required!" in p.stderr and "Error rate is required!" in p.stderr
+    p = subprocess.run([exe, "pcr", "--inp", "x.mdf"], capture_output=True, text=True)
+    assert p.returncode == 1 and "Option '--inp' does not exist" in p.stderr
+
+
+def test_no_output_file_is_created_before_the_run_can_start(tmp_path):
+    """the outputs are created (truncated) only once devices, references, models and the input are usable: a run that stops before
+    that -- here: no device, or no such input -- leaves an existing file alone and creates none"""
+    import torch
+    keep = tmp_path / "keep.fastq"
+    keep.write_text("precious\n")
+    new = tmp_path / "new.fastq"
+    rc, _, err = _cli("-i", str(tmp_path / "missing.mdf"), "-o", str(keep), "--perfect", str(new))
+    assert rc == 1
+    assert ("no HIP device" in err) if not torch.cuda.is_available() else ("cannot open" in err)
+    assert keep.read_text() == "precious\n" and not new.exists()
+
+
+def test_error_model_loader_limits_are_reported(tmp_path):
+    """Loader limits the reference's dict-of-lists model does not have (py/tksm_badread.py:91-117), rejected loudly with the reason
+    (tksmseq_last_error(NULL) after tksmseq_prefetch_model; the same loader serves tksmseq_load_error_model): an alternative whose
+    alignment puts more than 5 bases into one k-mer slot, k > 8, k-mers of unequal size.  The shipped models have <= 5 / 7 / 7."""
+    import gzip
+    from tksm_amd import _lib
+    lib = _lib.load()
+
+    def load(text, name):
+        p = tmp_path / name
+        with gzip.open(p, "wt") as f:
+            f.write(text)
+        rc = lib.tksmseq_prefetch_model(str(p).encode(), b"error")
+        return rc, lib.tksmseq_last_error(None).decode()
+    ok = "ACGTACG,0.8;ACGTTACG,0.1;ACGACG,0.05;\n"
+    assert load(ok, "ok.error.gz")[0] == 0
+    rc, msg = load("ACGTACG,0.8;ACGTTTTTTTACG,0.1;\n", "slot6.error.gz")
+    assert rc != 0 and "alternative slot longer than 5 bases" in msg
+    rc, msg = load("ACGTACGTA,0.8;ACGTACGTT,0.1;\n", "k9.error.gz")
+    assert rc != 0 and "k-mer longer than 8" in msg
+    rc, msg = load("ACGTACG,0.8;ACGTTACG,0.1;\nACGTAC,0.9;ACGAC,0.05;\n", "mixed.error.gz")
+    assert rc != 0 and "k-mers differ in size" in msg
+    rc, msg = load("ACGTACG\n", "malformed.error.gz")
+    assert rc != 0 and "malformed error model line" in msg
+
+
 def test_cli_utility_flags_are_validated_before_the_device_is_touched(tmp_path):
     """--batch-bytes / --in-flight / --devices / --verbosity / --log-file (src/module.h:95-122): bad values end the run
     with a message instead of spinning, being ignored or silently running on device 0"""

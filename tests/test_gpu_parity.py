@@ -335,6 +335,24 @@ def test_full_size_properties_and_shard_invariance():
     res2 = s.run(b, seed=5)
     rec2, _ = res2.download()
     assert rec1 == rec2                                                   # deterministic
+    # canary on what parity tests cannot see (tksmseq_run_diagnostics): a lane-per-alignment job that k_alnf gives up falls back
+    # to the exact wave-wide kernel with the same bytes -- a miscompiled queue (the spill episode) shows only here
+    dg = s.run_diagnostics()
+    assert dg["fallbacks"] == 0 and dg["fallback_reasons"] == 0 and dg["exact_kernel_reads"] == 0 and dg["band_exits"] == 0, dg
+    assert 15 <= dg["rounds"] <= 60 and dg["jobs_all_rounds"] > 5 * n, dg
+    # (a batch of this size aligns at full width in every round -- TKSMSEQ_SMALL_ALN = 131072; the 14-row pass + redo list of the
+    # bench-size batches runs here with the threshold at 0: same bytes, 1 - 3 % of its jobs redone, none given up)
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("TKSMSEQ_SMALL_ALN", "0")
+        s4 = Sequencer(0)
+    setup(s4)
+    b4 = s4.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
+    rec4, _ = s4.run(b4, seed=5).download()
+    dg4 = s4.run_diagnostics()
+    s4.close()
+    assert rec4 == rec1
+    assert dg4["fallbacks"] == 0 and dg4["fallback_reasons"] == 0 and dg4["exact_kernel_reads"] == 0, dg4
+    assert dg4["jobs_14_row_rounds"] > 5 * n and 0.01 <= dg4["jobs_redone_full_width"] / dg4["jobs_14_row_rounds"] <= 0.03, dg4
     # slices of the record stream (tksmseq_result_download_range: what the CLI streams through its page-locked pieces)
     for lo, nb in ((0, 1), (12345, 70001), (len(rec1) - 5, 5), (len(rec1), 0)):
         assert res2.download_range(lo, nb) == rec1[lo:lo + nb]
@@ -761,6 +779,30 @@ def test_cli_devices_list_threads_and_error_path(tmp_path, po, oracle_models):
     assert r.returncode == 1 and "write failed" in r.stderr
     r = subprocess.run(base + ["-o", str(tmp_path / "x.fastq"), "--devices", "99"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 1 and "device index out of range" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_devices_list_over_distinct_gpus(tmp_path):
+    """--devices over DISTINCT device indices where the box has more than one GPU (reference and models loaded per device, batches
+    handed to whichever group is free, MDF order restored): the bytes of --devices 0.  The analogue of the reference's
+    Pool(args.threads).imap_unordered over molecules (py/sequence.py:360-368)."""
+    import subprocess
+    import torch
+    from conftest import ROOT
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU on this box (--devices 0,0 is covered by test_cli_devices_list_threads_and_error_path)")
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    d = os.path.join(GOLDEN, "splice_corpus")
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    base = [exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-s", "11", "--batch-bytes", "4096"]
+    one, many = tmp_path / "one.fastq", tmp_path / "many.fastq"
+    r = subprocess.run(base + ["-o", str(one), "--devices", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    devs = ",".join(str(i) for i in range(min(n_dev, 4)))
+    r = subprocess.run(base + ["-o", str(many), "--devices", devs, "-t", "4"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert one.read_bytes() == many.read_bytes() and len(one.read_bytes()) > 10000
 
 
 @pytest.mark.gpu

@@ -62,7 +62,7 @@ SYMBOLS = [
     "tksmseq_clone", "tksmseq_host_alloc", "tksmseq_host_free", "tksmseq_load_tail_model", "tksmseq_set_tail_model",
     "tksmseq_set_host_threads", "tksmseq_model_available",
     "tksmseq_device_alloc", "tksmseq_device_free", "tksmseq_copy_to_host", "tksmseq_pcr_preset", "tksmseq_pcr", "tksmseq_pcr_template_counts", "tksmseq_truncate", "tksmseq_batch_to_mdf_text", "tksmseq_text_free",
-    "tksmseq_molecules_from_mdf_text", "tksmseq_pcr_main", "tksmseq_truncate_main",
+    "tksmseq_molecules_from_mdf_text", "tksmseq_pcr_main", "tksmseq_truncate_main", "tksmseq_run_diagnostics",
 ]
 
 _lib = None
@@ -120,6 +120,7 @@ def load():
         "tksmseq_run": (C.c_int, [vp, vp, P(RunParams), P(Result)]),
         "tksmseq_set_output_buffer": (C.c_int, [vp, vp, u64]),
         "tksmseq_set_timing": (C.c_int, [vp, C.c_int]),
+        "tksmseq_run_diagnostics": (C.c_int, [vp, P(C.c_uint32)]),
         "tksmseq_result_download": (C.c_int, [vp, vp, vp]),
         "tksmseq_prefetch_model": (C.c_int, [C.c_char_p, C.c_char_p]),
         "tksmseq_prefetch_identity": (C.c_int, [C.c_double, C.c_double, C.c_double]),

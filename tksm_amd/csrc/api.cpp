@@ -368,8 +368,10 @@ int tksmseq_set_identity(tksmseq_ctx* ctx, double mean, double max, double stdev
 int tksmseq_prefetch_model(const char* name_or_path, const char* kind) {
     if (!name_or_path || !kind) return TKSMSEQ_EINVAL;
     std::string err;
-    if (!strcmp(kind, "error")) { ErrorModelHost m; return load_error_model(name_or_path, m, err) ? TKSMSEQ_OK : TKSMSEQ_EIO; }
-    if (!strcmp(kind, "qscore")) { QScoreModelHost m; return load_qscore_model(name_or_path, m, err) ? TKSMSEQ_OK : TKSMSEQ_EIO; }
+    // (the loader's message: tksmseq_last_error(NULL) on the calling thread)
+    if (!strcmp(kind, "error")) { ErrorModelHost m; if (load_error_model(name_or_path, m, err)) return TKSMSEQ_OK; g_create_error = err; return TKSMSEQ_EIO; }
+    if (!strcmp(kind, "qscore")) { QScoreModelHost m; if (load_qscore_model(name_or_path, m, err)) return TKSMSEQ_OK; g_create_error = err; return TKSMSEQ_EIO; }
+    g_create_error = std::string("unknown model kind: ") + kind;
     return TKSMSEQ_EINVAL;
 }
 
@@ -943,6 +945,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         }
         ctx->last_early = n_early;
         uint32_t rounds = 0, n_deferred = 0;
+        uint64_t jobs_all = 0, jobs_14 = 0;                  // alignment jobs launched (diagnostics)
         bool revive = false, revived = false;
         // waves of the straggler kernel the device holds at once (its LDS per wave grows with the longest fragment of the batch): it
         // takes over when every read that is left gets a wave of its own at once
@@ -1054,6 +1057,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             {
                 const uint32_t n_jobs = hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u);
                 const bool full_only = cnt[0] <= std::min(ctx->small_aln, FB.full_rows);
+                jobs_all += cnt[0]; if (!full_only) jobs_14 += cnt[0];
                 HIPCHK(ctx, tk::launch_alnf(P, FB, O, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, s));
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
@@ -1068,6 +1072,13 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
         }
         ctx->last_rounds = rounds; ctx->last_slow = cnt[2];
         mark("rounds done");
+        {
+            // (the counters came down with the last round's copy; nothing that counts has run since)
+            uint32_t* d = ctx->last_diag;
+            memset(d, 0, sizeof(ctx->last_diag));
+            d[0] = rounds; d[1] = cnt[2]; d[2] = n_early; d[3] = (uint32_t)std::min<uint64_t>(jobs_14, 0xffffffffu); d[4] = cnt[8]; d[5] = cnt[12];
+            d[6] = cnt[13]; d[7] = cnt[24]; d[8] = cnt[25]; d[9] = (uint32_t)std::min<uint64_t>(jobs_all, 0xffffffffu); d[10] = cnt[4] + cnt[7];
+        }
         if (getenv("TKSMSEQ_VERBOSE")) {
             uint32_t cc[32];
             HIPCHK(ctx, hipMemcpy(cc, FB.counters, 128, hipMemcpyDeviceToHost));
@@ -1187,6 +1198,7 @@ int tksmseq_run(tksmseq_ctx* ctx, const tksmseq_batch* batch, const tksmseq_run_
     }
     tksmseq_batch* b = const_cast<tksmseq_batch*>(batch);
     bool overflow = false;
+    memset(ctx->last_diag, 0, sizeof(ctx->last_diag));
     int rc = apply_tail(ctx, b, p);
     if (rc != TKSMSEQ_OK) return rc;
     rc = run_once(ctx, b, p, 3, 2, 64, result, &overflow);
@@ -1197,6 +1209,13 @@ int tksmseq_run(tksmseq_ctx* ctx, const tksmseq_batch* batch, const tksmseq_run_
     }
     if (rc == TKSMSEQ_OK) { ctx->last = *result; ctx->have_last = true; ctx->have_stats = p->collect_stats != 0; }
     return rc;
+}
+
+int tksmseq_run_diagnostics(tksmseq_ctx* ctx, uint32_t* out) {
+    if (!ctx || !out) return TKSMSEQ_EINVAL;
+    if (!ctx->have_last) return TKSMSEQ_ESTATE;
+    memcpy(out, ctx->last_diag, sizeof(ctx->last_diag));
+    return TKSMSEQ_OK;
 }
 
 int tksmseq_result_download(tksmseq_ctx* ctx, uint8_t* records, uint64_t* offsets) {

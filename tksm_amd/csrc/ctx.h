@@ -140,6 +140,7 @@ struct tksmseq_ctx : ContigLookup {
     int hbm_state_len = 2304;   // fragments longer than this are edited in HBM instead of being staged in LDS every round
     std::vector<hipEvent_t> evpool;
     uint32_t last_rounds = 0, last_slow = 0, last_early = 0;
+    uint32_t last_diag[16] = {};      // tksmseq_run_diagnostics
     void* user_out = nullptr; uint64_t user_out_cap = 0;
     bool timing = false;
     int host_threads = 1;       // host threads for MDF parsing (tksmseq_set_host_threads)

@@ -148,7 +148,10 @@ int run_pieces(const Common& c, Logger& log, const char* what, Prepare prepare, 
 
 }  // namespace
 
-extern "C" int tksmseq_pcr_main(int argc, char** argv) {
+extern "C" int tksmseq_pcr_main(int argc0, char** argv0) {
+    std::vector<std::string> arg_store; std::vector<char*> arg_ptrs;
+    tkmod::split_equals(argc0, argv0, arg_store, arg_ptrs);
+    const int argc = (int)arg_ptrs.size(); char** const argv = arg_ptrs.data();
     Common c;
     bool have_count = false, have_cycles = false, have_er = false, have_ef = false;
     std::string preset;
@@ -232,7 +235,10 @@ extern "C" int tksmseq_pcr_main(int argc, char** argv) {
     return run_pieces(c, log, "PCR", prepare, next_piece, work);
 }
 
-extern "C" int tksmseq_truncate_main(int argc, char** argv) {
+extern "C" int tksmseq_truncate_main(int argc0, char** argv0) {
+    std::vector<std::string> arg_store; std::vector<char*> arg_ptrs;
+    tkmod::split_equals(argc0, argv0, arg_store, arg_ptrs);
+    const int argc = (int)arg_ptrs.size(); char** const argv = arg_ptrs.data();
     Common c;
     tksmseq_trc_params p{};
     std::string kde;

@@ -40,6 +40,19 @@ struct Logger {
     ~Logger() { if (own) fclose(f); }
 };
 
+// cxxopts (the C++ modules' parser, src/module.h:75-104) accepts `--opt=value` next to `--opt value`: the former is rewritten into the
+// latter before a module's own loop reads the command line.  `store` owns the strings `out` points into.
+inline void split_equals(int argc, char** argv, std::vector<std::string>& store, std::vector<char*>& out) {
+    store.clear(); out.clear();
+    for (int i = 0; i < argc; i++) {
+        const std::string t = argv[i];
+        const size_t eq = t.find('=');
+        if (i > 0 && t.size() > 2 && t[0] == '-' && t[1] == '-' && eq != std::string::npos) { store.push_back(t.substr(0, eq)); store.push_back(t.substr(eq + 1)); }
+        else store.push_back(t);
+    }
+    for (auto& t : store) out.push_back(const_cast<char*>(t.c_str()));
+}
+
 // "D[,D...]": one entry per device group (an entry may repeat); false: not a list of non-negative integers
 inline bool parse_device_list(const char* v, std::vector<int>& out) {
     out.clear();

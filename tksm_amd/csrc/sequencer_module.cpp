@@ -96,15 +96,19 @@ bool gzip_member(const uint8_t* d, size_t n, std::vector<uint8_t>& out) {
 struct Writer {
     int fd = -1; bool gz = false, fastq = false, wrote = false;
     bool positional = false;                             // a regular file: the workers write their batches at their offsets (pwrite)
-    bool open(const std::string& path) {                 // get_output_file, py/sequence.py:291-300
+    void classify(const std::string& path) {             // get_output_file, py/sequence.py:291-300: the NAME decides format and compression
         std::string p = path;
+        gz = false;
         if (p.size() >= 3 && p.compare(p.size() - 3, 3, ".gz") == 0) { gz = true; p.resize(p.size() - 3); }
+        auto ends = [&](const char* s) { size_t n = strlen(s); return p.size() >= n && p.compare(p.size() - n, n, s) == 0; };
+        fastq = ends(".fastq") || ends(".fq");
+    }
+    bool open(const std::string& path) {                 // creates / truncates: only once devices, references, models and the input are usable
+        classify(path);
         fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
         if (fd < 0) return false;
         struct stat st;
         positional = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
-        auto ends = [&](const char* s) { size_t n = strlen(s); return p.size() >= n && p.compare(p.size() - n, n, s) == 0; };
-        fastq = ends(".fastq") || ends(".fq");
         return true;
     }
     bool write(const uint8_t* d, size_t n) {             // appends; for .gz outputs the bytes are finished gzip members
@@ -206,11 +210,61 @@ struct Finished { int worker = -1; uint64_t bytes[2] = {0, 0}; uint64_t n_reads 
 
 }  // namespace
 
+// The reference's parser is argparse with its defaults (py/sequence.py:35-40, :124): a long option may be abbreviated to any
+// unambiguous prefix, `--opt=value` and a value glued to a short option (`-t8`) are accepted.  The command line is rewritten into
+// the plain `--opt value` form the loop below reads; `glued` marks values that came with their option (for -r/--references,
+// nargs="+": an explicit value is the option's only one).
+struct OptSpec { const char* name; bool takes_value; };
+const OptSpec LONG_OPTS[] = {
+    {"--help", false}, {"--input", true}, {"--references", true}, {"--badread", true}, {"--perfect", true}, {"--skip-qual-compute", false},
+    {"--output-format", true}, {"--threads", true}, {"--badread-identity", true}, {"--badread-error-model", true},
+    {"--badread-qscore-model", true}, {"--badread-tail-model", true}, {"--list", false}, {"--seed", true}, {"--devices", true},
+    {"--batch-bytes", true}, {"--in-flight", true}, {"--pcr-cycles", true}, {"--pcr-molecule-count", true}, {"--pcr-error-rate", true},
+    {"--pcr-efficiency", true}, {"--pcr-preset", true}, {"--pcr-slice-molecules", true}, {"--truncate-normal", true},
+    {"--truncate-lognormal", true}, {"--truncate-kde-model", true}, {"--truncate-always-end", false},
+    {"--truncate-kde-models-length", false}, {"--verbosity", true}, {"--log-file", true}};
+const char SHORT_WITH_VALUE[] = "iroOts";
+
+int normalise_args(int argc, char** argv, std::vector<std::string>& out, std::vector<char>& glued) {
+    out.clear(); glued.clear();
+    auto put = [&](const std::string& t, bool g) { out.push_back(t); glued.push_back(g ? 1 : 0); };
+    if (argc > 0) put(argv[0], false);
+    for (int i = 1; i < argc; i++) {
+        const std::string t = argv[i];
+        if (t.size() > 2 && t[0] == '-' && t[1] == '-') {
+            const size_t eq = t.find('=');
+            const std::string name = t.substr(0, eq);
+            const OptSpec* hit = nullptr; std::string could;
+            int n_hit = 0;
+            for (const OptSpec& o : LONG_OPTS) if (name == o.name) { hit = &o; n_hit = 1; break; }
+            if (!hit)
+                for (const OptSpec& o : LONG_OPTS)
+                    if (strncmp(o.name, name.c_str(), name.size()) == 0) { hit = &o; n_hit++; could += (could.empty() ? "" : ", ") + std::string(o.name); }
+            if (n_hit > 1) { usage(stderr); fprintf(stderr, "sequence: error: ambiguous option: %s could match %s\n", name.c_str(), could.c_str()); return 2; }
+            if (n_hit == 0) { put(t, false); continue; }                       // the loop reports it as unrecognized
+            put(hit->name, false);
+            if (eq != std::string::npos) {
+                if (!hit->takes_value) { usage(stderr); fprintf(stderr, "sequence: error: argument %s: ignored explicit argument '%s'\n", hit->name, t.substr(eq + 1).c_str()); return 2; }
+                put(t.substr(eq + 1), true);
+            }
+        } else if (t.size() > 2 && t[0] == '-' && t[1] != '-' && strchr(SHORT_WITH_VALUE, t[1])) {
+            put(t.substr(0, 2), false);
+            put(t.substr(t[2] == '=' ? 3 : 2), true);
+        } else put(t, false);
+    }
+    return 0;
+}
+
 class Sequencer_module::impl {
     int argc; char** argv;
     Args a;
+    std::vector<std::string> norm; std::vector<char> glued; std::vector<char*> norm_argv;
 
     int parse() {
+        if (int rc = normalise_args(argc, argv, norm, glued)) return rc;
+        norm_argv.clear();
+        for (auto& t : norm) norm_argv.push_back(const_cast<char*>(t.c_str()));
+        const int argc = (int)norm_argv.size(); char** const argv = norm_argv.data();
         auto need = [&](int& i) -> const char* { if (i + 1 >= argc) { usage(stderr); fprintf(stderr, "sequence: error: argument %s: expected one argument\n", argv[i]); return nullptr; } return argv[++i]; };
         for (int i = 1; i < argc; i++) {
             std::string o = argv[i];
@@ -218,7 +272,8 @@ class Sequencer_module::impl {
             if (o == "-h" || o == "--help") a.help = true;
             else if (o == "-i" || o == "--input") { if (!(v = need(i))) return 2; a.input = v; }
             else if (o == "-r" || o == "--references") {
-                while (i + 1 < argc && argv[i + 1][0] != '-') a.references.push_back(argv[++i]);
+                if (i + 1 < argc && glued[(size_t)i + 1]) a.references.push_back(argv[++i]);
+                else while (i + 1 < argc && argv[i + 1][0] != '-') a.references.push_back(argv[++i]);
                 if (a.references.empty()) { usage(stderr); fprintf(stderr, "sequence: error: argument -r/--references: expected at least one argument\n"); return 2; }
             }
             else if (o == "-o" || o == "--badread") { if (!(v = need(i))) return 2; a.badread = v; }
@@ -351,13 +406,12 @@ public:
         if (a.threads < 1) a.threads = 1;
 
         const auto t_begin = std::chrono::steady_clock::now();
+        // the output NAMES decide what is computed (py/sequence.py:349-353); the files are created below, after the devices, references,
+        // models and the input have turned out usable (a run that fails before that leaves no empty output behind)
         Writer wb, wp;
         bool compute_q = false;
-        if (!a.badread.empty()) {
-            if (!wb.open(a.badread)) return die("Error: cannot open " + a.badread);
-            compute_q = !a.skip_qual && wb.fastq;
-        }
-        if (!a.perfect.empty() && !wp.open(a.perfect)) return die("Error: cannot open " + a.perfect);
+        if (!a.badread.empty()) { wb.classify(a.badread); compute_q = !a.skip_qual && wb.fastq; }
+        if (!a.perfect.empty()) wp.classify(a.perfect);
         if (!a.badread.empty() && !a.perfect.empty())
             log.log(Logger::WARN, "with both -o and --perfect the reference writes the badread sequence (quals 'K') to the "
                                   "--perfect file (py/sequence.py:317-319); reproduced here");
@@ -442,6 +496,8 @@ public:
 
         FILE* in = fopen(a.input.c_str(), "rb");
         if (!in) { destroy_all(); return die("Error: cannot open " + a.input); }
+        if (!a.badread.empty() && !wb.open(a.badread)) { fclose(in); destroy_all(); return die("Error: cannot open " + a.badread); }
+        if (!a.perfect.empty() && !wp.open(a.perfect)) { fclose(in); wb.close(); destroy_all(); return die("Error: cannot open " + a.perfect); }
         ChunkQueue queue;
         queue.cap = (size_t)n_workers;
         std::vector<std::unique_ptr<ParsedQueue>> pq;
@@ -454,7 +510,9 @@ public:
             if (!failed.exchange(true)) first_error = msg;
             queue.close();
             for (auto& q2 : pq) q2->close();
-            done_cv.notify_all();
+            // (under done_m: a writer that has just evaluated its predicate -- `failed` still false -- holds done_m until it blocks, so the
+            // notification cannot fall between its check and its wait)
+            { std::lock_guard<std::mutex> dl(done_m); done_cv.notify_all(); }
             // a worker may be waiting for the writer to release its host buffers: nobody will (the writer stops at the
             // first error), so wake it -- its wait also checks `failed`
             for (auto& W : workers) { std::lock_guard<std::mutex> wl(W->m); W->cv.notify_all(); }

@@ -306,6 +306,14 @@ class Sequencer:
     def set_timing(self, on=True):
         self._chk(self._lib.tksmseq_set_timing(self._ctx, 1 if on else 0))
 
+    def run_diagnostics(self):
+        """counts of the last Badread run (tksmseq_run_diagnostics): rounds, reads that took the exact kernel, redo share, fall-backs"""
+        out = (C.c_uint32 * 16)()
+        self._chk(self._lib.tksmseq_run_diagnostics(self._ctx, out))
+        keys = ("rounds", "exact_kernel_reads", "predicted_stragglers", "jobs_14_row_rounds", "jobs_redone_full_width", "fallbacks",
+                "fallback_reasons", "fallbacks_qscore_jobs", "fallbacks_list_pass", "jobs_all_rounds", "band_exits")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
+
     def set_output_buffer(self, ptr, capacity):
         self._chk(self._lib.tksmseq_set_output_buffer(self._ctx, C.c_void_p(ptr) if ptr else None, capacity))
 

@@ -93,6 +93,30 @@ def make_molecules(rs, contig_lens, n, mean_len=1000, sd_len=200, kind="bulk", i
                 n_intervals_per_read=ivl_count, n_mods=len(mods))
 
 
+def take(m, sel):
+    """The molecules `sel` (indices, in that order) of a make_molecules() set as a set of their own: intervals and substitutions
+    regathered so that every interval's substitutions stay one contiguous run (the batch layout's rule); id and literal pools are
+    shared with the source.  What a rank's round-robin shard of a common set is built with."""
+    sel = np.asarray(sel, np.int64)
+    reads = m["reads"][sel]
+    cnt, beg = reads[:, 1].astype(np.int64), reads[:, 0].astype(np.int64)
+    n_iv = int(cnt.sum())
+    new_begin = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64) if len(sel) else np.zeros(0, np.int64)
+    iv_idx = np.repeat(beg - new_begin, cnt) + np.arange(n_iv)
+    iv = m["intervals"][iv_idx].copy()
+    mb_all = (m["intervals"][:, 3] & 0x7fffffff).astype(np.int64)
+    me_all = np.concatenate([mb_all[1:], [len(m["mods"])]])
+    mcnt = (me_all - mb_all)[iv_idx]
+    new_mb = np.concatenate([[0], np.cumsum(mcnt)[:-1]]).astype(np.int64) if n_iv else np.zeros(0, np.int64)
+    mod_idx = np.repeat(mb_all[iv_idx] - new_mb, mcnt) + np.arange(int(mcnt.sum()))
+    mods = m["mods"][mod_idx] if len(m["mods"]) else m["mods"]
+    iv[:, 3] = (iv[:, 3] & np.uint32(0x80000000)) | new_mb.astype(np.uint32)
+    out = dict(m)
+    out.update(reads=np.stack([new_begin, cnt], 1).astype(np.uint32), intervals=iv, mods=mods, ids=m["ids"][sel], raw_len=m["raw_len"][sel],
+               n_intervals_per_read=cnt, n_mods=len(mods))
+    return out
+
+
 def algorithmic_bytes(m, records_bytes):
     """B = B_mdf + B_ref + B_out per launch.
     B_mdf = 8 + 16 S + 8 M per read (+ literal bytes / 4), B_ref = ceil(L / 4), B_out = the emitted record bytes."""

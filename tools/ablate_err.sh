@@ -4,6 +4,8 @@ set -e
 R=$PWD
 export TKSMSEQ_LIB=$R/tksm_amd/libtksmseq_prof.so
 cd /tmp && export TMPDIR=/tmp
+# the queue configuration of the headline run (bench.py / the CLI set it themselves, but under rocprofv3 --pmc the runtime starts before the program does)
+export GPU_MAX_HW_QUEUES=16
 for a in "$@"; do
   export TKSMSEQ_ABLATE=$a
   timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ab$a -- python $R/tools/quick_stage_times.py 1310720 > $R/gpurun_out/ab$a.log 2>&1 || true

@@ -7,6 +7,8 @@ R=$PWD
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# the queue configuration of the headline run (bench.py / the CLI set it themselves, but under rocprofv3 --pmc the runtime starts before the program does)
+export GPU_MAX_HW_QUEUES=16
 python $R/bench.py --no-e2e > $out/bench.json 2> $out/bench.err
 echo bench done >> $out/progress.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python $R/bench.py --no-cpu-baseline --no-e2e --no-side-legs > $out/bench_under_rocprof.json 2> $out/stats.err

@@ -1,6 +1,7 @@
 #!/bin/bash
 # per-round kernel durations of one 2M-read step (rocprofv3 kernel trace); usage: bash tools/round_profile.sh [B]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export GPU_MAX_HW_QUEUES=16     # the queue configuration of the headline run
 B=${1:-2097152}
 rm -rf gpurun_out/rp
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/rp -- python tools/quick_stage_times.py $B > gpurun_out/rp.log 2>&1

@@ -4,6 +4,8 @@ tag=$1; B=${2:-1310720}; shift; shift
 R=$PWD; out=$R/gpurun_out/$tag; mkdir -p $out
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
+# the queue configuration of the headline run (bench.py / the CLI set it themselves, but under rocprofv3 --pmc the runtime starts before the program does)
+export GPU_MAX_HW_QUEUES=16
 TKSMSEQ_VERBOSE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/tools/quick_stage_times.py $B > $out/trace.log 2>&1
 cd $R
 cp $out/trace/*/*kernel_stats.csv $out/kernel_stats.csv
