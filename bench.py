@@ -98,18 +98,20 @@ def cpu_baseline(n_reads, mean_len, seconds_budget=20.0):
             "gbases_per_s": sum(r[1] for r in res) / wall / 1e9}
 
 
-def e2e_leg(n_molecules):
-    """`tksm sequence` on files, wall time of the whole process (start, device, reference packing, models, MDF parse, PCIe,
-    FASTQ written to a file): a fixed file of n_molecules bulk molecules (blocks of 1 M distinct molecules) on a 4 x 8 Mb genome.
-    Three destinations, so that the bound is visible: the temporary directory (the headline: page cache of the box's file system),
-    /dev/shm (tmpfs) and /dev/null (no file system at all: process start + device + parse + PCIe ceiling)."""
+def e2e_leg(n_molecules, n_stream):
+    """`tksm sequence` on files -- PCIe and host I/O inclusive, never `value`.  Two runs of the binary on a 4 x 8 Mb genome (MDF text made of
+    blocks of 1 M distinct molecules):
+      * n_molecules (8 M) into a FASTQ FILE in the temporary directory, wall time of the whole process (start, device, reference packing,
+        models, MDF parse, PCIe, 16 GB written): `reads_per_s`.  Bounded by the box's single-file write rate (11 - 13.5 GB/s = ~5.5 M reads/s
+        whatever the device does, profiles/r03_fs_write_probe.log);
+      * n_stream (32 M) into /dev/null (a character device: the ordered-writer path, no file system), with the CLI's own clocks
+        (TKSMSEQ_STATS_FILE): `to_dev_null.stream_reads_per_s` = reads / (first chunk read -> last record byte written), the per-stage
+        seconds summed over each stage's threads and the rates that follow from them."""
     import shutil
     import subprocess
     import tempfile
     from tksm_amd import synthetic
     exe = os.path.join(ROOT, "tksm_amd", "tksm")
-    # files in the temporary directory (page cache of the box's overlay file system) when it has room, else in /dev/shm: three
-    # threads writing 16 GB reach 6 - 8 GB/s there and 3 - 4 GB/s in tmpfs
     base = tempfile.gettempdir()
     if shutil.disk_usage(base).free < 40e9 and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40e9:
         base = "/dev/shm"
@@ -126,42 +128,57 @@ def e2e_leg(n_molecules):
         block = min(n_molecules, 1_000_000)
         m = synthetic.make_molecules(rs, lens, block, 1000, 200)
         text = synthetic.mdf_text(m, [f"chr{c + 1}" for c in range(4)])
-        reps = max(1, n_molecules // block)
-        with open(os.path.join(d, "mols.mdf"), "w") as f:
-            for _ in range(reps):
-                f.write(text)
-        n = block * reps
+
+        def mdf_file(name, n):
+            reps = max(1, n // block)
+            with open(os.path.join(d, name), "w") as f:
+                for _ in range(reps):
+                    f.write(text)
+            return block * reps
+        n = mdf_file("mols.mdf", n_molecules)
         env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
         cores = host_cores()
-        def one(out_path):
-            cmd = [exe, "sequence", "-i", os.path.join(d, "mols.mdf"), "-r", os.path.join(d, "ref.fa"), "-o", out_path,
-                   "-t", str(max(1, cores // 2)), "--verbosity", "ERROR"]
+        threads = max(1, cores // 2)
+
+        def one(mdf, out_path, stats=None):
+            cmd = [exe, "sequence", "-i", os.path.join(d, mdf), "-r", os.path.join(d, "ref.fa"), "-o", out_path, "-t", str(threads), "--verbosity", "ERROR"]
+            e = dict(env, TKSMSEQ_STATS_FILE=stats) if stats else env
             t0 = time.time()
-            r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+            r = subprocess.run(cmd, capture_output=True, text=True, env=e)
             dt = time.time() - t0
             return (None, r.stderr[-300:]) if r.returncode else (dt, None)
-        dt, err = one(os.path.join(d, "out.fastq"))
+        dt, err = one("mols.mdf", os.path.join(d, "out.fastq"))
         if dt is None:
             return {"reads_per_s": None, "error": err}
         res = {"reads_per_s": n / dt, "molecules": n, "wall_s": dt, "mdf_bytes": os.path.getsize(os.path.join(d, "mols.mdf")),
                "fastq_bytes": os.path.getsize(os.path.join(d, "out.fastq")), "files_on": base,
-               "command": "tksm sequence -i mols.mdf -r ref.fa -o out.fastq -t %d (Badread + q-scores, nanopore2020)" % max(1, cores // 2)}
+               "bound": "one FASTQ file: the box's file system takes 11 - 13.5 GB/s into a single file (profiles/r03_fs_write_probe.log), ~5.5 M reads/s before any fixed cost",
+               "command": "tksm sequence -i mols.mdf -r ref.fa -o out.fastq -t %d (Badread + q-scores, nanopore2020)" % threads}
         os.remove(os.path.join(d, "out.fastq"))
-        # the same run with the records going nowhere (a character device: the ordered-writer path) and to tmpfs.  A pause in front of
-        # each: a process that starts right after another one released its ~100 GiB of device memory (and while the page cache still
-        # writes the previous leg's 16 GB back) takes 1.5 - 2 x as long (tools/e2e_ab.sh)
+        os.remove(os.path.join(d, "mols.mdf"))
+        # the streaming rate: more molecules, records into a character device, the CLI's own clocks.  A pause in front: a process that
+        # starts right after another one released its ~100 GiB of device memory (and while the page cache still writes the previous
+        # leg's 16 GB back) takes 1.5 - 2 x as long (tools/e2e_ab.sh)
+        n2 = mdf_file("stream.mdf", n_stream)
         os.symlink("/dev/null", os.path.join(d, "null.fastq"))
         time.sleep(8)
-        dt0, _ = one(os.path.join(d, "null.fastq"))
-        res["to_dev_null"] = {"reads_per_s": n / dt0 if dt0 else None, "wall_s": dt0}
-        if base != "/dev/shm" and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40e9:
-            shm = tempfile.mkdtemp(prefix="tksm_e2e_", dir="/dev/shm")
-            try:
-                time.sleep(8)
-                dt1, _ = one(os.path.join(shm, "out.fastq"))
-                res["to_dev_shm"] = {"reads_per_s": n / dt1 if dt1 else None, "wall_s": dt1}
-            finally:
-                shutil.rmtree(shm, ignore_errors=True)
+        stats = os.path.join(d, "stats.json")
+        dt0, err0 = one("stream.mdf", os.path.join(d, "null.fastq"), stats)
+        leg = {"molecules": n2, "wall_s": dt0, "reads_per_s": n2 / dt0 if dt0 else None, "error": err0}
+        if dt0 and os.path.exists(stats):
+            st = json.load(open(stats))
+            leg["stream_s"] = st["stream_s"]
+            leg["setup_s"] = st["setup_s"]
+            leg["stream_reads_per_s"] = st["reads"] / st["stream_s"]
+            leg["stream_record_GBps"] = st["record_bytes"] / st["stream_s"] / 1e9
+            leg["stage_seconds_summed_over_threads"] = {k: st[k] for k in ("read_count_s", "parse_s", "run_s", "device_copy_s", "d2h_wait_s", "write_s", "wait_for_writer_s")}
+            safe = lambda x, y: (x / y) if y else None
+            leg["rates"] = {"read_and_count_mdf_GBps": safe(st["mdf_bytes"] / 1e9, st["read_count_s"]),
+                            "parse_and_upload_mdf_GBps_per_parser": safe(st["mdf_bytes"] / 1e9, st["parse_s"]), "parsers": st["parsers"], "parse_threads_each": st["parse_threads"],
+                            "device_Mreads_per_s_per_context": safe(st["reads"] / 1e6, st["run_s"]), "contexts": st["workers"],
+                            "d2h_GBps_per_writer_while_waiting": safe(st["d2h_bytes"] / 1e9, st["d2h_wait_s"]),
+                            "write_GBps_per_writer": safe(st["record_bytes"] / 1e9, st["write_s"]), "writers": st["workers"]}
+        res["to_dev_null"] = leg
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -209,7 +226,8 @@ def main():
                     help="N > 1: gather = exact-size send / recv of every rank's records to rank 0 + device interleave (north_star); "
                          "offsets = all_gather of record lengths only, every rank learns its records' final file offsets (tksm_amd/ordering.py)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the short legs on the other workloads (scRNA-like, PCR-like, lognormal lengths)")
-    ap.add_argument("--e2e-molecules", type=int, default=8_000_000)
+    ap.add_argument("--e2e-molecules", type=int, default=8_000_000, help="end-to-end leg into a FASTQ file")
+    ap.add_argument("--e2e-stream-molecules", type=int, default=32_000_000, help="end-to-end leg into /dev/null with the CLI's stage clocks")
     ap.add_argument("--order-check-reads", type=int, default=32768,
                     help="N > 1 (or the forced exchange): after the timed steps every rank runs its round-robin shard of ONE common set of "
                          "N x this many molecules through the same exchange, and rank 0 compares the ordered stream with its own "
@@ -584,7 +602,7 @@ def main():
         ctxs.clear()
         torch.cuda.empty_cache()
         try:
-            e2e = e2e_leg(args.e2e_molecules)
+            e2e = e2e_leg(args.e2e_molecules, args.e2e_stream_molecules)
         except Exception as e:                   # the end-to-end leg is an extra: it never costs the bench line
             e2e = {"reads_per_s": None, "error": repr(e)[:300]}
         out["e2e_reads_per_s"] = e2e["reads_per_s"]

@@ -40,6 +40,10 @@
  *   TKSMSEQ_BUCKETS=N      length buckets of the last visit's launches (default 16)
  *   TKSMSEQ_TAIL_CUT=N     diagnostic: once fewer than N reads are left, they finish in the wave-wide kernel (default 0: off)
  *   TKSMSEQ_FULL_POOL_MB=M memory for the unbanded alignment fallback of the wave-wide kernel (default 1024)
+ *   TKSMSEQ_STATS_FILE=P   (CLI) `tksm sequence` writes one JSON object with the run's stage clocks to P: reads, batches, MDF bytes in, record
+ *                          bytes out, seconds of set-up (devices, references, models), of streaming (first chunk read -> last record byte
+ *                          written) and, summed over the threads of a stage, of parsing, running, device-side staging copies, waiting for
+ *                          device-to-host pieces, write calls, waiting for the writer, reading + counting (bench.py's end-to-end leg)
  *   TKSMSEQ_PIECE_BYTES=B  (CLI) size of the page-locked pieces a batch's records pass through (default 64 MB; the tests use 4 KB)
  *   TKSMSEQ_ABLATE=N       only in the diagnostic build (`make ablate`, -DTKSM_ABLATE): timing experiments on the last visit's q-score loop
  *                          (40 - 45, tools/ablate_err.sh) and k_loop's prologue (33)
@@ -277,11 +281,16 @@ int tksmseq_interleave_records(tksmseq_ctx* ctx, int n_ranks, const void* const*
  * probability) substitutions at distinct positions, bases uniform in "ACTG", on top of its template's; each copy is
  * written with probability target_count / ((1 + efficiency)^cycles x molecules); id = template id + "." + cycle.
  * More than 2 x target_count input molecules: 2 x target_count of them are used (:217-220). */
+/* flags of both transforms.  TKSMSEQ_MOL_NO_COMMENTS: the output batch carries no header comments.  Comments ("truncated=...", "TR=...",
+ * the template's own) are host-side text per molecule; a caller whose next step is tksmseq_run -- which never reads them, like the
+ * reference's Seq (mdf_generator, py/sequence.py:206-213, drops the comment column) -- saves that work: the chained `tksm sequence
+ * --pcr-... --truncate-...` sets it, `tksm pcr` / `tksm truncate` (MDF text out) do not. */
+#define TKSMSEQ_MOL_NO_COMMENTS 1
 typedef struct {
     uint64_t seed;
     uint64_t target_count;        /* --molecule-count */
     int32_t cycles;               /* --cycles (at most 56) */
-    int32_t reserved;
+    int32_t flags;                /* TKSMSEQ_MOL_NO_COMMENTS or 0 */
     double error_rate;            /* --error-rate, before the 4/3 adjustment of src/pcr.cpp:36 */
     double efficiency;            /* --efficiency */
     /* the copies of the input molecules template_begin <= u < template_end only (0, 0: all of them).  The drop ratio and the
@@ -310,7 +319,7 @@ typedef struct {
     int32_t mode;                    /* TKSMSEQ_TRC_* */
     int32_t always_end;              /* --always-end */
     int32_t kde_models_length;       /* --kde-models-length */
-    int32_t reserved;
+    int32_t flags;                   /* TKSMSEQ_MOL_NO_COMMENTS or 0 */
     double mu, sigma;                /* --normal / --lognormal */
     const char* kde_model_path;      /* --kde-model */
 } tksmseq_trc_params;

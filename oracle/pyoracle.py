@@ -79,6 +79,15 @@ _lib.oracle_sequence_fragment.restype = C.c_int
 _lib.oracle_sequence_fragment.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p,
                                           C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(FragStats)]
+_lib.oracle_set_qscore_alignment_variant.argtypes = [C.c_int]
+
+
+def set_qscore_alignment_variant(v):
+    """TEST-ONLY switch of the q-score alignment's path choice (tksm_oracle.c: 0 shipped, 1 opposite indel preference, 2 edlib as
+    published incl. its Hirschberg branch, 3 shipped order without the band); process-wide."""
+    _lib.oracle_set_qscore_alignment_variant(int(v))
+
+
 _lib.oracle_format_record.restype = C.c_int64
 _lib.oracle_format_record.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p,
                                       C.c_int64, C.c_int64, C.c_double, C.c_char_p, C.c_int]

@@ -322,6 +322,98 @@ static int full_align(const uint8_t* F, int n, const uint8_t* N, int m, int mode
     return dist;
 }
 
+/* ------------------------------------------------------------------ TEST-ONLY variants of the q-score alignment
+ * (tests/test_edlib_hole.py, tools/edlib_hole.py): how far do the q-scores and the printed identity move when co-optimal
+ * paths are chosen differently?  The shipped specification keeps edlib's TRACEBACK order at every size; the real edlib
+ * (python-edlib, not in the reference tree) switches to Hirschberg's divide and conquer once its alignment data reach
+ * 1 MB -- (2 * 8 + 4) * ceil(query / 64) * target + 2 * 4 * target bytes -- i.e. for the q-score alignment
+ * (py/tksm_badread.py:611-613: query = read, target = fragment) of every read above ~1.77 kb.  Restated from edlib's
+ * published source (obtainAlignment / obtainAlignmentHirschberg): the target is cut in half, the forward scores of the
+ * left half's last column and the reverse scores of the right half's first column are summed, the FIRST query row
+ * 0 .. n-2 (0-based cell row; then row -1, then row n-1) whose sum equals the distance is where the path crosses, and
+ * both parts recurse through the same size rule.
+ *   variant 0  shipped: guided band, traceback order read-only ('I'), fragment-only ('D'), diagonal
+ *   variant 1  the opposite indel preference (fragment-only first), unbanded
+ *   variant 2  edlib as published: traceback below the 1 MB rule, Hirschberg above it, unbanded
+ *   variant 3  the shipped order, unbanded (the control for 1 and 2)
+ * Cigar letters as edlib.align(read, fragment) writes them: 'I' read-only, 'D' fragment-only. */
+static int g_qalign_variant = 0;
+void oracle_set_qscore_alignment_variant(int v) { g_qalign_variant = v; }
+
+/* q = read (edlib's query, rows), t = fragment (edlib's target, columns); pref 0: up ('I') before left ('D'), 1: left first */
+static void nw_trace_pref(const uint8_t* q, int n, const uint8_t* t, int m, int pref, uint8_t* ops, int* nops) {
+    size_t W = (size_t)m + 1;
+    int32_t* H = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1) * W);
+    for (int j = 0; j <= m; j++) H[j] = j;
+    for (int i = 1; i <= n; i++) {
+        int32_t* r = H + (size_t)i * W; const int32_t* p = r - W;
+        r[0] = i;
+        for (int j = 1; j <= m; j++) {
+            int32_t d = p[j - 1] + (q[i - 1] != t[j - 1]), u = p[j] + 1, l = r[j - 1] + 1;
+            int32_t v = d < u ? d : u;
+            r[j] = v < l ? v : l;
+        }
+    }
+    int i = n, j = m, k = 0;
+    while (i > 0 || j > 0) {
+        int32_t cur = H[(size_t)i * W + j];
+        int upok = i > 0 && H[(size_t)(i - 1) * W + j] + 1 == cur;
+        int leftok = j > 0 && H[(size_t)i * W + j - 1] + 1 == cur;
+        int take = pref == 0 ? (upok ? 0 : (leftok ? 1 : 2)) : (leftok ? 1 : (upok ? 0 : 2));
+        if (take == 0) { ops[k++] = 'I'; i--; }
+        else if (take == 1) { ops[k++] = 'D'; j--; }
+        else { ops[k++] = (H[(size_t)(i - 1) * W + j - 1] == cur) ? '=' : 'X'; i--; j--; }
+    }
+    for (int a = 0, b = k - 1; a < b; a++, b--) { uint8_t x = ops[a]; ops[a] = ops[b]; ops[b] = x; }
+    *nops = k;
+    free(H);
+}
+
+/* out[i] = edit distance of q[0, i) and t[0, m) (rev: of the last i query bytes and the last m target bytes), i = 0 .. n */
+static void nw_last_column(const uint8_t* q, int n, const uint8_t* t, int m, int rev, int32_t* out) {
+    for (int i = 0; i <= n; i++) out[i] = i;
+    for (int j = 1; j <= m; j++) {
+        uint8_t tc = rev ? t[m - j] : t[j - 1];
+        int32_t diag = out[0];
+        out[0] = j;
+        for (int i = 1; i <= n; i++) {
+            uint8_t qc = rev ? q[n - i] : q[i - 1];
+            int32_t d = diag + (qc != tc), u = out[i - 1] + 1, l = out[i] + 1;
+            diag = out[i];
+            int32_t v = d < u ? d : u;
+            out[i] = v < l ? v : l;
+        }
+    }
+}
+
+static void edlib_like_path(const uint8_t* q, int n, const uint8_t* t, int m, uint8_t* ops, int* nops, int* n_splits) {
+    if (n == 0 || m == 0) {                                    /* edlib: one sequence empty */
+        for (int a = 0; a < n + m; a++) ops[a] = n == 0 ? 'D' : 'I';
+        *nops = n + m;
+        return;
+    }
+    long long blocks = (n + 63) / 64;
+    long long data = (2ll * 8 + 4) * blocks * m + 2ll * 4 * m;
+    if (data < 1024 * 1024) { nw_trace_pref(q, n, t, m, 0, ops, nops); return; }
+    (*n_splits)++;
+    int lw = m / 2, rw = m - lw;
+    int32_t* fwd = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1) * 2);
+    int32_t* bwd = fwd + n + 1;
+    nw_last_column(q, n, t, lw, 0, fwd);                      /* fwd[i]: q[0, i) vs t[0, lw) */
+    nw_last_column(q, n, t + lw, rw, 1, bwd);                 /* bwd[x]: last x of q vs t[lw, m) */
+    int32_t best = INF;
+    for (int i = 0; i <= n; i++) { int32_t v = fwd[i] + bwd[n - i]; if (v < best) best = v; }
+    int cut = -1;
+    for (int i = 1; i <= n - 1 && cut < 0; i++) if (fwd[i] + bwd[n - i] == best) cut = i;    /* cell rows 0 .. n-2 */
+    if (cut < 0 && fwd[0] + bwd[n] == best) cut = 0;          /* row -1 */
+    if (cut < 0) cut = n;                                     /* row n-1 */
+    free(fwd);
+    int k1 = 0, k2 = 0;
+    edlib_like_path(q, cut, t, lw, ops, &k1, n_splits);
+    edlib_like_path(q + cut, n - cut, t + lw, rw, ops + k1, &k2, n_splits);
+    *nops = k1 + k2;
+}
+
 /* join new bases of window [p0,p0+n) into buf; owner[j] = window-relative slot of joined base j; returns joined length */
 static int join_window(const fstate* s, int p0, int n, uint8_t* buf, uint32_t* owner) {
     int m = 0;
@@ -543,7 +635,15 @@ int oracle_sequence_fragment(const uint8_t* raw, int raw_len, double target_iden
         /* get_qscores :607-655; cigar of edlib.align(seq, frag): 'I' = read-only base, 'D' = fragment-only */
         uint8_t* ops = (uint8_t*)malloc((size_t)L + (size_t)m + 8);
         int nops = 0, mt = 0, cols = 0;
-        if (use_full) full_align(s.frag, L, joined, m, 1, &mt, &cols, ops, &nops);
+        if (g_qalign_variant) {                                   /* test-only: see oracle_set_qscore_alignment_variant */
+            int splits = 0;
+            if (g_qalign_variant == 1) nw_trace_pref(joined, m, s.frag, L, 1, ops, &nops);
+            else if (g_qalign_variant == 2) edlib_like_path(joined, m, s.frag, L, ops, &nops, &splits);
+            else nw_trace_pref(joined, m, s.frag, L, 0, ops, &nops);
+            for (int a = 0; a < nops; a++) mt += ops[a] == '=';
+            cols = nops;
+            st->pad0 = splits;
+        } else if (use_full) full_align(s.frag, L, joined, m, 1, &mt, &cols, ops, &nops);
         else {
             uint8_t* trace = (uint8_t*)malloc((size_t)(m + 1) * 64);
             int32_t* ttop = (int32_t*)malloc(sizeof(int32_t) * ((size_t)m + 1));

@@ -199,6 +199,47 @@ int main() {
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
+def test_chunk_reader_cuts_whole_molecules_and_scans_each_byte_once(tmp_path):
+    """tkmod::ChunkReader (csrc/module_log.h; the same boundary search serves `tksm sequence`'s reader): pieces of about `bytes` that
+    end in front of a molecule header, their concatenation is the input -- for piece sizes below a molecule's size too (a molecule
+    larger than the piece size is scanned once across its refills: the search keeps the position it has covered)."""
+    src = tmp_path / "chunks.cpp"
+    src.write_text(r'''
+#include "module_log.h"
+#include <cstdio>
+#include <string>
+int main(int argc, char** argv) {
+    std::string all, got;
+    for (int m = 0; m < 400; m++) {
+        all += "+mol" + std::to_string(m) + "\t1\tc=+x;\n";
+        const int lines = m == 7 ? 3000 : 1 + m % 5;               // one molecule far larger than the small piece sizes
+        for (int l = 0; l < lines; l++) all += "chr1\t" + std::to_string(100 * l) + "\t" + std::to_string(100 * l + 90) + "\t+\t3A,7+\n";
+    }
+    FILE* f = fopen(argv[1], "wb"); fwrite(all.data(), 1, all.size(), f); fclose(f);
+    const uint64_t sizes[] = {64, 1000, 4096, 1 << 20};
+    for (uint64_t b : sizes) {
+        tkmod::ChunkReader rd; rd.in = fopen(argv[1], "rb"); rd.bytes = b;
+        std::vector<char> piece; got.clear();
+        size_t pieces = 0;
+        while (rd.next(piece)) {
+            if (piece.empty() || piece[0] != '+' || piece.back() != '\n') { std::printf("bad piece at size %llu\n", (unsigned long long)b); return 1; }
+            got.append(piece.begin(), piece.end()); pieces++;
+        }
+        fclose(rd.in);
+        if (got != all) { std::printf("differs at size %llu\n", (unsigned long long)b); return 1; }
+        if (b == (1u << 20) && pieces != 1) return 2;
+        if (b == 64 && pieces < 300) return 3;
+    }
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "chunks"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tksm_amd", "csrc"), "-o", str(exe), str(src)], check=True)
+    r = subprocess.run([str(exe), str(tmp_path / "in.mdf")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_prefetch_entry_points_are_host_only():
     """tksmseq_prefetch_model / tksmseq_prefetch_identity parse into the process-wide store without a context or a device"""
     from tksm_amd import _lib

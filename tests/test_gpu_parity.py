@@ -841,13 +841,15 @@ def test_config3_and_config5_workloads_bit_exact_vs_oracle(seqr, po, oracle_mode
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,sigma", [("bulk", 1_703_936, None), ("scrna", 1_703_936, None), ("bulk", 1_048_576, 0.6)])
-def test_bench_size_batch_sampled_reads_equal_the_oracle(po, oracle_models, kind, n, sigma):
+def test_bench_size_batch_every_record_by_digest(po, oracle_models, kind, n, sigma):
     """BASELINE's full sizes: one batch of 1 703 936 molecules (bench.py's default: every launch shape, buffer size and 32-bit
     offset of the bench; bulk = config 2, scRNA-like with barcode / UMI / polyA literals = config 3) and one of 1 048 576
     molecules with lognormal lengths (median 1 kb, clipped at 16 kb: ragged state rows, the long-read buckets), default settings.
-    Results depend on (seed, global read index) only, so every 499th read (first and last included) is compared with the
-    oracle's record for that index, byte for byte, and the whole stream is checked for its record structure; then the same batch
-    and sample through the --perfect kernel."""
+    EVERY record of the two 1 703 936-molecule batches is compared with the oracle's: tests/golden/bench_digests_<kind>.json holds a
+    SHA-256 per block of 4 096 records, computed by the oracle in the build container (tests/golden/make_bench_digests.py, same
+    generator calls); the device output is hashed the same way.  On top, and for the lognormal batch alone: every 499th read (first
+    and last included) byte for byte against the oracle run here, the record structure of the whole stream, and the same batch and
+    sample through the --perfect kernel."""
     from tksm_amd import synthetic
     from tksm_amd.sequence import Sequencer
     rs = np.random.RandomState(23)
@@ -864,8 +866,40 @@ def test_bench_size_batch_sampled_reads_equal_the_oracle(po, oracle_models, kind
     b = s.batch_from_arrays(m["reads"], m["intervals"], m["mods"], m["literals"], m["literal_pool"], m["ids"], m["id_pool"])
     rec, off = s.run(b, target="badread", fastq=True, compute_qual=True, seed=9).download()
     assert len(off) == n + 1 and int(off[-1]) == len(rec) and rec.count(b"\n") == 4 * n
-    sel = np.unique(np.concatenate([np.arange(0, n, 499), [n - 1]]))
     ident = po.Identities(84.0, 5.5, 99.0)
+    if sigma is None:
+        import hashlib
+        import json
+        gold = json.load(open(os.path.join(GOLDEN, f"bench_digests_{kind}.json")))
+        blk = gold["block_records"]
+        assert (gold["n"], gold["run_seed"], gold["generator_seed"]) == (n, 9, 23) and len(gold["sha256"]) == (n + blk - 1) // blk
+        view = memoryview(rec)
+        bad = [k for k, want in enumerate(gold["sha256"])
+               if hashlib.sha256(view[int(off[k * blk]):int(off[min(n, (k + 1) * blk)])]).hexdigest() != want]
+        # A block that differs is looked at record by record.  The one legitimate cause: the oracle's Beta quantile table here is
+        # scipy's, the device's is the library's own (equal to 1e-10, test_identity_table_matches_scipy) -- a read whose stop rule
+        # `1 - errors / len <= target` falls into that gap (~1e-7 per read) flips.  Such a read must equal the oracle run with the
+        # library's table and have a different target under the two tables; anything else fails.
+        if bad:
+            import sys
+            sys.path.insert(0, os.path.join(GOLDEN))
+            import make_bench_digests as mk
+            lib_ident = po.Identities(84.0, 5.5, 99.0, qtab=s.identity_tables()["qtab"])
+            flagged = []
+            for k in bad[:8]:
+                lo, hi = k * blk, min(n, (k + 1) * blk)
+                mine = mk.block_records(po, ref, m, lo, hi, ident, oracle_models["em"], oracle_models["qm"])
+                lib = mk.block_records(po, ref, m, lo, hi, lib_ident, oracle_models["em"], oracle_models["qm"])
+                for g in range(lo, hi):
+                    got = rec[int(off[g]):int(off[g + 1])]
+                    assert got == lib[g - lo], (kind, g, "differs from the oracle with the library's own quantile table")
+                    if got != mine[g - lo]:
+                        assert ident.get_identity(9, g) != lib_ident.get_identity(9, g), (kind, g)
+                        flagged.append(g)
+            assert len(bad) <= 2 and flagged, (kind, bad[:10])
+            import warnings
+            warnings.warn(f"{kind}: reads {flagged} differ from the golden digests through the 1e-10 gap between the two Beta quantile tables")
+    sel = np.unique(np.concatenate([np.arange(0, n, 499), [n - 1]]))
     text = synthetic.mdf_text({**m, "reads": m["reads"][sel], "ids": m["ids"][sel]}, names)
     mols = list(po.mdf_generator(text.splitlines(keepends=True)))
     assert len(mols) == len(sel)

@@ -424,3 +424,63 @@ def test_chained_cli_equals_the_three_module_route(mo, tmp_path):
     assert r.returncode == 1 and "molecule-count is required!" in r.stderr and "Error rate is required!" in r.stderr
     r = subprocess.run([exe, "sequence", "-i", str(src), "-r", str(fa), "-o", str(s2), "--truncate-normal", "5,1", "--truncate-lognormal", "5,1"], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "Only one of kde-model, normal or lognormal is allowed!" in r.stderr
+
+
+@pytest.mark.gpu
+def test_config5_at_20_million_molecules_does_not_depend_on_slices_or_device_groups(tmp_path):
+    """BASELINE config 5 a tenth of its stated size, as the one command: 20 000 templates -> 20 M molecules (20 PCR cycles, Taq-setting1),
+    lognormal truncation, Badread reads -- ~25 GB of FASTQ streamed into a pipe and hashed on the fly (xxh3-128), never held anywhere.
+    Two runs: slices of 2 M copies on one device group, slices of 700 k copies on two groups (--devices 0,0, two contexts each, three
+    parser threads): the same digest, the same 20 M reads; the host's resident set stays bounded (the reference's PCR holds every
+    molecule in RAM: src/pcr.cpp:215).  The 200 M-molecule run of the same command: tools/config5_200M.py, profiles/r04_config5_200M.log."""
+    import fcntl
+    import re
+    import resource
+    import subprocess
+    import threading
+    import xxhash
+    from tksm_amd import synthetic
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    rs = np.random.RandomState(5)
+    lens = [4_000_000] * 4
+    with open(tmp_path / "ref.fa", "w") as f:
+        for c, L in enumerate(lens):
+            f.write(f">chr{c + 1}\n" + rs.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes().decode() + "\n")
+    m = synthetic.make_molecules(rs, lens, 20_000, 1000, 200)
+    (tmp_path / "in.mdf").write_text(synthetic.mdf_text(m, [f"chr{c + 1}" for c in range(4)]))
+    target = 20_000_000
+
+    def run(tag, *extra):
+        fifo = tmp_path / f"{tag}.fastq"
+        os.mkfifo(fifo)
+        got = {}
+
+        def drain():
+            h, n, lines = xxhash.xxh3_128(), 0, 0
+            with open(fifo, "rb", buffering=0) as p:
+                try:
+                    fcntl.fcntl(p.fileno(), 1031, 1 << 20)            # F_SETPIPE_SZ
+                except OSError:
+                    pass
+                while True:
+                    b = p.read(1 << 24)
+                    if not b:
+                        break
+                    h.update(b); n += len(b); lines += b.count(b"\n")
+            got.update(digest=h.hexdigest(), bytes=n, lines=lines)
+        th = threading.Thread(target=drain, daemon=True)
+        th.start()
+        r = subprocess.run([exe, "sequence", "-i", str(tmp_path / "in.mdf"), "-r", str(tmp_path / "ref.fa"), "-o", str(fifo), "-s", "7", "-t", "3",
+                            "--pcr-cycles", "20", "--pcr-molecule-count", str(target), "--pcr-preset", "Taq-setting1", "--truncate-lognormal", "6.9,0.5", *extra],
+                           capture_output=True, text=True, env=env, timeout=900)
+        th.join(timeout=120)
+        assert r.returncode == 0, r.stderr[-800:]
+        reads = int(re.search(r"Sequencing: (\d+) reads", r.stderr).group(1))
+        return got, reads
+    a, reads_a = run("a", "--pcr-slice-molecules", "2000000", "--devices", "0")
+    b, reads_b = run("b", "--pcr-slice-molecules", "700000", "--devices", "0,0", "--in-flight", "2")
+    assert reads_a == reads_b and 0.97 * target < reads_a < 1.03 * target            # (the written copies are a draw around the target)
+    assert a["lines"] == 4 * reads_a and a["bytes"] > 1000 * reads_a
+    assert a == b
+    assert resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss < 24 * 2**20          # KiB: under 24 GiB of host memory for ~25 GB of output

@@ -39,13 +39,13 @@ class TailModelDesc(C.Structure):            # tksmseq_tail_model
 
 # every symbol include/tksmseq.h declares (checked by tests/test_abi.py without a GPU)
 class PcrParams(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("target_count", C.c_uint64), ("cycles", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("seed", C.c_uint64), ("target_count", C.c_uint64), ("cycles", C.c_int32), ("flags", C.c_int32),
                 ("error_rate", C.c_double), ("efficiency", C.c_double), ("template_begin", C.c_uint64), ("template_end", C.c_uint64)]
 
 
 class TrcParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_molecule_index", C.c_uint64), ("mode", C.c_int32), ("always_end", C.c_int32),
-                ("kde_models_length", C.c_int32), ("reserved", C.c_int32), ("mu", C.c_double), ("sigma", C.c_double),
+                ("kde_models_length", C.c_int32), ("flags", C.c_int32), ("mu", C.c_double), ("sigma", C.c_double),
                 ("kde_model_path", C.c_char_p)]
 
 

@@ -59,6 +59,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     c->own_stream = true;
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     *out = c.release();
+    DevCache::get().context_created();
     return TKSMSEQ_OK;
 }
 
@@ -120,6 +121,7 @@ void tksmseq_destroy(tksmseq_ctx* ctx) {
     if (ctx->h_round) (void)hipHostFree(ctx->h_round);
     if (ctx->h_geo) (void)hipHostFree(ctx->h_geo);
     delete ctx;
+    DevCache::get().context_destroyed();                     // (the last context of the process frees the cached batch buffers)
 }
 
 const char* tksmseq_last_error(const tksmseq_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }

@@ -5,6 +5,8 @@
 #include <chrono>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -28,12 +30,75 @@ using namespace tkh;
 inline double& alloc_seconds() { static thread_local double v = 0.0; return v; }
 inline unsigned& alloc_calls() { static thread_local unsigned v = 0; return v; }
 
+// ---- Cache of device allocations, per process and device, for the buffers that live for ONE batch: the tables of a molecule batch and
+// the temporaries of PCR / truncation.  hipFree waits until the whole device is idle -- every stream of every context: ~100 ms while
+// three batches are in flight -- and a streaming run frees (and allocates) such buffers once per batch: the workers of `tksm sequence`
+// spent a third of their cycle in tksmseq_batch_free (profiles/r04_e2e_stream.log).  A pooled buffer goes back to the cache instead
+// (after the stream that used it has drained -- the caller's duty, see DevBuf::pool_stream) and the next request of about its size takes
+// it.  Bounded: beyond CACHE_LIMIT bytes per device a block is really freed; everything is freed when the last context goes.
+struct DevCache {
+    static constexpr int MAX_DEV = 16;
+    static constexpr size_t CACHE_LIMIT = 12ull << 30;
+    std::mutex m;
+    std::multimap<size_t, void*> blocks[MAX_DEV];
+    size_t cached[MAX_DEV] = {};
+    int live_contexts = 0;
+    static DevCache& get() { static DevCache c; return c; }
+    // sizes in classes of 1/8 of a power of two, so that consecutive batches (a few percent apart) reuse each other's blocks
+    static size_t size_class(size_t bytes) {
+        if (bytes < 4096) return 4096;
+        int top = 63 - __builtin_clzll((unsigned long long)bytes);
+        const size_t step = (size_t)1 << (top > 3 ? top - 3 : 0);
+        return (bytes + step - 1) & ~(step - 1);
+    }
+    void* take(int dev, size_t cap) {                        // a cached block of exactly this class, or nullptr
+        if (dev < 0 || dev >= MAX_DEV) return nullptr;
+        std::lock_guard<std::mutex> l(m);
+        auto it = blocks[dev].find(cap);
+        if (it == blocks[dev].end()) return nullptr;
+        void* p = it->second;
+        blocks[dev].erase(it);
+        cached[dev] -= cap;
+        return p;
+    }
+    void give(int dev, void* p, size_t cap) {
+        if (dev >= 0 && dev < MAX_DEV) {
+            std::lock_guard<std::mutex> l(m);
+            if (live_contexts > 0 && cached[dev] + cap <= CACHE_LIMIT) { blocks[dev].emplace(cap, p); cached[dev] += cap; return; }
+        }
+        (void)hipFree(p);
+    }
+    void context_created() { std::lock_guard<std::mutex> l(m); live_contexts++; }
+    void context_destroyed() {                               // the last one out frees the cache
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> l(m);
+            if (--live_contexts > 0) return;
+            for (int d = 0; d < MAX_DEV; d++) { for (auto& kv : blocks[d]) drop.push_back(kv.second); blocks[d].clear(); cached[d] = 0; }
+        }
+        for (void* p : drop) (void)hipFree(p);
+    }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     bool owned = true;                     // false: a view of another context's buffer (tksmseq_clone), read-only
-    ~DevBuf() { if (p && owned) (void)hipFree(p); }
-    void borrow(const DevBuf& o) { if (p && owned) (void)hipFree(p); p = o.p; cap = o.cap; owned = false; }
+    // pooled: allocations come from / go back to DevCache.  Whoever lets go of a pooled buffer must know that no queued work still
+    // uses it: pool_stream, if set, is drained first (the temporaries of a call); the tables of a batch are released by
+    // tksmseq_batch_free, which drains the stream of the context that ran the batch.
+    bool pooled = false;
+    hipStream_t pool_stream = nullptr;
+    int dev = -1;
+    void release() {
+        if (p && owned) {
+            if (pooled) { if (pool_stream) (void)hipStreamSynchronize(pool_stream); DevCache::get().give(dev, p, cap); }
+            else (void)hipFree(p);
+        }
+        p = nullptr; cap = 0;
+    }
+    ~DevBuf() { release(); }
+    void borrow(const DevBuf& o) { release(); p = o.p; cap = o.cap; owned = false; }
     hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
         if (bytes <= cap && owned) return hipSuccess;
         // a borrowed buffer is never written: the first write access replaces it by a private copy
@@ -42,18 +107,27 @@ struct DevBuf {
         size_t ncap = std::max(bytes > (64u << 20) ? bytes + bytes / 8 : bytes, owned ? cap + cap / 2 : cap);
         ncap = (ncap + 255) & ~(size_t)255;
         void* np = nullptr;
-        const auto t_alloc = std::chrono::steady_clock::now();
-        hipError_t e = hipMalloc(&np, ncap);
-        alloc_seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
-        alloc_calls()++;
-        if (e != hipSuccess) return e;
-        if (keep && p && cap) {
-            e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) { (void)hipFree(np); return e; }
+        int ndev = dev;
+        if (pooled) {
+            ncap = DevCache::size_class(std::max<size_t>(bytes, 1));
+            if (hipGetDevice(&ndev) != hipSuccess) ndev = -1;
+            np = DevCache::get().take(ndev, ncap);
         }
-        if (p && owned) (void)hipFree(p);
-        p = np; cap = ncap; owned = true;
+        if (!np) {
+            const auto t_alloc = std::chrono::steady_clock::now();
+            hipError_t e = hipMalloc(&np, ncap);
+            alloc_seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_alloc).count();
+            alloc_calls()++;
+            if (e != hipSuccess) return e;
+        }
+        if (keep && p && cap) {
+            hipError_t e = hipMemcpyAsync(np, p, std::min(cap, ncap), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { if (pooled) DevCache::get().give(ndev, np, ncap); else (void)hipFree(np); return e; }
+        }
+        const bool was_owned = owned;
+        if (was_owned) release(); else { p = nullptr; cap = 0; }
+        p = np; cap = ncap; owned = true; dev = ndev;
         return hipSuccess;
     }
     template <class T> T* as() const { return (T*)p; }
@@ -62,6 +136,7 @@ struct DevBuf {
 struct tksmseq_batch {
     uint64_t n_reads = 0, n_intervals = 0, n_mods = 0, n_literals = 0;
     DevBuf reads, intervals, mods, literals, litpool, ids, idpool;
+    tksmseq_batch() { for (DevBuf* b : {&reads, &intervals, &mods, &literals, &litpool, &ids, &idpool, &d_dup, &d_order, &d_tail}) b->pooled = true; }
     // what PCR / truncation / the MDF writer need beyond Seq (batches parsed from MDF text only)
     std::vector<uint32_t> h_dup;         // [n_reads] bit 31: copy of a depth > 1 molecule, low bits: its index (unroll naming)
     DevBuf d_dup;

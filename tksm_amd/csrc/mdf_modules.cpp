@@ -12,6 +12,7 @@
 // --devices D[,D...] (two contexts per entry: one formats its text while the other computes) and are written in input order, so the
 // output does not depend on the device list or the piece size.
 // Exit codes as the reference's run(): 0 ok (also for --help), 1 for missing / inconsistent arguments and runtime errors.
+#include <deque>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -273,15 +274,36 @@ extern "C" int tksmseq_truncate_main(int argc0, char** argv0) {
     rd.in = fopen(c.input.c_str(), "rb");
     if (!rd.in) { fprintf(stderr, "Could not open file %s\n", c.input.c_str()); return 1; }
     rd.bytes = c.batch_bytes;
-    uint64_t seq = 0, first = 0;
-    auto prepare = [&](tksmseq_ctx*, void**) -> bool { return true; };
-    auto next_piece = [&](Piece& pc) -> bool {                   // (serialised by the engine: the molecules are numbered in input order)
-        if (!rd.next(pc.text)) {
-            if (seq) return false;
-            pc.text.clear();                                      // an empty input still makes an (empty) output
+    // a reader thread of its own cuts the input into pieces of whole molecules and numbers them (input order), a few pieces ahead of the
+    // workers: what the engine serialises is a pop from this queue, not the read + scan of a piece
+    std::mutex q_m; std::condition_variable q_put, q_get; std::deque<Piece> pieces; bool q_done = false, q_stop = false;
+    const size_t q_cap = c.devices.size() * 2 + 1;
+    std::thread reader([&]() {
+        uint64_t seq = 0, first = 0;
+        for (;;) {
+            Piece pc;
+            if (!rd.next(pc.text)) {
+                if (seq) break;
+                pc.text.clear();                                  // an empty input still makes an (empty) output
+            }
+            pc.seq = seq++; pc.first = first;
+            first += tkmod::count_reads(pc.text.data(), pc.text.size());
+            std::unique_lock<std::mutex> l(q_m);
+            q_put.wait(l, [&] { return pieces.size() < q_cap || q_stop; });
+            if (q_stop) break;
+            pieces.push_back(std::move(pc));
+            q_get.notify_one();
         }
-        pc.seq = seq++; pc.first = first;
-        first += tkmod::count_reads(pc.text.data(), pc.text.size());
+        { std::lock_guard<std::mutex> l(q_m); q_done = true; }
+        q_get.notify_all();
+    });
+    auto prepare = [&](tksmseq_ctx*, void**) -> bool { return true; };
+    auto next_piece = [&](Piece& pc) -> bool {
+        std::unique_lock<std::mutex> l(q_m);
+        q_get.wait(l, [&] { return !pieces.empty() || q_done; });
+        if (pieces.empty()) return false;
+        pc = std::move(pieces.front()); pieces.pop_front();
+        q_put.notify_one();
         return true;
     };
     auto work = [&](tksmseq_ctx* ctx, void*, const Piece& pc, tksmseq_batch** out) -> int {
@@ -295,6 +317,9 @@ extern "C" int tksmseq_truncate_main(int argc0, char** argv0) {
         return rc;
     };
     const int rc = run_pieces(c, log, "truncate", prepare, next_piece, work);
+    { std::lock_guard<std::mutex> l(q_m); q_stop = true; }          // (an error: the reader may be waiting for room)
+    q_put.notify_all();
+    reader.join();
     fclose(rd.in);
     return rc;
 }

@@ -211,6 +211,7 @@ int tksmseq_pcr_template_counts(tksmseq_ctx* ctx, const tksmseq_batch* in, const
     int rc = pcr_setup(ctx, in, &whole, keep, n_kept, P);
     if (rc) return rc;
     DevBuf d_keep, d_cnt, d_status;
+    for (DevBuf* pb_ : {&d_keep, &d_cnt, &d_status}) { pb_->pooled = true; pb_->pool_stream = s; }   // (per-call temporaries: DevCache, ctx.h)
     if (!keep.empty()) { HIPCHK(ctx, d_keep.ensure(n_kept * 4 + 16)); HIPCHK(ctx, hipMemcpyAsync(d_keep.p, keep.data(), n_kept * 4, hipMemcpyHostToDevice, s)); }
     tk::MolView M{view_of(in), in->d_dup.p ? in->d_dup.as<uint32_t>() : nullptr, in->n_intervals, in->n_mods, keep.empty() ? nullptr : d_keep.as<uint32_t>(), n_kept};
     HIPCHK(ctx, d_cnt.ensure(n_kept * 8 + 16));
@@ -242,6 +243,7 @@ int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_par
     }
 
     DevBuf d_keep, d_cnt, d_off, d_status, n_mol, n_mask, n_ivl, n_mod, n_idl, o_ivl, o_mod, o_id;
+    for (DevBuf* pb_ : {&d_keep, &d_cnt, &d_off, &d_status, &n_mol, &n_mask, &n_ivl, &n_mod, &n_idl, &o_ivl, &o_mod, &o_id}) { pb_->pooled = true; pb_->pool_stream = s; }   // (per-call temporaries: DevCache, ctx.h)
     if (!keep.empty()) { HIPCHK(ctx, d_keep.ensure(n_kept * 4 + 16)); HIPCHK(ctx, hipMemcpyAsync(d_keep.p, keep.data(), n_kept * 4, hipMemcpyHostToDevice, s)); }
     tk::MolView M{view_of(in), in->d_dup.p ? in->d_dup.as<uint32_t>() : nullptr, in->n_intervals, in->n_mods,
                   keep.empty() ? nullptr : d_keep.as<uint32_t>(), n_kept};
@@ -277,7 +279,7 @@ int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_par
     const uint32_t sentinel[4] = {0u, 0u, 0u, (uint32_t)t_mod};          // the interval after the last carries n_mods
     HIPCHK(ctx, hipMemcpyAsync(b->intervals.as<uint32_t>() + 4 * t_ivl, sentinel, 16, hipMemcpyHostToDevice, s));
     // comments follow the template (re-serialised the way the reference's reader / writer pair does)
-    if (!in->h_comments.empty()) {
+    if (!in->h_comments.empty() && !(p->flags & TKSMSEQ_MOL_NO_COMMENTS)) {
         std::vector<uint32_t> mol(n_nodes);
         HIPCHK(ctx, hipMemcpyAsync(mol.data(), n_mol.p, n_nodes * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
@@ -310,6 +312,7 @@ int tksmseq_truncate(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_tr
     T.seed = p->seed; T.mode = p->mode; T.mu = p->mu; T.sigma = p->sigma; T.min_len = 100;      // truncate()'s default min_val
     T.always_end = p->always_end ? 1 : 0; T.models_length = p->kde_models_length ? 1 : 0;
     DevBuf d_x, d_y, d_cdf, d_rn, d_sl, d_sc;
+    for (DevBuf* pb_ : {&d_x, &d_y, &d_cdf, &d_rn, &d_sl, &d_sc}) { pb_->pooled = true; pb_->pool_stream = s; }   // (per-call temporaries: DevCache, ctx.h)
     TrcModelHost tm;
     auto upv = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         HIPCHK(ctx, b.ensure(bytes + 64));
@@ -331,6 +334,7 @@ int tksmseq_truncate(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_tr
     else if (!std::isfinite(p->mu) || !std::isfinite(p->sigma)) { ctx->err = "truncate: mu and sigma must be finite"; return TKSMSEQ_EINVAL; }
     tk::MolView M{view_of(in), in->d_dup.p ? in->d_dup.as<uint32_t>() : nullptr, in->n_intervals, in->n_mods, nullptr, n};
     DevBuf kf, kt, tl, ts, n_ivl, n_mod, n_idl, o_ivl, o_mod, o_id;
+    for (DevBuf* pb_ : {&kf, &kt, &tl, &ts, &n_ivl, &n_mod, &n_idl, &o_ivl, &o_mod, &o_id}) { pb_->pooled = true; pb_->pool_stream = s; }   // (per-call temporaries: DevCache, ctx.h)
     HIPCHK(ctx, kf.ensure(n * 4 + 16)); HIPCHK(ctx, kt.ensure(n * 4 + 16));
     for (DevBuf* b : {&tl, &ts, &n_ivl, &n_mod, &n_idl}) HIPCHK(ctx, b->ensure(n * 8 + 16));
     HIPCHK(ctx, tk::launch_trc_plan(M, T, p->first_molecule_index, kf.as<uint32_t>(), kt.as<uint32_t>(), tl.as<double>(), ts.as<double>(),
@@ -351,7 +355,7 @@ int tksmseq_truncate(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_tr
     HIPCHK(ctx, hipMemcpyAsync(b->intervals.as<uint32_t>() + 4 * t_ivl, sentinel, 16, hipMemcpyHostToDevice, s));
     // comments: the template's, plus truncated=chr:start-end,... for what was cut away and (KDE mode) TR=<length>,<3' share>
     // (src/truncate.cpp:54-60, :343).  Needs the input tables on the host.
-    if (!in->h_comments.empty()) {
+    if (!in->h_comments.empty() && !(p->flags & TKSMSEQ_MOL_NO_COMMENTS)) {
         std::vector<uint32_t> reads(2 * n), ivs(4 * (in->n_intervals + 1)), hkf(n), hkt(n);
         std::vector<double> htl(n), hts(n);
         std::vector<uint64_t> lits(2 * in->n_literals);

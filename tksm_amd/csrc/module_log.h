@@ -87,8 +87,18 @@ inline uint64_t count_reads(const char* p, size_t len) {
 }
 
 // Reads MDF text in pieces of about `bytes` that hold whole molecules (cut at the last "\n+").  next(): false at the end of the input.
+// the last molecule boundary ("\n+") of buf[0, have), searched backwards down to `floor` (positions below it are known to hold none):
+// the index of the '+', or 0 if there is none
+inline size_t last_molecule_boundary(const char* buf, size_t have, size_t floor) {
+    size_t p = have;
+    const size_t lo = floor > 1 ? floor : 1;
+    while (p > lo && !(buf[p - 1] == '\n' && p < have && buf[p] == '+')) p--;
+    return p > lo ? p : 0;
+}
+
 struct ChunkReader {
     FILE* in = nullptr; uint64_t bytes = 64ull << 20; std::vector<char> buf; size_t have = 0; bool eof = false;
+    size_t floor = 0;                                        // buf[0, floor) holds no boundary: a molecule larger than `bytes` is scanned once, not once per refill
     bool next(std::vector<char>& out) {
         while (!eof || have) {
             buf.resize(have + bytes);
@@ -97,15 +107,14 @@ struct ChunkReader {
             have += got;
             size_t cut = have;
             if (!eof) {
-                size_t p = have;
-                while (p > 1 && !(buf[p - 1] == '\n' && p < have && buf[p] == '+')) p--;
-                if (p <= 1) { buf.resize(have); continue; }   // no boundary yet: read more
-                cut = p;
+                cut = last_molecule_boundary(buf.data(), have, floor);
+                if (!cut) { floor = have ? have - 1 : 0; buf.resize(have); continue; }   // no boundary yet: read more
             }
             if (cut == 0) return false;
             out.assign(buf.begin(), buf.begin() + (ptrdiff_t)cut);
             memmove(buf.data(), buf.data() + cut, have - cut);
             have -= cut;
+            floor = have ? have - 1 : 0;                      // (the cut was the LAST boundary: what is left holds none)
             return true;
         }
         return false;

@@ -529,7 +529,8 @@ public:
         uint64_t next_place[2] = {0, 0}, place[2] = {0, 0};                                        // per output; guarded by done_m
         // stage clocks (TKSMSEQ_VERBOSE): seconds spent parsing, running, copying, writing, reading
         const bool verbose = getenv("TKSMSEQ_VERBOSE") != nullptr || log.level <= Logger::DEBUG;
-        std::mutex clk_m; double clk[6] = {0, 0, 0, 0, 0, 0};
+        std::mutex clk_m; double clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // 0 parse, 1 run, 2 device copy / download, 3 write, 4 wait for writer, 5 read + count, 6 wait for device-to-host pieces
+        std::atomic<uint64_t> bytes_in{0}, bytes_d2h{0};
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto add_clk = [&](int k, std::chrono::steady_clock::time_point t0) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -555,12 +556,16 @@ public:
                     if (a.pcr_on) {
                         // a slice of the templates amplified on the device: its copies are numbered from c.first_read on
                         tksmseq_pcr_params q = a.pcr;
+                        q.flags = TKSMSEQ_MOL_NO_COMMENTS;             // (Seq never reads header comments: no per-molecule text on the host)
                         q.template_begin = c.t_begin; q.template_end = c.t_end;
                         if (c.t_begin == c.t_end) { q.template_begin = q.template_end = 0; q.cycles = 0; }
                         if (tksmseq_pcr(pc, templates[(size_t)(pi / parsers_per_group)], &q, &pr.b)) { set_error(tksmseq_last_error(pc)); ok = false; }
+                        if (verbose2) fprintf(stderr, "[sequence] slice %llu parser %d: pcr %.3f s at %.3f s\n", (unsigned long long)c.seq, pi,
+                                              std::chrono::duration<double>(now() - t_parse).count(), std::chrono::duration<double>(now() - t_start).count());
                     } else if ((a.trc_n ? tksmseq_molecules_from_mdf_text : tksmseq_batch_from_mdf_text)(pc, c.text.data(), c.text.size(), &pr.b)) { set_error(tksmseq_last_error(pc)); ok = false; }
                     if (ok && a.trc_n) {
                         tksmseq_trc_params q = a.trc;
+                        q.flags = TKSMSEQ_MOL_NO_COMMENTS;
                         q.first_molecule_index = c.first_read;
                         tksmseq_batch* cut = nullptr;
                         if (tksmseq_truncate(pc, pr.b, &q, &cut)) { set_error(tksmseq_last_error(pc)); ok = false; }
@@ -568,6 +573,8 @@ public:
                         pr.b = cut;
                     }
                     add_clk(0, t_parse);
+                    if (verbose2) fprintf(stderr, "[sequence] batch %llu parser %d: parsed / made in %.3f s at %.3f s\n", (unsigned long long)c.seq, pi,
+                                          std::chrono::duration<double>(now() - t_parse).count(), std::chrono::duration<double>(now() - t_start).count());
                 }
                 std::unique_lock<std::mutex> l(out.order_m);
                 out.order_cv.wait(l, [&] { return out.handed == ticket; });
@@ -728,6 +735,7 @@ public:
                 W.cv.notify_all();
                 if (!ok) { set_error("write failed"); return; }
                 total_reads += fin.n_reads;
+                { std::lock_guard<std::mutex> l(done_m); place[0] += fin.bytes[0]; place[1] += fin.bytes[1]; }     // (bytes written, for the run's summary)
                 next++;
             }
         };
@@ -756,7 +764,11 @@ public:
                     ok = !failed;
                 }
                 for (uint64_t q = 0; q < np && ok; q++) {
-                    if (tksmseq_synchronize(W.wctx)) { set_error(tksmseq_last_error(W.wctx)); ok = false; break; }
+                    const auto t_d2h = now();
+                    const bool sync_failed = tksmseq_synchronize(W.wctx) != 0;
+                    add_clk(6, t_d2h);
+                    bytes_d2h += piece_bytes(q);
+                    if (sync_failed) { set_error(tksmseq_last_error(W.wctx)); ok = false; break; }
                     if (q + 1 < np && tksmseq_copy_to_host(W.wctx, W.ring[(q + 1) & 1], src + (q + 1) * W.piece, piece_bytes(q + 1), 1)) { set_error(tksmseq_last_error(W.wctx)); ok = false; break; }
                     const auto t_write = now();
                     const bool wok = wr.positional ? wr.write_at(W.ring[q & 1], piece_bytes(q), j.off + q * W.piece) : wr.write(W.ring[q & 1], piece_bytes(q));
@@ -783,7 +795,7 @@ public:
         std::vector<char> buf;
         uint64_t read_index = 0, seq = 0;
         bool eof = false;
-        size_t have = 0;
+        size_t have = 0, scan_floor = 0;
         if (a.pcr_on) {
             // chained PCR (src/pcr.cpp:215: the module holds its whole input): the templates go to every device group once; the
             // copies per template (tksmseq_pcr_template_counts) cut them into slices of about --pcr-slice-molecules copies, which
@@ -822,10 +834,8 @@ public:
             have += got;
             size_t cut = have;
             if (!eof) {
-                size_t p = have;
-                while (p > 1 && !(buf[p - 1] == '\n' && p < have && buf[p] == '+')) p--;
-                if (p <= 1) { buf.resize(have); continue; }   // no boundary yet: read more
-                cut = p;
+                cut = tkmod::last_molecule_boundary(buf.data(), have, scan_floor);
+                if (!cut) { scan_floor = have ? have - 1 : 0; buf.resize(have); continue; }   // no boundary yet: read more (what was scanned is not scanned again)
             }
             if (cut == 0) break;
             Chunk c;
@@ -833,10 +843,12 @@ public:
             c.text.assign(buf.begin(), buf.begin() + (ptrdiff_t)cut);
             c.n_reads = count_reads(c.text.data(), c.text.size());
             read_index += c.n_reads;
+            bytes_in += c.text.size();
             add_clk(5, t_read);
             queue.push(std::move(c));
             memmove(buf.data(), buf.data() + cut, have - cut);
             have -= cut;
+            scan_floor = have ? have - 1 : 0;                       // (the cut was the last boundary: the rest holds none)
         }
         { std::lock_guard<std::mutex> l(done_m); n_batches = seq; reader_done = true; }
         queue.close();
@@ -852,10 +864,26 @@ public:
         if ((positional || behind) && !failed) { wb.wrote = wb.wrote || place[0] != 0; wp.wrote = wp.wrote || place[1] != 0; }
         int status = failed ? 1 : 0;
         if (status) fprintf(stderr, "Error: %s\n", first_error.c_str());
+        const double t_stream = std::chrono::duration<double>(now() - t_start).count();        // first chunk read -> last record byte written
+        if (const char* sf = getenv("TKSMSEQ_STATS_FILE")) {
+            // machine-readable stage clocks of this run (bench.py's end-to-end leg): seconds are summed over the threads of a stage
+            if (FILE* f = fopen(sf, "w")) {
+                const uint64_t out_b = place[0] + place[1];
+                fprintf(f, "{\"reads\": %llu, \"batches\": %llu, \"workers\": %d, \"parsers\": %d, \"parse_threads\": %d, \"mdf_bytes\": %llu, "
+                           "\"record_bytes\": %llu, \"d2h_bytes\": %llu, \"setup_s\": %.4f, \"stream_s\": %.4f, \"parse_s\": %.4f, \"run_s\": %.4f, "
+                           "\"device_copy_s\": %.4f, \"d2h_wait_s\": %.4f, \"write_s\": %.4f, \"wait_for_writer_s\": %.4f, \"read_count_s\": %.4f, "
+                           "\"written_behind\": %s, \"positional\": %s, \"status\": %d}\n",
+                        (unsigned long long)total_reads, (unsigned long long)seq, n_workers, n_groups * parsers_per_group, a.threads,
+                        (unsigned long long)bytes_in.load(), (unsigned long long)out_b, (unsigned long long)bytes_d2h.load(),
+                        std::chrono::duration<double>(t_start - t_begin).count(), t_stream, clk[0], clk[1], clk[2], clk[6], clk[3], clk[4], clk[5],
+                        behind ? "true" : "false", positional ? "true" : "false", status);
+                fclose(f);
+            }
+        }
         if (verbose)
             fprintf(stderr, "[sequence] %d batches, %d in flight, %.2f s streaming: parse %.2f, run %.2f, copy %.2f, wait for writer %.2f "
-                            "(summed over workers); write %.2f; read + count %.2f\n", (int)seq, n_workers,
-                    std::chrono::duration<double>(now() - t_start).count(), clk[0], clk[1], clk[2], clk[4], clk[3], clk[5]);
+                            "(summed over workers); waiting for device-to-host pieces %.2f, write %.2f (summed over writers); read + count %.2f\n", (int)seq, n_workers,
+                    t_stream, clk[0], clk[1], clk[2], clk[4], clk[6], clk[3], clk[5]);
         for (auto& W : workers) {
             tksmseq_host_free(W->host[0]); tksmseq_host_free(W->host[1]); tksmseq_host_free(W->ring[0]); tksmseq_host_free(W->ring[1]);
             if (W->wctx) { tksmseq_device_free(W->wctx, W->stage[0]); tksmseq_device_free(W->wctx, W->stage[1]); tksmseq_destroy(W->wctx); W->wctx = nullptr; }
@@ -868,7 +896,8 @@ public:
         if (verbose)
             fprintf(stderr, "[sequence] closing the outputs %.2f s, releasing the device %.2f s\n",
                     std::chrono::duration<double>(t_destroy - t_close).count(), std::chrono::duration<double>(now() - t_destroy).count());
-        if (!status) log.log(Logger::INFO, "Sequencing: %llu reads", (unsigned long long)total_reads);
+        if (!status) log.log(Logger::INFO, "Sequencing: %llu reads, %llu record bytes, %.2f s streaming (%.2f M reads/s)", (unsigned long long)total_reads,
+                             (unsigned long long)(place[0] + place[1]), t_stream, t_stream > 0 ? total_reads / t_stream / 1e6 : 0.0);
         return status;
     }
 };
