@@ -280,7 +280,8 @@ int tksmseq_interleave_records(tksmseq_ctx* ctx, int n_ranks, const void* const*
  * molecule present with probability `efficiency`; a copy gets floor(4/3 error_rate x size) (+1 with the fractional
  * probability) substitutions at distinct positions, bases uniform in "ACTG", on top of its template's; each copy is
  * written with probability target_count / ((1 + efficiency)^cycles x molecules); id = template id + "." + cycle.
- * More than 2 x target_count input molecules: 2 x target_count of them are used (:217-220). */
+ * More than 2 x target_count input molecules: 2 x target_count of them are used, a uniformly random ORDERED subset as :217-220's
+ * std::shuffle + resize gives (the molecules with the smallest Philox keys, in key order); their copies are written in that order. */
 /* flags of both transforms.  TKSMSEQ_MOL_NO_COMMENTS: the output batch carries no header comments.  Comments ("truncated=...", "TR=...",
  * the template's own) are host-side text per molecule; a caller whose next step is tksmseq_run -- which never reads them, like the
  * reference's Seq (mdf_generator, py/sequence.py:206-213, drops the comment column) -- saves that work: the chained `tksm sequence
@@ -293,14 +294,15 @@ typedef struct {
     int32_t flags;                /* TKSMSEQ_MOL_NO_COMMENTS or 0 */
     double error_rate;            /* --error-rate, before the 4/3 adjustment of src/pcr.cpp:36 */
     double efficiency;            /* --efficiency */
-    /* the copies of the input molecules template_begin <= u < template_end only (0, 0: all of them).  The drop ratio and the
-     * 2 x target_count subsample are those of the WHOLE input either way, and a copy depends on (seed, u, its path of cycles)
-     * alone, so the outputs of consecutive slices, one after the other, are the output of the whole: how `tksm pcr` streams
-     * 200 M molecules through bounded memory and spreads them over several devices */
+    /* the copies of the templates at positions template_begin <= i < template_end of the PROCESSING ORDER only (0, 0: all of them):
+     * input order, or the subsample's key order when more than 2 x target_count molecules come in.  The drop ratio and the subsample
+     * are those of the WHOLE input either way, and a copy depends on (seed, its template, its path of cycles) alone, so the outputs
+     * of consecutive slices, one after the other, are the output of the whole: how `tksm pcr` streams 200 M molecules through
+     * bounded memory and spreads them over several devices */
     uint64_t template_begin, template_end;
 } tksmseq_pcr_params;
-/* written copies per input molecule (counts[n_reads of the batch]; 0 for a molecule outside the subsample): what a caller needs
- * to number the molecules of a slice's output before the slices before it have been made */
+/* written copies per template, by position in the processing order (counts[n_reads of the batch]; positions beyond the subsample:
+ * 0): what a caller needs to number the molecules of a slice's output before the slices before it have been made */
 int tksmseq_pcr_template_counts(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* params, uint64_t* counts);
 int tksmseq_pcr_preset(const char* name, double* error_rate, double* efficiency);   /* -x/--preset, src/pcr.cpp:136-140 */
 int tksmseq_pcr(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* params, tksmseq_batch** out);

@@ -168,20 +168,22 @@ def pcr_mutations(seed, u, mask, rate, size):
 def pcr_spec(mols, cycles, efficiency, error_rate, target, seed, only=None):
     """The specification the HIP kernels implement: only the branches that lead to a written copy are walked (kernels:
     tksm_amd/csrc/mdf_kernels.hip, pcr_walk); written set, ancestry and substitutions have the reference's distribution.
-    only = (lo, hi): the copies of the templates with index lo <= u < hi alone (the templates are independent given the
-    drop ratio, so the tests compute a large output in slices, side by side)."""
+    only = (lo, hi): the copies of the templates at positions lo <= i < hi of the processing order alone (the templates are
+    independent given the drop ratio, so the tests compute a large output in slices, side by side).  Processing order: input order;
+    with more than 2 x target templates (src/pcr.cpp:217-220: std::shuffle, then resize) the 2 x target templates with the smallest
+    keys IN KEY ORDER -- a uniformly random ordered subset, as the reference's shuffle + cut gives."""
     n = len(mols)
     keep = list(range(n))
     if n > 2 * target:
         keys = sorted(((lambda w: (w[0] << 32) | w[1])(po.philox(seed, u, ST_PCR_PICK, 0)), u) for u in range(n))
-        keep = sorted(u for _, u in keys[: 2 * target])
+        keep = [u for _, u in keys[: 2 * target]]
     rate = (4 * error_rate) / 3
     expected_after = math.pow(1 + efficiency, cycles) * float(len(keep))
     drop = min(1.0, target / expected_after) if expected_after > 0 else 0.0
     q, A = pcr_tables(cycles, efficiency, drop)
     out = []
-    for u in keep:
-        if only is not None and not only[0] <= u < only[1]:
+    for pos, u in enumerate(keep):
+        if only is not None and not only[0] <= pos < only[1]:
             continue
         md, size = mols[u], mol_size(mols[u])
         stack = [[0, 0, True]]                                          # mask, next cycle, satisfied

@@ -113,6 +113,39 @@ def test_pcr_specification_has_the_reference_distribution(mo, cycles, eff, er, p
             assert steps == sorted(set(steps)) and steps and steps[-1] < cycles
 
 
+def test_pcr_subsample_is_a_random_ordered_subset_like_shuffle_and_resize(mo):
+    """More than 2 x target templates: the reference shuffles the molecules and keeps the first 2 x target (src/pcr.cpp:217-220) -- a
+    uniformly random ORDERED subset; its copies come out in that order.  The specification takes the 2 x target templates with the
+    smallest counter-based keys, in key order: the template ids of the output follow that order (not input order), every kept
+    template is distinct, over seeds every template is kept with probability 2 x target / n and first with probability 1 / n."""
+    text = _mdf(np.random.RandomState(12), 60, mods=False)
+    mols = mo.stream_mdf(text, unroll=True)
+    n = len(mols)
+    target = 8
+    first, kept = np.zeros(n), np.zeros(n)
+    index_of = {m["id"]: i for i, m in enumerate(mols)}
+    unsorted = 0
+    for seed in range(400):
+        out = mo.pcr_spec(mols, 2, 1.0, 0.0, target, seed)
+        order = []
+        for m in out:
+            root = m["id"].split(".")[0]                                          # a copy's id: template id + "." + cycle (+ ...)
+            if not order or order[-1] != index_of[root]:
+                order.append(index_of[root])
+        assert len(set(order)) == len(order) <= 2 * target                      # a template's copies are contiguous, each template once
+        unsorted += order != sorted(order)
+        if order:
+            first[order[0]] += 1
+        for u in order:
+            kept[u] += 1
+        # slices of the processing order, one after the other, are the whole
+        parts = sum((mo.pcr_spec(mols, 2, 1.0, 0.0, target, seed, only=(lo, lo + 5)) for lo in range(0, 2 * target, 5)), [])
+        assert [m["id"] for m in parts] == [m["id"] for m in out]
+    assert unsorted > 300                                                         # key order, not input order
+    assert kept.min() > 0 and kept.max() < 3.0 * kept.mean()                      # every template gets its turn
+    assert first.max() < 400 * 6.0 / n                                            # no template is favoured as the first one
+
+
 def test_reference_written_kde_model_in_the_oracle(mo):
     """tests/golden/kde_truncation_model.json was written by the reference's own py/truncate_kde.py (main -> printModelJson,
     :298-320) from synthetic mappings (tests/golden/make_kde_golden.py).  The oracle's loader (custom_distribution2D / end_mtx,
@@ -192,6 +225,18 @@ def test_pcr_kernels_match_the_oracle(gseq, mo, cycles, eff, er, target, seed):
     want = mo.write_mdf(mo.pcr_spec(mo.stream_mdf(text, unroll=True), cycles, eff, er, target, seed))
     assert got == want
     assert cycles == 0 or abs(out.n_reads - target) < 6 * np.sqrt(target) + 10
+    if cycles == 4:
+        # the subsample's processing order (key order, as the reference's shuffle + resize) in template slices: one after the other = the whole
+        parts = []
+        for lo in range(0, 2 * target, 64):
+            o2 = s.pcr(b, cycles, target, error_rate=er, efficiency=eff, seed=seed, templates=(lo, min(2 * target, lo + 64)))
+            parts.append(s.to_mdf_text(o2))
+            o2.free()
+        assert "".join(parts) == got
+        ids = [l.split("\t")[0].split(".")[0] for l in got.splitlines() if l.startswith("+")]
+        roots = [x for i, x in enumerate(ids) if i == 0 or ids[i - 1] != x]
+        assert len(set(roots)) == len(roots) and roots != sorted(roots, key=lambda x: (int(x[4:].split("_")[0]), x))      # shuffled, each template once
+        assert list(s.pcr_template_counts(b, cycles, target, er, eff, seed=seed)[2 * target:]) == [0] * (b.n_reads - 2 * target)
     out.free(); b.free()
 
 

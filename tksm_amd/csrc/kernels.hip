@@ -2145,7 +2145,7 @@ struct AlnJobF {
 struct AlnResF { uint32_t mt, cols; int m; bool fail, needfull, overflow; uint32_t why; };
 
 template <int MODE, int ROWS>
-DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls, int mcap) {
+DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls, int mcap) {      // (tg, cl, ls: the same for every lane of the wave)
     static_assert(ROWS == 14 || ROWS == 64, "14 stored rows, or all of them");
     constexpr int NC = ROWS == 14 ? 16 : 4;                       // iterations per 64-byte line of codes
     constexpr int ST = ROWS == 14 ? 24 : 0;                       // first stored band row once the window moves
@@ -2153,7 +2153,12 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     const bool act = J.act;
     const int n = act ? J.n : 0;
     const int base = J.p0 & ~1, skip = J.p0 - base;               // slot codes are fetched from an even position
-    const int nmax = wave_max(act ? n + skip : 0);
+    // wave-uniform by construction, and TOLD so (scalar registers): the loop below and the walk then leave by uniform branches only.
+    // Left as vector values (the compiler cannot know that a shuffle reduction or a per-lane load of the wave's range geometry is
+    // uniform) they made every exit of the pass loop a divergent one: a page of EXEC bookkeeping per pass -- and, in builds forced
+    // below the kernel's natural register count, spill code around that bookkeeping that gave WRONG results (tools/spill_probe.py)
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max(act ? n + skip : 0));
+    tg = __builtin_amdgcn_readfirstlane(tg); cl = __builtin_amdgcn_readfirstlane(cl);
     // ---- fragment planes as a stream aligned to `base` (x = position - base): word j = x in [64 j, 64 j + 64)
     const int wb = base >> 6, bsh = base & 63;
     auto fpw = [&](int w) { return J.fp[min(max(w, 0), J.wlast)]; };
@@ -2243,6 +2248,12 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 Mv = mk64(hi32(Mv) >> sh, alignbit(hi32(Mv), lo32(Mv), sh) | f);
                 // {EA : A} and {EB : B} move down by sh rows, IN PLACE and from the low word up (the compiler, left to itself, computes the
                 // four new words of a plane into fresh registers and copies them back behind the branch: four v_mov_b64 per column)
+#ifdef TKSM_NO_INLINE_ASM                                        // (diagnostic builds of tools/spill_probe.sh: the same arithmetic in plain C++)
+                {
+                    const unsigned long long nA = sh >= 64u ? 0ull : (A >> sh) | (sh ? EA << (64u - sh) : 0ull), nB = sh >= 64u ? 0ull : (B >> sh) | (sh ? EB << (64u - sh) : 0ull);
+                    EA = sh >= 64u ? 0ull : EA >> sh; EB = sh >= 64u ? 0ull : EB >> sh; A = nA; B = nB;
+                }
+#else
                 {
                     uint32_t a0 = lo32(A), a1 = hi32(A), a2 = lo32(EA), a3 = hi32(EA), b0 = lo32(B), b1 = hi32(B), b2 = lo32(EB), b3 = hi32(EB);
                     asm("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a0) : "v"(a1), "v"(sh));
@@ -2255,6 +2266,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                     asm("v_lshrrev_b32 %0, %1, %0" : "+v"(b3) : "v"(sh));
                     A = mk64(a1, a0); EA = mk64(a3, a2); B = mk64(b1, b0); EB = mk64(b3, b2);
                 }
+#endif
                 const unsigned long long clm = mk64(cl, cl), chm = mk64(ch, ch);
                 const unsigned long long Eq = bool3<BOOL3(TA & (TB ^ TC))>(A ^ clm, B, chm);
                 const unsigned long long Xv = Eq | Mv;
@@ -2273,7 +2285,11 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                     // stored rows st .. st + 13, st = clamp(iteration - RAMP0, 0, ST): a function of the iteration alone
                     // (on the scalar unit: the compiler fuses min(max()) into a vector v_med3_i32 and reads it back)
                     int st_s;
+#ifdef TKSM_NO_INLINE_ASM
+                    st_s = min(max(it0 + q, RAMP0), 31);
+#else
                     asm("s_max_i32 %0, %1, %2\n\ts_min_i32 %0, %0, 31" : "=&s"(st_s) : "s"(it0 + q), "i"(RAMP0) : "scc");
+#endif
                     const uint32_t st = (uint32_t)(st_s - RAMP0);
                     const uint32_t c0 = alignbit(hi32(w0), lo32(w0), st), c1 = alignbit(hi32(w1), lo32(w1), st);
                     const uint32_t c1s = c1 << 14;
@@ -2474,8 +2490,13 @@ DEV void store_result_f(const FastBuffers& FB, uint32_t r, const AlnResF& R) {
 // the pop's divergent region cost correct results once: never again below its natural size)
 constexpr int ALNF_WAVES = 4;
 constexpr int LONG_QJOB = 3000;         // slots; q-score jobs above it skip the 14-row pass
+#ifdef TKSM_ALNF_NUM_VGPR                                        // (diagnostic builds of tools/spill_probe.sh: a register cap without a change of occupancy)
+#define ALNF_VGPR_CAP __attribute__((amdgpu_num_vgpr(TKSM_ALNF_NUM_VGPR)))
+#else
+#define ALNF_VGPR_CAP
+#endif
 template <int MODE, int ROWS, bool LIST>
-__global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
+__global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) ALNF_VGPR_CAP void k_alnf(SimParams P, FastBuffers FB, SimBuffers O, uint32_t n_jobs) {
 #ifndef TKSM_ABLATE
     if (ROWS == 64) __builtin_amdgcn_s_setprio(2);            // (the full-width passes are a few latency-bound waves)
 #endif

@@ -151,9 +151,10 @@ int tksmseq_pcr_preset(const char* name, double* error_rate, double* efficiency)
     return TKSMSEQ_EINVAL;
 }
 
-// The templates of a PCR call and its kernel parameters.  Templates: every (depth-unrolled) molecule, or 2 x target of them when
-// there are more (src/pcr.cpp:217-220 shuffles and cuts; here: the 2 x target molecules with the smallest Philox keys, in input
-// order); of those, the ones inside [template_begin, template_end) when the caller asks for a slice.  keep empty = every molecule.
+// The templates of a PCR call and its kernel parameters, in PROCESSING ORDER.  Templates: every (depth-unrolled) molecule in input order,
+// or 2 x target of them when there are more (src/pcr.cpp:217-220 shuffles and cuts: a uniformly random ordered subset; here: the
+// 2 x target molecules with the smallest Philox keys, in key order); of those, positions [template_begin, template_end) of that order
+// when the caller asks for a slice.  keep empty = every molecule, in input order.
 static int pcr_setup(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pcr_params* p, std::vector<uint32_t>& keep, uint64_t& n_local, tk::PcrParams& P) {
     if (p->cycles < 0 || p->cycles > tk::PCR_MAX_CYCLES) { ctx->err = "PCR: between 0 and " + std::to_string(tk::PCR_MAX_CYCLES) + " cycles are supported"; return TKSMSEQ_ELIMIT; }
     if (!(p->efficiency >= 0.0) || !(p->error_rate >= 0.0)) { ctx->err = "PCR: efficiency and error rate must be non-negative"; return TKSMSEQ_EINVAL; }
@@ -166,19 +167,21 @@ static int pcr_setup(tksmseq_ctx* ctx, const tksmseq_batch* in, const tksmseq_pc
         n_kept = 2 * p->target_count;
         std::vector<std::pair<uint64_t, uint32_t>> key(n);
         for (uint64_t u = 0; u < n; u++) { const Ph4h w = philox_host(p->seed, (uint32_t)u, 0u, 16u, 0u); key[u] = {((uint64_t)w.x << 32) | w.y, (uint32_t)u}; }
+        // std::shuffle + resize (src/pcr.cpp:217-220) = a uniformly random ORDERED subset: the 2 x target molecules with the smallest
+        // keys, in the order of their keys -- the order in which their copies are written
         std::nth_element(key.begin(), key.begin() + (ptrdiff_t)n_kept, key.end());
+        std::sort(key.begin(), key.begin() + (ptrdiff_t)n_kept);
         keep.resize(n_kept);
         for (uint64_t i = 0; i < n_kept; i++) keep[i] = key[i].second;
-        std::sort(keep.begin(), keep.end());
     }
     n_local = n_kept;
     if (sliced) {
         if (keep.empty()) {
             if (p->template_begin != 0 || p->template_end != n) { keep.resize(p->template_end - p->template_begin); for (size_t i = 0; i < keep.size(); i++) keep[i] = (uint32_t)(p->template_begin + i); }
         } else {
-            const auto lo = std::lower_bound(keep.begin(), keep.end(), (uint32_t)p->template_begin);
-            const auto hi = p->template_end > 0xffffffffull ? keep.end() : std::lower_bound(keep.begin(), keep.end(), (uint32_t)p->template_end);
-            keep = std::vector<uint32_t>(lo, hi);
+            // (a slice is a range of POSITIONS in the processing order: with the subsample that is the order of the keys)
+            const uint64_t lo = std::min<uint64_t>(p->template_begin, n_kept), hi = std::min<uint64_t>(p->template_end, n_kept);
+            keep = std::vector<uint32_t>(keep.begin() + (ptrdiff_t)lo, keep.begin() + (ptrdiff_t)hi);
         }
         n_local = (keep.empty() && p->template_begin == 0 && p->template_end == n) ? n : keep.size();
         if (n_local == 0) keep.assign(1, 0u);                     // (an empty slice: a list that is not "every molecule")
@@ -225,7 +228,7 @@ int tksmseq_pcr_template_counts(tksmseq_ctx* ctx, const tksmseq_batch* in, const
     HIPCHK(ctx, hipStreamSynchronize(s));
     if (st & 1u) { ctx->err = "PCR: more than " + std::to_string(tk::PCR_MAX_MUT) + " substitutions per copy (error rate x molecule length) are not supported"; return TKSMSEQ_ELIMIT; }
     std::fill(counts, counts + in->n_reads, 0ull);
-    for (uint64_t i = 0; i < n_kept; i++) counts[keep.empty() ? i : keep[i]] = h[i];
+    for (uint64_t i = 0; i < n_kept; i++) counts[i] = h[i];          // by position in the processing order (beyond n_kept: 0)
     return TKSMSEQ_OK;
 }
 
