@@ -81,7 +81,12 @@ class RunResult:
 
 
 class Sequencer:
-    """One context = one GPU (the reference's module globals: reference_seqs, identities, models)."""
+    """One context = one GPU (the reference's module globals: reference_seqs, identities, models).
+
+    Several contexts in flight (clone(), one host thread and stream each) want a hardware queue each: start the process with
+    GPU_MAX_HW_QUEUES=16 in its environment (read once, when the HIP runtime starts; its default of 4 makes the streams of different
+    contexts share queues, and their kernels then run one after the other).  The `tksm` CLI and bench.py set it for their own
+    processes; importing this module does not touch the embedding application's environment."""
 
     def __init__(self, device=0, stream=None):
         self._lib = L.load()
@@ -95,7 +100,7 @@ class Sequencer:
 
     def clone(self, stream=None):
         """A second Sequencer on the same device that shares this one's packed reference and model tables (for another
-        host thread / batch in flight).  Close clones before the source."""
+        host thread / batch in flight).  Close clones before the source.  (Hardware queues: GPU_MAX_HW_QUEUES=16, see the class.)"""
         other = object.__new__(Sequencer)
         other._lib = self._lib
         ctx = C.c_void_p()
