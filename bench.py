@@ -191,7 +191,7 @@ def launch_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n and not os.environ.get("TKSM_BENCH_SKIP_DEVICE_CHECK"):     # (the variable: for the CPU test of this launcher)
+    if have < n and not os.environ.get("TKSM_BENCH_SKIP_DEVICE_CHECK") and not os.environ.get("TKSM_BENCH_REHEARSE"):     # (the variables: CPU test of this launcher; rehearsal on one GPU)
         print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -262,6 +262,12 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # TKSM_BENCH_REHEARSE=gloo: the N > 1 code of this file -- sharding, exchange thread, buffers, order check -- with every rank on
+    # GPU 0 and the collectives over gloo on host copies (RCCL refuses two ranks on one device): what a one-GPU box can rehearse of
+    # an N-rank run.  Never a measurement: the line carries "rehearsal" and the ranks share one card.
+    rehearse = os.environ.get("TKSM_BENCH_REHEARSE") == "gloo"
+    if rehearse:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the Seq hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -272,7 +278,11 @@ def main():
     if exchange_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    cdev = torch.device("cpu") if rehearse else dev          # where the small collectives' tensors live
     import threading
 
     # ---- inputs resident in HBM before the timed region: genome packed on the device, models, one batch per context
@@ -350,10 +360,11 @@ def main():
         n_reads = args.batch if n_reads is None else n_reads
         with torch.cuda.stream(xstream):
             if args.ordering == "offsets":
-                xbuf["keep"] = ordering.global_offsets(off_t[1:n_reads + 1] - off_t[:n_reads], [n_reads] * world, rank, world)
+                lens = off_t[1:n_reads + 1] - off_t[:n_reads]
+                xbuf["keep"] = ordering.global_offsets(lens.cpu() if rehearse else lens, [n_reads] * world, rank, world)
                 xstream.synchronize()
                 return
-            sizes = ordering.exchange_sizes(n_bytes, n_reads, world, dev)
+            sizes = ordering.exchange_sizes(n_bytes, n_reads, world, cdev)
             if rank == 0:
                 need_b, need_o = int(sizes[:, 0].sum()), int(sizes[:, 1].sum()) + world
                 if xbuf["bytes"] is None or xbuf["bytes"].numel() < need_b:
@@ -361,7 +372,14 @@ def main():
                     xbuf["out"] = torch.empty(int(need_b * 1.02) + 4096, dtype=torch.uint8, device=dev)
                 if xbuf["offs"] is None or xbuf["offs"].numel() < need_o:
                     xbuf["offs"] = torch.empty(need_o, dtype=torch.int64, device=dev)
-            got = ordering.gather_exact(out_t[:n_bytes], off_t[:n_reads + 1], sizes, rank, world, xbuf["bytes"], xbuf["offs"])
+            if rehearse:
+                got = ordering.gather_exact(out_t[:n_bytes].cpu(), off_t[:n_reads + 1].cpu(), sizes, rank, world)
+                if rank == 0:                                     # (host copies over gloo; the interleave runs on the device as always)
+                    hb, bstart, ho, ostart = got
+                    xbuf["bytes"][:hb.numel()].copy_(hb); xbuf["offs"][:ho.numel()].copy_(ho)
+                    got = (xbuf["bytes"], bstart, xbuf["offs"], ostart)
+            else:
+                got = ordering.gather_exact(out_t[:n_bytes], off_t[:n_reads + 1], sizes, rank, world, xbuf["bytes"], xbuf["offs"])
             if rank == 0:
                 fb, bstart, fo, ostart = got
                 xbuf["n_out"] = xseq.interleave_records([fb.data_ptr() + int(bstart[p]) for p in range(world)], [fo.data_ptr() + 8 * int(ostart[p]) for p in range(world)],
@@ -450,13 +468,13 @@ def main():
                 res["bytes"] = n_out
                 res["equal"] = bool(n_out == int(rw.records_bytes) and torch.equal(xbuf["out"][:n_out], out_t[:n_out]))
             else:
-                ok = bool(total == int(rw.records_bytes) and torch.equal(my_off, woff[rank:nv * world:world]))
+                ok = bool(total == int(rw.records_bytes) and torch.equal(my_off.to(dev), woff[rank:nv * world:world]))
                 res["bytes"] = int(total)
                 res["equal"] = ok
             wb.free()
         c.batch = keep
         if args.ordering == "offsets":
-            flag = torch.tensor([1 if res["equal"] else 0], dtype=torch.int64, device=dev)
+            flag = torch.tensor([1 if res["equal"] else 0], dtype=torch.int64, device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             res["equal"] = bool(flag.item())
         return res
@@ -494,10 +512,10 @@ def main():
     if exchange_on and args.order_check_reads > 0 and not args.perfect:
         order_check = run_order_check()
     if exchange_on:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        agg = torch.tensor([bases_in, bases_out], dtype=torch.float64, device=dev)
+        agg = torch.tensor([bases_in, bases_out], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg)
         bases_in_all, bases_out_all = float(agg[0].item()), float(agg[1].item())
     else:
@@ -544,7 +562,8 @@ def main():
                    "kind": args.kind, "molecules_per_gpu_per_step": args.batch, "mean_len": args.mean_len,
                    "length_distribution": f"lognormal(median {args.mean_len}, sigma {args.lognormal_sigma})" if args.lognormal_sigma else f"normal({args.mean_len}, {args.mean_len * 0.2:.0f})",
                    "compute_qual": bool(compute_q and not args.perfect), "sharding": f"round-robin x{world}",
-                   "ordering": (args.ordering if exchange_on else None), "contexts_in_flight_per_gpu": n_ctx},
+                   "ordering": (args.ordering if exchange_on else None), "contexts_in_flight_per_gpu": n_ctx,
+                   **({"rehearsal": "every rank on GPU 0, collectives over gloo on host copies: not a measurement"} if rehearse else {})},
         "gbases_per_s": bases_in_all / elapsed / 1e9,
         "gbases_out_per_s": bases_out_all / elapsed / 1e9,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -75,6 +75,21 @@ def test_exchange_path_on_one_rank_orders_like_the_plain_run(ordering):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,ordering", [(2, "gather"), (3, "gather"), (2, "offsets")])
+def test_n_rank_logic_rehearsed_on_one_gpu(ranks, ordering):
+    """`python bench.py --gpus N` with TKSM_BENCH_REHEARSE=gloo: N real ranks (launcher, torch.distributed.run, RANK / WORLD_SIZE), all on
+    GPU 0, the collectives over gloo on host copies -- RCCL refuses two ranks on one device, so this is what a one-GPU box can run of an
+    N-rank job: round-robin shards with stride N through the kernels, the exchange thread and its buffers, the device interleave of N
+    streams, max-over-ranks timing, and the FASTQ order check against one rank's run of the whole set."""
+    r = _bench("--gpus", str(ranks), "--ordering", ordering, *SMALL, env={"TKSM_BENCH_REHEARSE": "gloo"}, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == ranks and line["config"]["sharding"] == f"round-robin x{ranks}" and "rehearsal" in line["config"]
+    oc = line["order_check"]
+    assert oc["equal"] is True and oc["reads"] == 20000 * ranks and oc["bytes"] > 20000 * ranks * 1500
+
+
+@pytest.mark.gpu
 def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
     """`python bench.py --gpus 2` with no launcher around it: two ranks over RCCL, n_gpus == 2, order check green"""
     import torch
