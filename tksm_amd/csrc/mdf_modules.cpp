@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -270,40 +271,45 @@ extern "C" int tksmseq_truncate_main(int argc0, char** argv0) {
     if (!open_log(c, "truncate", log)) return 1;
     if (!kde.empty()) { p.mode = TKSMSEQ_TRC_KDE; p.kde_model_path = kde.c_str(); }
     p.seed = (uint64_t)c.seed;
-    tkmod::ChunkReader rd;
-    rd.in = fopen(c.input.c_str(), "rb");
-    if (!rd.in) { fprintf(stderr, "Could not open file %s\n", c.input.c_str()); return 1; }
-    rd.bytes = c.batch_bytes;
     // a reader thread of its own cuts the input into pieces of whole molecules and numbers them (input order), a few pieces ahead of the
-    // workers: what the engine serialises is a pop from this queue, not the read + scan of a piece
-    std::mutex q_m; std::condition_variable q_put, q_get; std::deque<Piece> pieces; bool q_done = false, q_stop = false;
-    const size_t q_cap = c.devices.size() * 2 + 1;
-    std::thread reader([&]() {
+    // workers: what the engine serialises is a pop from this queue, not the read + scan of a piece.  Its state lives on the heap and is
+    // shared with the thread: after an error the module returns without waiting for a reader that may sit in a read() on a pipe nobody
+    // closes (the thread is detached and ends with the process).
+    struct ReaderState {
+        tkmod::ChunkReader rd;
+        std::mutex m; std::condition_variable put, get; std::deque<Piece> pieces; bool done = false, stop = false; size_t cap = 3;
+    };
+    auto rs = std::make_shared<ReaderState>();
+    rs->rd.in = fopen(c.input.c_str(), "rb");
+    if (!rs->rd.in) { fprintf(stderr, "Could not open file %s\n", c.input.c_str()); return 1; }
+    rs->rd.bytes = c.batch_bytes;
+    rs->cap = c.devices.size() * 2 + 1;
+    std::thread reader([rs]() {
         uint64_t seq = 0, first = 0;
         for (;;) {
             Piece pc;
-            if (!rd.next(pc.text)) {
+            if (!rs->rd.next(pc.text)) {
                 if (seq) break;
                 pc.text.clear();                                  // an empty input still makes an (empty) output
             }
             pc.seq = seq++; pc.first = first;
             first += tkmod::count_reads(pc.text.data(), pc.text.size());
-            std::unique_lock<std::mutex> l(q_m);
-            q_put.wait(l, [&] { return pieces.size() < q_cap || q_stop; });
-            if (q_stop) break;
-            pieces.push_back(std::move(pc));
-            q_get.notify_one();
+            std::unique_lock<std::mutex> l(rs->m);
+            rs->put.wait(l, [&] { return rs->pieces.size() < rs->cap || rs->stop; });
+            if (rs->stop) break;
+            rs->pieces.push_back(std::move(pc));
+            rs->get.notify_one();
         }
-        { std::lock_guard<std::mutex> l(q_m); q_done = true; }
-        q_get.notify_all();
+        { std::lock_guard<std::mutex> l(rs->m); rs->done = true; }
+        rs->get.notify_all();
     });
     auto prepare = [&](tksmseq_ctx*, void**) -> bool { return true; };
     auto next_piece = [&](Piece& pc) -> bool {
-        std::unique_lock<std::mutex> l(q_m);
-        q_get.wait(l, [&] { return !pieces.empty() || q_done; });
-        if (pieces.empty()) return false;
-        pc = std::move(pieces.front()); pieces.pop_front();
-        q_put.notify_one();
+        std::unique_lock<std::mutex> l(rs->m);
+        rs->get.wait(l, [&] { return !rs->pieces.empty() || rs->done; });
+        if (rs->pieces.empty()) return false;
+        pc = std::move(rs->pieces.front()); rs->pieces.pop_front();
+        rs->put.notify_one();
         return true;
     };
     auto work = [&](tksmseq_ctx* ctx, void*, const Piece& pc, tksmseq_batch** out) -> int {
@@ -317,9 +323,10 @@ extern "C" int tksmseq_truncate_main(int argc0, char** argv0) {
         return rc;
     };
     const int rc = run_pieces(c, log, "truncate", prepare, next_piece, work);
-    { std::lock_guard<std::mutex> l(q_m); q_stop = true; }          // (an error: the reader may be waiting for room)
-    q_put.notify_all();
-    reader.join();
-    fclose(rd.in);
+    bool finished;
+    { std::lock_guard<std::mutex> l(rs->m); rs->stop = true; finished = rs->done; }      // (an error: the reader may be waiting for room, or for input)
+    rs->put.notify_all();
+    if (rc == 0 || finished) { reader.join(); fclose(rs->rd.in); }
+    else reader.detach();
     return rc;
 }
