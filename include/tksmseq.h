@@ -173,6 +173,10 @@ int tksmseq_batch_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len
  * the context does not know stay what they are (the writer prints them back), substitution positions are not checked. */
 int tksmseq_molecules_from_mdf_text(tksmseq_ctx* ctx, const char* text, uint64_t len, tksmseq_batch** out);
 int tksmseq_batch_info(const tksmseq_batch* b, uint64_t* n_reads, uint64_t* n_intervals, uint64_t* n_mods);
+/* Releases a batch.  `ctx`: the context that last ran / transformed the batch -- its stream is drained first, then the batch's device
+ * tables go back to the library's per-process cache of device blocks (not to the driver: hipFree waits for the whole device), from
+ * which the next batch of about that size takes them.  A caller that used the batch on SEVERAL contexts frees it through the last one
+ * after the others have been synchronised (tksmseq_synchronize).  ctx may be NULL once every context has been destroyed. */
 void tksmseq_batch_free(tksmseq_ctx* ctx, tksmseq_batch* b);
 
 /* ---- the hot path ----------------------------------------------------------------------------

@@ -868,7 +868,8 @@ def test_bench_size_batch_every_record_by_digest(po, oracle_models, kind, n, sig
     assert len(off) == n + 1 and int(off[-1]) == len(rec) and rec.count(b"\n") == 4 * n
     ident = po.Identities(84.0, 5.5, 99.0)
     tag = "lognormal" if sigma else kind
-    if os.path.exists(os.path.join(GOLDEN, f"bench_digests_{tag}.json")):
+    assert os.path.exists(os.path.join(GOLDEN, f"bench_digests_{tag}.json")), "python tests/golden/make_bench_digests.py " + tag
+    if True:
         import hashlib
         import json
         gold = json.load(open(os.path.join(GOLDEN, f"bench_digests_{tag}.json")))
