@@ -1,9 +1,10 @@
 #!/bin/bash
-# duration of the FIRST k_alnf<0,14> launch of each run (round 0: the same jobs whatever the library does with the results)
+# A/B of alignment-kernel variants: duration of the FIRST k_alnf<0,14> launch of each run (round 0: the same 1.7 M jobs whatever the library
+# does with the results).  usage (GPU box, repo root): bash tools/first_aln_ab.sh libtksmseq.so libtksmseq_<variant>.so ...   (names under tksm_amd/)
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
-for lib in libtksmseq.so libtksmseq_exp_w32.so libtksmseq.so libtksmseq_exp_w32.so; do
+for lib in "$@"; do
   rm -rf $R/gpurun_out/fa
   TKSMSEQ_LIB=$lib timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/fa -- python3 $R/tools/quick_stage_times.py 1703936 > $R/gpurun_out/fa.log 2>&1
   python3 - <<PY
