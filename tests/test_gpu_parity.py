@@ -779,6 +779,26 @@ def test_cli_devices_list_threads_and_error_path(tmp_path, po, oracle_models):
     assert r.returncode == 1 and "write failed" in r.stderr
     r = subprocess.run(base + ["-o", str(tmp_path / "x.fastq"), "--devices", "99"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 1 and "device index out of range" in r.stderr
+    # ... and with the input coming through a pipe whose writer neither writes on nor closes (Snakemake's pipes, Snakefile:283-305): the
+    # reader polls the descriptor and gives up once a worker has failed, instead of sleeping in read() until the producer goes away
+    import time
+    fin = tmp_path / "in.mdf.pipe"
+    os.mkfifo(fin)
+    hold = threading.Event()
+    def feed():
+        with open(fin, "wb") as w:
+            w.write(open(os.path.join(d, "mols.mdf"), "rb").read())
+            w.flush()
+            hold.wait(120)                                  # keeps the write end open
+    fw = threading.Thread(target=feed, daemon=True)
+    fw.start()
+    t0 = time.time()
+    r = subprocess.run([exe, "sequence", "-i", str(fin), "-r", os.path.join(d, "ref.fa"), "-s", "11", "--batch-bytes", "2048", "-o", "/dev/full", "--skip-qual-compute"],
+                       capture_output=True, text=True, env=env, timeout=100)
+    took = time.time() - t0
+    hold.set()
+    fw.join(timeout=30)
+    assert r.returncode == 1 and "write failed" in r.stderr and took < 60, (r.returncode, took, r.stderr[-300:])
 
 
 @pytest.mark.gpu

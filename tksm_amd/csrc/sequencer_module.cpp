@@ -18,6 +18,7 @@
 #include "sequencer_module.h"
 
 #include <fcntl.h>
+#include <poll.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -496,6 +497,12 @@ public:
 
         FILE* in = fopen(a.input.c_str(), "rb");
         if (!in) { destroy_all(); return die("Error: cannot open " + a.input); }
+        // the input is read through its descriptor: a pipe (Snakemake's `tksm ... | tksm sequence -i /dev/stdin`, Snakefile:283-305) may stay
+        // open with nothing to read while a worker has already failed -- the reader polls it and gives up then, instead of sleeping in a
+        // read() until the producer closes
+        const int in_fd = fileno(in);
+        bool in_regular = false;
+        { struct stat st_in; in_regular = fstat(in_fd, &st_in) == 0 && S_ISREG(st_in.st_mode); }
         if (!a.badread.empty() && !wb.open(a.badread)) { fclose(in); destroy_all(); return die("Error: cannot open " + a.badread); }
         if (!a.perfect.empty() && !wp.open(a.perfect)) { fclose(in); wb.close(); destroy_all(); return die("Error: cannot open " + a.perfect); }
         ChunkQueue queue;
@@ -791,6 +798,22 @@ public:
         std::thread writer;
         if (!positional && !behind) writer = std::thread(write_all);
 
+        auto read_full = [&](char* dst, size_t n) -> size_t {          // like fread(dst, 1, n, in): n bytes unless the input ends -- or the run has failed
+            size_t got = 0;
+            while (got < n && !failed) {
+                if (!in_regular) {
+                    struct pollfd pf; pf.fd = in_fd; pf.events = POLLIN; pf.revents = 0;
+                    const int pr = poll(&pf, 1, 200);
+                    if (pr == 0) continue;
+                    if (pr < 0) { if (errno == EINTR) continue; break; }
+                }
+                const ssize_t r = ::read(in_fd, dst + got, std::min<size_t>(n - got, (size_t)1 << 30));
+                if (r < 0) { if (errno == EINTR) continue; break; }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            return got;
+        };
         // reader: batches of whole molecules, numbered; the first read index of a batch is known before it is parsed
         std::vector<char> buf;
         uint64_t read_index = 0, seq = 0;
@@ -801,7 +824,7 @@ public:
             // copies per template (tksmseq_pcr_template_counts) cut them into slices of about --pcr-slice-molecules copies, which
             // the parser threads amplify (and truncate) in place of parsing text
             std::vector<char> all;
-            { char tmp[1 << 16]; size_t n2; while ((n2 = fread(tmp, 1, sizeof tmp, in)) > 0) all.insert(all.end(), tmp, tmp + n2); }
+            { std::vector<char> tmp(1 << 20); size_t n2; while ((n2 = read_full(tmp.data(), tmp.size())) > 0) all.insert(all.end(), tmp.begin(), tmp.begin() + (ptrdiff_t)n2); }
             for (int g = 0; g < n_groups && !failed; g++)
                 if (tksmseq_molecules_from_mdf_text(pctx[(size_t)g * parsers_per_group], all.data(), all.size(), &templates[(size_t)g])) set_error(tksmseq_last_error(pctx[(size_t)g * parsers_per_group]));
             uint64_t nt = 0;
@@ -829,7 +852,7 @@ public:
             // fill up to batch_bytes, then cut at the last molecule header so a batch holds whole molecules
             const auto t_read = now();
             buf.resize(have + a.batch_bytes);
-            size_t got = eof ? 0 : fread(buf.data() + have, 1, a.batch_bytes, in);
+            size_t got = eof ? 0 : read_full(buf.data() + have, a.batch_bytes);
             if (got < a.batch_bytes) eof = true;
             have += got;
             size_t cut = have;
