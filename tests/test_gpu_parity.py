@@ -1030,3 +1030,43 @@ def test_cli_reads_mdf_from_a_pipe_and_chains_with_the_mdf_modules(tmp_path):
     p1.stdout.close()
     assert p1.wait(timeout=120) == 0 and p2.returncode == 0, p2.stderr
     assert o_pipe.read_bytes() == o_file.read_bytes() and len(o_file.read_bytes()) > 1000
+
+
+@pytest.mark.gpu
+def test_cli_stream_equals_one_api_batch_at_scale(tmp_path):
+    """`tksm sequence` streaming 300 000 bulk molecules in ~20 batches (three in flight, four parse threads, records written behind the
+    workers at their offsets) writes the bytes ONE tksmseq_run of the same molecules gives through the API -- which the digest tests tie to
+    the oracle record for record: read numbering across batches, the multi-threaded parser, the staging buffers and the positional writes
+    at scale (the reference's `for read_dict in mapper(...)` loop over the whole MDF, py/sequence.py:360-370)."""
+    import subprocess
+    from conftest import ROOT
+    from tksm_amd import synthetic
+    from tksm_amd.sequence import Sequencer
+    rs = np.random.RandomState(77)
+    lens = [3_000_000] * 3
+    names = ["chrA", "chrB", "chrC"]
+    ref = {nm: rs.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes() for nm, L in zip(names, lens)}
+    with open(tmp_path / "ref.fa", "wb") as f:
+        for nm in names:
+            f.write(b">" + nm.encode() + b"\n" + ref[nm] + b"\n")
+    n = 300_000
+    m = synthetic.make_molecules(rs, lens, n, 1000, 200)
+    text = synthetic.mdf_text(m, names)
+    (tmp_path / "mols.mdf").write_text(text)
+    exe = os.path.join(ROOT, "tksm_amd", "tksm")
+    env = dict(os.environ, TKSM_MODELS=os.path.join(ROOT, "tksm_amd", "models"))
+    out = tmp_path / "out.fastq"
+    r = subprocess.run([exe, "sequence", "-i", str(tmp_path / "mols.mdf"), "-r", str(tmp_path / "ref.fa"), "-o", str(out), "-s", "31", "-t", "4",
+                        "--batch-bytes", str(1 << 20), "--verbosity", "ERROR"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    s = Sequencer(0)
+    for nm in names:
+        s.add_contig(nm, ref[nm])
+    s.set_identity(84.0, 99.0, 5.5)
+    s.load_error_model(ERR_MODEL)
+    s.load_qscore_model(QS_MODEL)
+    b = s.batch_from_mdf(text)
+    rec, off = s.run(b, target="badread", fastq=True, compute_qual=True, seed=31).download()
+    b.free(); s.close()
+    got = out.read_bytes()
+    assert len(off) == n + 1 and len(got) == len(rec) and got == rec
