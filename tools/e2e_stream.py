@@ -1,7 +1,8 @@
 """The end-to-end streaming leg of bench.py on its own, for A/B runs of the CLI's knobs: `tksm sequence` on N molecules (blocks of 1 M distinct
 ones) into /dev/null with the CLI's stage clocks (TKSMSEQ_STATS_FILE) and, with V=2, its per-batch timeline on stderr.
 
-    python tools/e2e_stream.py [molecules=32000000] [-- extra CLI arguments ...]      env: V=<TKSMSEQ_VERBOSE level>, E2E_DIR, OUT=<path instead of /dev/null>
+    python tools/e2e_stream.py [molecules=32000000] [-- extra CLI arguments ...]      env: V=<TKSMSEQ_VERBOSE level>, E2E_DIR, OUT=<path instead of /dev/null>,
+                                                                                          KIND=bulk|scrna|pcr (synthetic.make_molecules; scrna = BASELINE config 3's barcode / UMI / polyA literals)
 """
 import json
 import os
@@ -25,7 +26,8 @@ def main():
     n = int(a[0]) if a else 32_000_000
     d = os.environ.get("E2E_DIR", "/tmp/e2e_stream")
     os.makedirs(d, exist_ok=True)
-    mdf = f"{d}/stream_{n}.mdf"
+    kind = os.environ.get("KIND", "bulk")
+    mdf = f"{d}/stream_{kind}_{n}.mdf"
     if not os.path.exists(mdf) or not os.path.exists(f"{d}/ref.fa"):
         rs = np.random.RandomState(1)
         lens = [8_000_000] * 4
@@ -34,7 +36,7 @@ def main():
                 s = rs.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes().decode()
                 f.write(f">chr{c + 1}\n" + "\n".join(s[i:i + 80] for i in range(0, L, 80)) + "\n")
         block = min(n, 1_000_000)
-        text = synthetic.mdf_text(synthetic.make_molecules(rs, lens, block, 1000, 200), [f"chr{c + 1}" for c in range(4)])
+        text = synthetic.mdf_text(synthetic.make_molecules(rs, lens, block, 1000, 200, kind=kind), [f"chr{c + 1}" for c in range(4)])
         with open(mdf, "w") as f:
             for _ in range(max(1, n // block)):
                 f.write(text)
@@ -52,7 +54,7 @@ def main():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     wall = time.time() - t0
     st = json.load(open(stats)) if os.path.exists(stats) else {}
-    print(f"extra={extra} rc={r.returncode} wall {wall:.2f} s; stream {st.get('stream_s')} s = {st.get('reads', 0) / max(1e-9, st.get('stream_s', 1)) / 1e6:.2f} M reads/s; "
+    print(f"kind={kind} molecules={st.get('reads')} mdf {os.path.getsize(mdf) / 1e9:.2f} GB, records {st.get('record_bytes', 0) / 1e9:.1f} GB; extra={extra} rc={r.returncode} wall {wall:.2f} s; stream {st.get('stream_s')} s = {st.get('reads', 0) / max(1e-9, st.get('stream_s', 1)) / 1e6:.2f} M reads/s; "
           f"batches {st.get('batches')}; summed stage seconds: read {st.get('read_count_s')}, parse {st.get('parse_s')}, run {st.get('run_s')}, device copy {st.get('device_copy_s')}, "
           f"d2h wait {st.get('d2h_wait_s')}, write {st.get('write_s')}, wait for writer {st.get('wait_for_writer_s')}", flush=True)
     if os.environ.get("V"):
