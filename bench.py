@@ -298,7 +298,7 @@ def main():
     ctxs = []
     for i in range(n_ctx):
         c = Ctx()
-        c.stream = torch.cuda.Stream(device=dev)
+        c.stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BENCH_STREAM_PRIORITY", "0")))    # (diagnostic: queue priority of the contexts' main streams)
         ctxs.append(c)
     first = ctxs[0]
     first.seqr = Sequencer(local_rank, stream=first.stream.cuda_stream)

@@ -47,6 +47,7 @@ int tksmseq_create(int device, tksmseq_ctx** out) {
     if (const char* tc = getenv("TKSMSEQ_TAIL_WAVE")) c->tail_wave = (uint32_t)atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_TAIL_WCAP")) c->tail_wcap = atoi(tc);
     if (const char* tc = getenv("TKSMSEQ_EARLY_TAIL")) c->early_tail = (uint32_t)std::min(4096, std::max(0, atoi(tc)));
+    if (const char* tc = getenv("TKSMSEQ_ALN_STREAM_PRIORITY")) { c->aln_prio_set = 1; c->aln_prio = atoi(tc); }
     if (const char* tc = getenv("TKSMSEQ_ALN_LDS_PAD")) c->aln_lds_pad = (unsigned)std::min(60000, std::max(0, atoi(tc)));
     if (const char* hl = getenv("TKSMSEQ_HBM_STATE_LEN")) c->hbm_state_len = atoi(hl);
     if (const char* dl = getenv("TKSMSEQ_DEFER_LEN")) c->defer_len = atoi(dl);
@@ -113,6 +114,9 @@ void tksmseq_destroy(tksmseq_ctx* ctx) {
     for (auto& ev : ctx->evpool) (void)hipEventDestroy(ev);
     for (auto& st : ctx->side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (ctx->early_stream) { (void)hipStreamSynchronize(ctx->early_stream); (void)hipStreamDestroy(ctx->early_stream); }
+    if (ctx->aln_stream) { (void)hipStreamSynchronize(ctx->aln_stream); (void)hipStreamDestroy(ctx->aln_stream); }
+    if (ctx->aln_start) (void)hipEventDestroy(ctx->aln_start);
+    if (ctx->aln_done) (void)hipEventDestroy(ctx->aln_done);
     if (ctx->early_start) (void)hipEventDestroy(ctx->early_start);
     if (ctx->early_done) (void)hipEventDestroy(ctx->early_done);
     for (auto& ev : ctx->side_done) if (ev) (void)hipEventDestroy(ev);
@@ -886,6 +890,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
             ~SideGuard() {
                 for (int k2 = 0; k2 < tksmseq_ctx::N_SIDE; k2++) if (c->side_used[k2] && c->side[k2]) (void)hipStreamSynchronize(c->side[k2]);
                 if (c->early_stream) (void)hipStreamSynchronize(c->early_stream);
+                if (c->aln_stream) (void)hipStreamSynchronize(c->aln_stream);
             }
         } side_guard{ctx};
         auto launch_side = [&](uint32_t upto) -> int {
@@ -1060,7 +1065,22 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
                 const uint32_t n_jobs = hbase_cur[FB.n_ranges - 1] + ((hcnt[(size_t)(FB.n_ranges - 1) * 32] + 63) & ~63u);
                 const bool full_only = cnt[0] <= std::min(ctx->small_aln, FB.full_rows);
                 jobs_all += cnt[0]; if (!full_only) jobs_14 += cnt[0];
-                HIPCHK(ctx, tk::launch_alnf(P, FB, O, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, s));
+                hipStream_t as = s;
+                if (ctx->aln_prio_set && !full_only) {
+                    if (!ctx->aln_stream) {
+                        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aln_stream, hipStreamNonBlocking, ctx->aln_prio));
+                        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aln_start, hipEventDisableTiming));
+                        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aln_done, hipEventDisableTiming));
+                    }
+                    HIPCHK(ctx, hipEventRecord(ctx->aln_start, s));
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->aln_stream, ctx->aln_start, 0));
+                    as = ctx->aln_stream;
+                }
+                HIPCHK(ctx, tk::launch_alnf(P, FB, O, n_jobs, full_only, qround ? 1 : 0, ctx->aln_lds_pad, as));
+                if (as != s) {
+                    HIPCHK(ctx, hipEventRecord(ctx->aln_done, as));
+                    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->aln_done, 0));
+                }
             }
             if (tick()) { ctx->err = "event"; return TKSMSEQ_EDEVICE; }
             kinds.push_back(2);

@@ -170,6 +170,10 @@ struct tksmseq_ctx : ContigLookup {
     // predicted stragglers: their straggler-kernel launch runs on a stream of its own from round 0 on (api.cpp)
     hipStream_t early_stream = nullptr;
     hipEvent_t early_start = nullptr, early_done = nullptr;
+    // the wide alignment passes on a stream of their own priority (TKSMSEQ_ALN_STREAM_PRIORITY; api.cpp)
+    hipStream_t aln_stream = nullptr;
+    hipEvent_t aln_start = nullptr, aln_done = nullptr;
+    int aln_prio_set = 0, aln_prio = 0;
     uint32_t early_tail = 1024;           // at most this many reads (and only from a batch with a long tail of predicted visits); 0: never
     DevBuf f_early;
     bool own_stream = false;
