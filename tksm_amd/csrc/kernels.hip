@@ -1305,8 +1305,9 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
     // gathers that go to the read's own rows and the big tables are paid once per pass, not once per four draws.  Phase 3 applies
     // them in draw order; the no-op draws in between only advance the draw counter (the stop rules move with applied changes
     // alone).  Draws behind the LOOP_K-th changing one, a re-estimation point or the end of the loop are dropped and drawn again.
+    // (the k-mer index of a chosen draw is cut out of the fragment words again in phase 2: a second array for the indices would make
+    // the wave's LDS 22 KB -- seven waves per CU; at 20 KB it is eight, two on every SIMD)
     uint32_t* ldi = lf + (size_t)Wl * 64;                     // [LOOP_N][64] draw positions of the pass
-    uint16_t* lki = reinterpret_cast<uint16_t*>(ldi + LOOP_N * 64);   // [LOOP_N][64] their k-mer indices
     while (__ballot(st == RUN) != 0ull) {
         if (st != RUN) continue;
         const uint32_t navail = (uint32_t)max(0ll, min((long long)LOOP_N, loop_limit - (long long)n));     // draws of this pass below the loop limit
@@ -1327,7 +1328,7 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                 const uint32_t hi = w < Wl ? lf[w * 64 + lane] : f2[w], lo = w + 1 < Wl ? lf[(w + 1) * 64 + lane] : f2[w + 1];
 #endif
                 const uint32_t kx = (uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask;
-                ldi[b * 64 + lane] = (uint32_t)di1; lki[b * 64 + lane] = (uint16_t)kx;
+                ldi[b * 64 + lane] = (uint32_t)di1;
 #ifdef TKSM_ABLATE
                 t0v[b] = abl_t0 ? 0xCF000000u : EM.pseg[kx].x;
 #else
@@ -1353,7 +1354,10 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                 const uint32_t bb = min(bj[j], (uint32_t)LOOP_N - 1u);
                 const Ph4 d = philox(P.seed, g, ST_DRAW, n + bb);
                 dw[j] = d.y;
-                di[j] = (int)ldi[bb * 64 + lane]; kidx[j] = (int)lki[bb * 64 + lane];
+                di[j] = (int)ldi[bb * 64 + lane];
+                const int w = di[j] >> 4, o = di[j] & 15;
+                const uint32_t hi = w < Wl ? lf[w * 64 + lane] : f2[w], lo = w + 1 < Wl ? lf[(w + 1) * 64 + lane] : f2[w + 1];
+                kidx[j] = (int)((uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask);
             }
             rest = mm != 0u;
         }
@@ -3055,7 +3059,7 @@ hipError_t launch_loop(const ErrModelView& em, const SimParams& p, const FastBuf
                        uint32_t count, int lcap, int from_jobs, uint32_t c0, uint32_t c1, hipStream_t s) {
     if (!count) return hipSuccess;
     const int Wl = loop_lds_words(lcap);
-    hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256 + (size_t)LOOP_N * 64 * 6, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
+    hipLaunchKernelGGL(k_loop, dim3((count + 63) / 64), dim3(64), (size_t)Wl * 256 + (size_t)LOOP_N * 64 * 4, s, em, p, fb, order, begin, count, Wl, from_jobs, c0, c1);
     return hipGetLastError();
 }
 hipError_t launch_loopw(const ErrModelView& em, const SimParams& p, const FastBuffers& fb, const uint32_t* order, uint32_t begin,
