@@ -1222,7 +1222,11 @@ DEV void join_out(const uint8_t* frag, const uint16_t* nb, int n, uint8_t* out_s
 // slot codes stay in HBM (read and written only by the draws that change something).
 // A read that stops at a re-estimation point gets an alignment job here (id, meta record: k_alnf decodes and aligns its window
 // it; pending = 1); one whose loop has ended waits in stage 3 for its q-score job and its last visit (k_qjobs, k_err).
-constexpr int LOOP_N = 16, LOOP_K = 3;      // draws per pass of k_loop; changing draws applied per pass
+#ifndef TKSM_LOOP_N                          // (diagnostic builds of tools/exp_ab.sh vary them)
+#define TKSM_LOOP_N 16
+#define TKSM_LOOP_K 3
+#endif
+constexpr int LOOP_N = TKSM_LOOP_N, LOOP_K = TKSM_LOOP_K;      // draws per pass of k_loop; changing draws applied per pass
 __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastBuffers FB, const uint32_t* __restrict__ order,
                                               uint32_t begin, uint32_t count, int Wl, int from_jobs, uint32_t c0, uint32_t c1) {
 #ifndef TKSM_ABLATE
