@@ -2629,7 +2629,9 @@ constexpr int EMIT_IMG = 6144;           // LDS image of a Badread record (bytes
 // Record formatting of the Badread path (py/sequence.py:242-258, :273-300): header, sequence and quality line of a read
 // are assembled as an image in LDS (16 bytes per lane from the read's scratch slot) and leave in aligned 16-byte pieces,
 // like k_perfect's records.
-__global__ __launch_bounds__(256) void k_emit(BatchView B, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
+// (six waves per SIMD: what the workgroup's 25 KB of LDS allow.  Left to itself the compiler takes 110 registers -- four waves -- for a kernel
+// that waits for its loads: 3.2 -> 1.5 ms per step, + 1.5 % on the bench)
+__global__ __launch_bounds__(256, 6) void k_emit(BatchView B, SimParams P, SimBuffers O, const uint64_t* __restrict__ rec_off,
                                                uint8_t* __restrict__ records) {
     __shared__ __attribute__((aligned(16))) uint8_t img_all[WAVES_PER_WG][EMIT_IMG + 32];
     __shared__ uint8_t hdr_all[WAVES_PER_WG][160];
