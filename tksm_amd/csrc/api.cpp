@@ -305,6 +305,10 @@ int tksmseq_load_qscore_model(tksmseq_ctx* ctx, const char* name_or_path) {
         const size_t ns = (size_t)m2.n_slots;
         std::vector<uint32_t> ent(ns * 4, 0), pairs(m2.q_pool.size() * 2, 0);
         std::vector<uint8_t> guide(ns * 64, 0);
+        // (the flag bit needs candidate indices and q values below 128: every model we know of; otherwise the plain guide)
+        bool direct = true;
+        for (size_t s2 = 0; s2 < ns; s2++) if (m2.keys[s2] && m2.row_cnt[s2] > 128) direct = false;
+        for (uint8_t qv : m2.q_pool) if (qv > 127) direct = false;
         for (size_t i = 0; i < m2.q_pool.size(); i++) { pairs[2 * i] = m2.cdf_pool[i]; pairs[2 * i + 1] = m2.q_pool[i]; }
         for (size_t s2 = 0; s2 < ns; s2++) {
             ent[4 * s2] = (uint32_t)m2.keys[s2]; ent[4 * s2 + 1] = (uint32_t)(m2.keys[s2] >> 32);
@@ -315,11 +319,15 @@ int tksmseq_load_qscore_model(tksmseq_ctx* ctx, const char* name_or_path) {
             uint32_t a = 0;
             for (uint32_t bkt = 0; bkt < 64; bkt++) {
                 // entries whose threshold is <= the smallest draw of the bucket can never be chosen in it
-                const uint32_t wmin = bkt << 26;
+                const uint32_t wmin = bkt << 26, wmax = wmin | 0x3ffffffu;
                 while (a + 1 < cnt && m2.cdf_pool[off + a] <= wmin) a++;
-                guide[s2 * 64 + bkt] = (uint8_t)a;
+                // ... and if the largest draw of the bucket stops at the same entry, the bucket IS that entry's q: no row read
+                uint32_t ah = a;
+                while (ah + 1 < cnt && m2.cdf_pool[off + ah] <= wmax) ah++;
+                guide[s2 * 64 + bkt] = (direct && ah == a) ? (uint8_t)(0x80u | m2.q_pool[off + a]) : (uint8_t)a;
             }
         }
+        ctx->qm.guide_direct = direct;
         if ((rc = upload(ctx, ctx->d_qent, ent))) return rc;
         if ((rc = upload(ctx, ctx->d_qpairs, pairs))) return rc;
         return upload(ctx, ctx->d_qguide, guide);
@@ -673,7 +681,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
     tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>(), ctx->d_pseg.as<uint4>(), ctx->d_altenc.as<uint4>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
-                       ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>()};
+                       ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>(), ctx->qm.guide_direct ? 1 : 0};
     tk::IdentView IM{ctx->idm.constant ? 1 : 0, ctx->idm.value, ctx->d_qtab.as<double>()};
     tk::SimParams P{};
     P.seed = p->seed; P.first_read = p->first_read_index; P.stride = p->read_index_stride ? p->read_index_stride : 1;

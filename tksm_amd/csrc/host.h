@@ -18,6 +18,7 @@ struct ErrorModelHost {
 
 struct QScoreModelHost {
     int n_slots = 0, kmer_size = 1;
+    bool guide_direct = false;          // the device guide table carries q itself for single-entry buckets (api.cpp)
     std::vector<uint64_t> keys;
     std::vector<uint32_t> row_off, row_cnt, cdf_pool;
     std::vector<uint8_t> q_pool;

@@ -52,10 +52,12 @@ struct QsModelView {
     const uint32_t* cdf_pool;
     const uint8_t* q_pool;
     // the same model in the layout k_err reads: one 16-byte hash entry {key, row offset, row count}, rows as
-    // {threshold, q} pairs, and a 64-bucket guide (first candidate index per quantile bucket of the draw)
+    // {threshold, q} pairs, and a 64-bucket guide per hash slot: the first candidate index for the quantile bucket of the draw -- or,
+    // with guide_direct, 0x80 | q where every draw of the bucket picks the same entry (no row read at all)
     const uint4* ent;
     const uint2* pairs;
     const uint8_t* guide;
+    int guide_direct;
 };
 
 struct IdentView {

@@ -2016,8 +2016,8 @@ __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, Qs
             if (P.ablate == 42) { out_qual[i2 - lo] = (uint8_t)(33 + (row & 31)); continue; }   // timing experiment: no draw, no row lookup
             if (P.ablate == 43 && row >= 0) {                                                     // ... a row lookup without the generator
                 const uint32_t w = (uint32_t)i2 * 2654435761u;
-                const uint32_t a2 = QM.guide[(size_t)row * 64 + (w >> 26)];
-                out_qual[i2 - lo] = (uint8_t)(33 + QM.pairs[roff + a2].y); continue;
+                const uint32_t a2 = QM.guide[(size_t)row * 64 + (w >> 26)] & 0x7fu;
+                out_qual[i2 - lo] = (uint8_t)(33 + QM.pairs[roff + min(a2, rcnt - 1u)].y); continue;
             }
 #endif
             if (row >= 0) {
@@ -2025,9 +2025,12 @@ __global__ __launch_bounds__(256, 8) void k_err(BatchView B, ErrModelView EM, Qs
                 // first a with w < cdf[a], else the last entry; the per-row guide table gives the first candidate
                 // for the 64-quantile bucket of w, the scan from there ends within a step or two
                 uint32_t a2 = QM.guide[(size_t)row * 64 + (w >> 26)];
-                uint2 pr = QM.pairs[roff + a2];
-                while (a2 + 1 < rcnt && !(w < pr.x)) { a2++; pr = QM.pairs[roff + a2]; }
-                q = (uint8_t)pr.y;
+                if (QM.guide_direct && (a2 & 0x80u)) q = (uint8_t)(a2 & 0x7fu);       // every draw of this bucket picks the same entry
+                else {
+                    uint2 pr = QM.pairs[roff + a2];
+                    while (a2 + 1 < rcnt && !(w < pr.x)) { a2++; pr = QM.pairs[roff + a2]; }
+                    q = (uint8_t)pr.y;
+                }
             }
             out_qual[i2 - lo] = (uint8_t)(q + 33);
         }
