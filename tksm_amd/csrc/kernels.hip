@@ -980,7 +980,9 @@ DEV uint32_t early_bin(int L, double target) {
     return (uint32_t)min(255, max(0, (int)(8.0f * __log2f(1.0f + sc))));
 }
 // ---- k_init: splice (S1), flanks, target identity, 2-bit planes of the fragment, classification
-__global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
+// (eight waves per SIMD: 52 registers, no spills -- once the modification loop below is kept from unrolling; the compiler's own choice was 99
+// registers, four waves: 7.35 -> ~6 ms per step)
+__global__ __launch_bounds__(256, 8) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
                                                SimBuffers O, FastBuffers FB) {
 #ifndef TKSM_ABLATE
     __builtin_amdgcn_s_setprio(2);                            // (a latency-bound kernel beside the alignment kernel's always-ready waves: see k_loopw)
@@ -1003,6 +1005,8 @@ __global__ __launch_bounds__(256) void k_init(BatchView B, RefView R, ErrModelVi
             for (uint32_t t0 = 16u * lane; t0 < (uint32_t)len; t0 += 1024u)
                 splice_piece(B, R, iv.gbase + iv.s, (uint32_t)len, iv.literal, iv.minus, t0, frag + o + t0);
             wave_sync();
+            // (not unrolled: with eight iterations' loads in flight the kernel took 99 registers -- four waves per SIMD -- instead of 80 -- six)
+#pragma unroll 1
             for (uint32_t mi = iv.mod_begin; mi < iv.mod_end; mi++) {
                 const uint32_t mp = B.mods[2ull * mi], mc = B.mods[2ull * mi + 1];
                 if (mp >= (uint32_t)len) { status |= 2; continue; }
