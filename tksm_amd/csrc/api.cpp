@@ -73,7 +73,7 @@ int tksmseq_clone(const tksmseq_ctx* src, tksmseq_ctx** out) {
     c->total_alloc = src->total_alloc; c->total_bases = src->total_bases; c->pool_blocks = src->pool_blocks;
     c->d_packed.borrow(src->d_packed); c->d_blocktab.borrow(src->d_blocktab); c->d_pool.borrow(src->d_pool); c->d_contigs.borrow(src->d_contigs);
     c->em = src->em; c->qm = src->qm; c->idm = src->idm; c->em_uniform = src->em_uniform; c->em_alt0 = src->em_alt0;
-    c->d_pself.borrow(src->d_pself); c->d_pseg.borrow(src->d_pseg); c->d_cdf32.borrow(src->d_cdf32); c->d_cdf.borrow(src->d_cdf); c->d_alts.borrow(src->d_alts); c->d_altenc.borrow(src->d_altenc);
+    c->d_pself.borrow(src->d_pself); c->d_pseg.borrow(src->d_pseg); c->d_pt0.borrow(src->d_pt0); c->d_cdf32.borrow(src->d_cdf32); c->d_cdf.borrow(src->d_cdf); c->d_alts.borrow(src->d_alts); c->d_altenc.borrow(src->d_altenc);
     c->d_nalts.borrow(src->d_nalts); c->d_qkeys.borrow(src->d_qkeys); c->d_qoff.borrow(src->d_qoff); c->d_qcnt.borrow(src->d_qcnt);
     c->d_qcdf.borrow(src->d_qcdf); c->d_qq.borrow(src->d_qq); c->d_qtab.borrow(src->d_qtab); c->d_qent.borrow(src->d_qent);
     c->d_qpairs.borrow(src->d_qpairs); c->d_qguide.borrow(src->d_qguide);
@@ -257,6 +257,9 @@ int tksmseq_load_error_model(tksmseq_ctx* ctx, const char* name_or_path) {
         std::vector<uint32_t> sg(nk * 4);                     // thresholds 0, 8, 16, 24 of every row (kernels.h ErrModelView::pseg)
         for (size_t i = 0; i < nk; i++) for (int q = 0; q < 4; q++) sg[4 * i + q] = c32[i * 32 + 8 * q];
         if ((rc = upload(ctx, ctx->d_pseg, sg))) return rc;
+        std::vector<uint32_t> t0(nk);
+        for (size_t i = 0; i < nk; i++) t0[i] = c32[i * 32];
+        if ((rc = upload(ctx, ctx->d_pt0, t0))) return rc;
     }
     if ((rc = upload(ctx, ctx->d_alts, ctx->em.alts))) return rc;
     {
@@ -678,7 +681,7 @@ static int run_once(tksmseq_ctx* ctx, tksmseq_batch* b, const tksmseq_run_params
 
     const tk::BatchView B = batch_view(b);
     const tk::RefView R = ref_view(ctx);
-    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>(), ctx->d_pseg.as<uint4>(), ctx->d_altenc.as<uint4>()};
+    tk::ErrModelView EM{ctx->em.type, k, ctx->em.max_alts, ctx->em_alt0 ? 1 : 0, ctx->em_uniform ? 1 : 0, ctx->d_cdf.as<uint32_t>(), ctx->d_alts.as<uint64_t>(), ctx->d_nalts.as<uint8_t>(), ctx->d_pself.as<uint2>(), ctx->d_cdf32.as<uint32_t>(), ctx->d_pseg.as<uint4>(), ctx->d_pt0.as<uint32_t>(), ctx->d_altenc.as<uint4>()};
     tk::QsModelView QM{ctx->qm.n_slots, ctx->qm.kmer_size, ctx->d_qkeys.as<uint64_t>(), ctx->d_qoff.as<uint32_t>(),
                        ctx->d_qcnt.as<uint32_t>(), ctx->d_qcdf.as<uint32_t>(), ctx->d_qq.as<uint8_t>(), ctx->d_qent.as<uint4>(),
                        ctx->d_qpairs.as<uint2>(), ctx->d_qguide.as<uint8_t>(), ctx->qm.guide_direct ? 1 : 0};

@@ -193,7 +193,7 @@ struct tksmseq_ctx : ContigLookup {
     bool em_uniform = false, em_alt0 = false;
     TailModelHost tail; uint64_t tail_version = 0;
     DevBuf d_tail_lx, d_tail_ly, d_tail_cdf, d_tail_chain;
-    DevBuf d_pself, d_pseg, d_cdf32, d_cdf, d_alts, d_altenc, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
+    DevBuf d_pself, d_pseg, d_pt0, d_cdf32, d_cdf, d_alts, d_altenc, d_nalts, d_qkeys, d_qoff, d_qcnt, d_qcdf, d_qq, d_qtab, d_qent, d_qpairs, d_qguide;
 
     // per-run work buffers
     DevBuf w_rawlen, w_slotcap, w_slotoff, w_outlen, w_ident, w_reclen, w_recoff, w_status, w_scan, w_trace, w_counter,

@@ -40,6 +40,7 @@ struct ErrModelView {
     const uint32_t* cdf32;  // [4^k][32] the same thresholds padded to 128-byte rows (max_alts <= 32 only)
     const uint4* pseg;      // [4^k] thresholds 0, 8, 16 and 24 of every row: a draw's first-level lookup in k_loop (k-mer itself /
                             // which 8-threshold segment of cdf32 to read)
+    const uint32_t* pt0;    // [4^k] threshold 0 alone (64 KB): what EVERY draw of k_loop looks at first (four times as many entries per cache line as pseg)
     const uint4* alts_enc;  // [4^k][max_alts] the alternatives as the fast pipeline applies them: eight 16-bit slot
                             // encodings (length << 12 | 2-bit codes), bit 15 = the slot differs from the k-mer's base
 };

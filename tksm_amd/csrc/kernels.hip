@@ -1338,9 +1338,9 @@ __global__ __launch_bounds__(64) void k_loop(ErrModelView EM, SimParams P, FastB
                 const uint32_t kx = (uint32_t)(mk64(hi, lo) >> (64 - 2 * o - 2 * k)) & kmask;
                 ldi[b * 64 + lane] = (uint32_t)di1;
 #ifdef TKSM_ABLATE
-                t0v[b] = abl_t0 ? 0xCF000000u : EM.pseg[kx].x;
+                t0v[b] = abl_t0 ? 0xCF000000u : EM.pt0[kx];
 #else
-                t0v[b] = EM.pseg[kx].x;
+                t0v[b] = EM.pt0[kx];
 #endif
             }
 #pragma unroll
