@@ -2318,8 +2318,10 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
             if constexpr (ROWS == 14) {
                 tw[q & 7] = ent0;
                 if ((q & 7) == 7) {                               // half a line at a time
-                    uint4* d = dl + 2 * (q >> 3);
-                    d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[1] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
+                    // (the four 16-byte pieces of a lane's line lie 64 pieces apart -- [wave][line][piece][lane] --: one store instruction
+                    // of the wave writes 1 KB of consecutive bytes, whole cache lines, instead of a quarter of each of 64 lines)
+                    uint4* d = dl + 128 * (q >> 3);
+                    d[0] = make_uint4(tw[0], tw[1], tw[2], tw[3]); d[64] = make_uint4(tw[4], tw[5], tw[6], tw[7]);
                 }
             } else {
                 tw[4 * (q & 3)] = ent0; tw[4 * (q & 3) + 1] = ent1; tw[4 * (q & 3) + 2] = ent2; tw[4 * (q & 3) + 3] = ent3;
@@ -2421,7 +2423,8 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     uint4 la0, la1, la2, la3, lb0, lb1, lb2, lb3;
     auto load_line = [&](int q, uint4& l0, uint4& l1, uint4& l2, uint4& l3) {
         const uint4* p = trl + (size_t)max(q, 0) * ls;
-        l0 = p[0]; l1 = p[1]; l2 = p[2]; l3 = p[3];
+        if constexpr (ROWS == 14) { l0 = p[0]; l1 = p[64]; l2 = p[128]; l3 = p[192]; }
+        else { l0 = p[0]; l1 = p[1]; l2 = p[2]; l3 = p[3]; }
     };
     uint4 sw = make_uint4(0u, 0u, 0u, 0u), swn = sw;               // all rows: the shift bytes of the current pass, of the pass below it
     auto load_shifts = [&](int pi) { return trl[(size_t)(cl + (max(pi, 0) >> 2)) * ls + (max(pi, 0) & 3)]; };
@@ -2544,7 +2547,7 @@ __global__ __launch_bounds__(64, ROWS == 64 ? 3 : ALNF_WAVES) ALNF_VGPR_CAP void
             const RangeGeo G = FB.geo_cur[rng];
             const uint32_t rel = job - rbase;
             tg = (int)G.tstride;
-            trl = reinterpret_cast<uint4*>(FB.trace) + (G.trace_off + (size_t)(rel >> 6) * G.tstride * 64 + (rel & 63u)) * 4;
+            trl = reinterpret_cast<uint4*>(FB.trace) + (G.trace_off + (size_t)(rel >> 6) * G.tstride * 64) * 4 + (rel & 63u);
         }
         load_job_f(FB, job, rng, act || norow, J, r, mcap);
         // a q-score alignment covers the whole read: one over thousands of columns leaves the 14 stored rows somewhere with near
