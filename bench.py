@@ -239,6 +239,8 @@ def main():
         # processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1); rank 0's JSON line reaches our stdout as it is
         sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:      # (before anything slow: a launcher that stops all ranks when the first one fails still shows that every rank started)
+        print(f"[bench] rank {os.environ.get('RANK', '0')} of {world} started (local rank {os.environ.get('LOCAL_RANK', '0')})", file=sys.stderr, flush=True)
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with --gpus N (or leave WORLD_SIZE unset and bench.py starts them)")
     # stdout carries the one JSON line and nothing else: libraries that print while they initialise (RCCL) go to stderr

@@ -40,7 +40,9 @@ def test_launcher_starts_one_rank_per_gpu():
         pytest.skip("a GPU is present: the GPU tests start real ranks")
     r = _bench("--gpus", "2", "--no-cpu-baseline", env={"TKSM_BENCH_SKIP_DEVICE_CHECK": "1"}, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
-    assert r.stderr.count("bench.py needs a GPU: the Seq hot path has no CPU fallback") == 2, r.stderr[-1500:]
+    # (the launcher stops the other rank as soon as the first one has failed: both must have STARTED, at least one reaches the check)
+    assert "[bench] rank 0 of 2 started" in r.stderr and "[bench] rank 1 of 2 started" in r.stderr, r.stderr[-1500:]
+    assert r.stderr.count("bench.py needs a GPU: the Seq hot path has no CPU fallback") >= 1, r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("kind", ["bulk", "pcr", "scrna"])
