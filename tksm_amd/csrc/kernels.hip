@@ -2136,8 +2136,9 @@ DEV void list_append(uint32_t* list, uint32_t* counter, bool want, uint32_t job,
 // the window wait in a 64-bit reservoir per plane, refilled by 32 rows every 32 slots (the same rows for all lanes: unconditional
 // loads).  The loop body is branch-free but for the pop's `if`, and every memory operation is unconditional.
 // Predecessor codes are stored PER ITERATION (the iteration index is wave-uniform, the column index is not): one u32 per
-// iteration = 14 band rows x 2 bits + the column's window shift (4 bits; 15 + codes 0 = no column in this iteration, all ones
-// = a shift the field cannot hold), 16 iterations per 64-byte line, the lines of a wave's 64 jobs interleaved ([wave][line][lane]),
+// iteration = 14 band rows x 2 bits + the column's window shift (4 bits; 15 + codes 0 = no column in this iteration; a job with
+// a shift the field cannot hold, >= 15, is redone with all rows whatever its entries say: the lane's largest shift is kept beside them),
+// 16 iterations per 64 bytes, the pieces of a wave's 64 jobs interleaved ([wave][line][16-byte piece][lane]),
 // so the walk back needs nothing but its code lines.  Stored rows: st .. st + 13 around the generative row, which sits at bit 31
 // once the window moves and climbs from bit 0 while it is still clamped at row 1 (st = clamp(iteration - 7, 0, 24)).  14 rows
 // (offsets -7 .. +6 from the generative row) miss 1.9 % of the bulk and 5.4 % of the polyA-tailed alignments (tools/band_rows.py
@@ -2149,7 +2150,7 @@ DEV void list_append(uint32_t* list, uint32_t* counter, bool want, uint32_t job,
 // find-first-bit on the column's "not up" bits.  Only the stored-row index `bs` of the current cell is tracked at iterations
 // >= 32 (matches and diagonal moves are counted, columns = n + m - diagonals); below (window possibly clamped at row 1, st
 // ramps) row and window position are tracked as well: there the path may reach row 0, after which only left moves remain.
-constexpr uint32_t ENT_EMPTY = 0xF0000000u, ENT_ESC = 0xFFFFFFFFu;
+constexpr uint32_t ENT_EMPTY = 0xF0000000u;
 constexpr int BACKLOG_DRAIN = 20;
 struct AlnJobF {
     bool act; int p0, n;
@@ -2254,7 +2255,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 const int tn = max(1, pcol - 30);
                 const uint32_t sh = (uint32_t)(tn - t);
                 t = tn;
-                if constexpr (ROWS == 64) shmax = max(shmax, (int)sh);   // (14 stored rows: a shift >= 15 is an escape entry, and the job is redone here)
+                shmax = max(shmax, (int)sh);                     // (14 stored rows: the entry's shift field holds 0 .. 14; a job with a larger one is redone with all rows)
                 const uint32_t cl = (uint32_t)__builtin_amdgcn_sbfe((int)qlo, 0u, 1u), ch = (uint32_t)__builtin_amdgcn_sbfe((int)qhi, 0u, 1u);
                 qlo >>= 1; qhi >>= 1; npend--; col++;
                 const bool g = t > 1;
@@ -2309,7 +2310,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                     const uint32_t c0 = alignbit(hi32(w0), lo32(w0), st), c1 = alignbit(hi32(w1), lo32(w1), st);
                     const uint32_t c1s = c1 << 14;
                     const uint32_t c01 = ((c0 & 0x3fffu) | (c1s & ~0x3fffu)) & 0x0fffffffu;      // (a bit-field insert and an and-or)
-                    ent0 = sh >= 15u ? ENT_ESC : (c01 | (sh << 28));
+                    ent0 = c01 | (min(sh, 15u) << 28);            // (sh >= 15: whatever the entry looks like, shmax sends the job to the full-width pass)
                 } else {
                     ent0 = lo32(w0); ent1 = hi32(w0); ent2 = lo32(w1); ent3 = hi32(w1);
                     shb = min(sh, 254u);
@@ -2368,15 +2369,15 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
     // ---- walk back from (n, m): all lanes in lockstep over the ITERATIONS; an entry without a column is skipped by its lane, a
     // lane joins at its own last column
     const uint32_t why = (bad ? 1u : 0u) | (shmax > 31 ? 8u : 0u) | (shmax > 14 ? 16u : 0u) | ((act && m > 0 && (n - t > 63 || n - t < 0)) ? 32u : 0u);
-    bad = bad || shmax > 31;
-    bool fail = act && m > 0 && (n - t > 63 || n - t < 0 || bad), needfull = false;
-    bool live = act && !fail && m > 0 && !ovf;
+    bad = bad || (ROWS == 64 && shmax > 31);                      // (the 14-row pass only hands such a job on)
+    bool fail = act && m > 0 && (n - t > 63 || n - t < 0 || bad), needfull = ROWS == 14 && act && shmax > 14;
+    bool live = act && !fail && m > 0 && !ovf && !needfull;
     uint32_t mt = 0, dg = 0;
     int bs = n - t - ST;
     int i = n, tt = t;                                            // used below iteration 32 only
     int c = m - 1;                                                // the lane's current column (q-score jobs: where its op byte goes)
     unsigned long long acc = 0ull;
-    auto walk_ent = [&](int it, auto ramp, auto lo, auto hi, uint32_t shc, bool is_col, bool is_esc) {
+    auto walk_ent = [&](int it, auto ramp, auto lo, auto hi, uint32_t shc, bool is_col) {
         constexpr bool RAMP = decltype(ramp)::value;
         if (live && is_col) {
             if (RAMP) bs = i - tt - (min(max(it, RAMP0), 31) - RAMP0);
@@ -2398,7 +2399,7 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 ok |= i == 0;
             }
             const int bs2 = bs - (int)run;
-            ok &= (bs2 >= 0 || zero) && !is_esc;
+            ok &= bs2 >= 0 || zero;
             const uint32_t lb = zero ? 1u : (uint32_t)(lo >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;
             const uint32_t hb = zero ? 0u : (uint32_t)(hi >> (bs2 & (ROWS == 64 ? 63 : 31))) & 1u;     // lb | hb << 1: 1 left, 2 diagonal mismatch, 3 diagonal match
             needfull |= !ok;
@@ -2441,10 +2442,10 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
             for (int e = NC - 1; e >= 0; e--) {
                 if constexpr (ROWS == 14) {
                     const uint32_t v = w[e];
-                    walk_ent(cq + e, ramp, v, v >> 14, v >> 28, v != ENT_EMPTY, v == ENT_ESC);
+                    walk_ent(cq + e, ramp, v, v >> 14, v >> 28, v != ENT_EMPTY);
                 } else {
                     const uint32_t shc = (swq >> (8 * e)) & 0xffu;
-                    walk_ent(cq + e, ramp, mk64(w[4 * e + 1], w[4 * e]), mk64(w[4 * e + 3], w[4 * e + 2]), shc, shc != 0xffu, false);
+                    walk_ent(cq + e, ramp, mk64(w[4 * e + 1], w[4 * e]), mk64(w[4 * e + 3], w[4 * e + 2]), shc, shc != 0xffu);
                 }
             }
         };
