@@ -2294,9 +2294,6 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                 const unsigned long long Mhs = mk64(alignbit(hi32(Mh), lo32(Mh), 31u), lo32(Mh) << 1);
                 Pv = bool3<BOOL3(TA | ~(TB | TC))>(Mhs, Xv, Phs);
                 Mv = Phs & Xv;
-                const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
-                const unsigned long long w1 = bool3<BOOL3(~(TA | TB))>(upv, Ph, 0ull);
-                const unsigned long long w0 = MODE ? bool3<BOOL3(TB | (~TA & TC))>(upv, Ph, D0) : bool3<BOOL3(~TA & (TB | TC))>(upv, Ph, D0);
                 if constexpr (ROWS == 14) {
                     // stored rows st .. st + 13, st = clamp(iteration - RAMP0, 0, ST): a function of the iteration alone
                     // (on the scalar unit: the compiler fuses min(max()) into a vector v_med3_i32 and reads it back)
@@ -2307,11 +2304,19 @@ DEV AlnResF aln_fused(const AlnJobF& J, uint4* trl, int tg, int cl, uint32_t ls,
                     asm("s_max_i32 %0, %1, %2\n\ts_min_i32 %0, %0, 31" : "=&s"(st_s) : "s"(it0 + q), "i"(RAMP0) : "scc");
 #endif
                     const uint32_t st = (uint32_t)(st_s - RAMP0);
-                    const uint32_t c0 = alignbit(hi32(w0), lo32(w0), st), c1 = alignbit(hi32(w1), lo32(w1), st);
+                    // the two code bits of the stored rows only: the 32-bit windows [st, st + 32) of Pv, Ph and D0 first, the logic on those.
+                    // ("row above the window unreachable" -- bit 0 of Pv cleared when t > 1 -- cannot touch a stored row: bit 0 is stored
+                    // only while st == 0, i.e. in the first RAMP0 + 1 iterations, whose columns belong to slots < 32: t is still 1 there)
+                    const uint32_t PvW = alignbit(hi32(Pv), lo32(Pv), st), PhW = alignbit(hi32(Ph), lo32(Ph), st), D0W = alignbit(hi32(D0), lo32(D0), st);
+                    const uint32_t c1 = bool3<BOOL3(~(TA | TB))>(PvW, PhW, 0u);
+                    const uint32_t c0 = MODE ? bool3<BOOL3(TB | (~TA & TC))>(PvW, PhW, D0W) : bool3<BOOL3(~TA & (TB | TC))>(PvW, PhW, D0W);
                     const uint32_t c1s = c1 << 14;
                     const uint32_t c01 = ((c0 & 0x3fffu) | (c1s & ~0x3fffu)) & 0x0fffffffu;      // (a bit-field insert and an and-or)
                     ent0 = c01 | (min(sh, 15u) << 28);            // (sh >= 15: whatever the entry looks like, shmax sends the job to the full-width pass)
                 } else {
+                    const unsigned long long upv = Pv & ~(g ? 1ull : 0ull);
+                    const unsigned long long w1 = bool3<BOOL3(~(TA | TB))>(upv, Ph, 0ull);
+                    const unsigned long long w0 = MODE ? bool3<BOOL3(TB | (~TA & TC))>(upv, Ph, D0) : bool3<BOOL3(~TA & (TB | TC))>(upv, Ph, D0);
                     ent0 = lo32(w0); ent1 = hi32(w0); ent2 = lo32(w1); ent3 = hi32(w1);
                     shb = min(sh, 254u);
                 }
