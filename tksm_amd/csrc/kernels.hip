@@ -980,9 +980,9 @@ DEV uint32_t early_bin(int L, double target) {
     return (uint32_t)min(255, max(0, (int)(8.0f * __log2f(1.0f + sc))));
 }
 // ---- k_init: splice (S1), flanks, target identity, 2-bit planes of the fragment, classification
-// (eight waves per SIMD: 52 registers, no spills -- once the modification loop below is kept from unrolling; the compiler's own choice was 99
-// registers, four waves: 7.35 -> ~6 ms per step)
-__global__ __launch_bounds__(256, 8) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
+// (seven waves per SIMD: 71 registers, no spills -- once the modification loop below is kept from unrolling; the compiler's own choice was 99
+// registers, four waves: 7.35 -> 5 ms per step.  Eight waves -- 52 registers -- spill six since the literal segments have a path of their own)
+__global__ __launch_bounds__(256, 7) void k_init(BatchView B, RefView R, ErrModelView EM, IdentView IM, SimParams P,
                                                SimBuffers O, FastBuffers FB) {
 #ifndef TKSM_ABLATE
     __builtin_amdgcn_s_setprio(2);                            // (a latency-bound kernel beside the alignment kernel's always-ready waves: see k_loopw)
@@ -1002,8 +1002,17 @@ __global__ __launch_bounds__(256, 8) void k_init(BatchView B, RefView R, ErrMode
         for (uint32_t ii = 0; ii < ic; ii++) {
             const Ivl iv = load_interval(B, R, ib + ii);
             const int len = (int)iv.len;
+            if (iv.literal) {
+                // literal segments (barcode, UMI, polyA: tens of bytes): a byte per lane -- as 16-byte pieces a single lane copied a barcode one
+                // dependent byte load after the other, three literals of an scRNA-like molecule cost as much as the rest of the kernel
+                const uint64_t lg = iv.gbase + iv.s;
+                for (uint32_t t = (uint32_t)lane; t < (uint32_t)len; t += 64u) {
+                    const uint8_t bch = upper(B.litpool[lg + (iv.minus ? (uint32_t)len - 1u - t : t)]);
+                    frag[o + t] = iv.minus ? comp(bch) : bch;
+                }
+            } else
             for (uint32_t t0 = 16u * lane; t0 < (uint32_t)len; t0 += 1024u)
-                splice_piece(B, R, iv.gbase + iv.s, (uint32_t)len, iv.literal, iv.minus, t0, frag + o + t0);
+                splice_piece(B, R, iv.gbase + iv.s, (uint32_t)len, false, iv.minus, t0, frag + o + t0);
             wave_sync();
             // (not unrolled: with eight iterations' loads in flight the kernel took 99 registers -- four waves per SIMD -- instead of 80 -- six)
 #pragma unroll 1
